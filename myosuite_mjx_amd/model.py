@@ -1,0 +1,98 @@
+"""Compiled-model container: arrays (mjModel naming) + names, (de)serialised as a
+MYOB blob (`blob.py`) plus a JSON name side-car.
+
+The MJCF sources live in the reference tree, which does not exist on the GPU box, so the
+compiled blobs for the config models are committed under `myosuite_mjx_amd/assets/`
+(data, produced by `tools/compile_models.py` from the reference's model files)."""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from . import blob as _blob
+
+ASSET_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+
+
+class Model:
+    def __init__(self, arrays: dict, names: dict, source: str = ""):
+        self.arrays = arrays
+        self.names = names
+        self.source = source
+        self._blob = None
+
+    def __getattr__(self, k):
+        arrays = self.__dict__.get("arrays", {})
+        if k in arrays:
+            return arrays[k]
+        raise AttributeError(k)
+
+    # sizes, mjModel style
+    @property
+    def nq(self): return int(self.arrays["sizes"][0])
+    @property
+    def nv(self): return int(self.arrays["sizes"][1])
+    @property
+    def nu(self): return int(self.arrays["sizes"][2])
+    @property
+    def na(self): return int(self.arrays["sizes"][3])
+    @property
+    def nbody(self): return int(self.arrays["sizes"][4])
+    @property
+    def njnt(self): return int(self.arrays["sizes"][5])
+    @property
+    def ngeom(self): return int(self.arrays["sizes"][6])
+    @property
+    def nsite(self): return int(self.arrays["sizes"][7])
+    @property
+    def ntendon(self): return int(self.arrays["sizes"][8])
+    @property
+    def timestep(self): return float(self.arrays["opt"][0])
+
+    def name2id(self, kind, name):
+        return self.names[kind].index(name)
+
+    def blob(self) -> bytes:
+        if self._blob is None:
+            self._blob = _blob.pack(self.arrays)
+        return self._blob
+
+    def save(self, stem):
+        with open(stem + ".myob", "wb") as f:
+            f.write(self.blob())
+        with open(stem + ".json", "w") as f:
+            json.dump({"names": self.names, "source": os.path.basename(self.source)}, f)
+
+    @classmethod
+    def load(cls, stem):
+        with open(stem + ".myob", "rb") as f:
+            b = f.read()
+        with open(stem + ".json") as f:
+            meta = json.load(f)
+        m = cls(_blob.unpack(b), meta["names"], meta.get("source", ""))
+        m._blob = b
+        return m
+
+
+def from_mjcf(path) -> Model:
+    """Compile an MJCF file (needs the reference tree; not available on the GPU box)."""
+    from .mjcf import compile_mjcf
+    from .setconst import set_constants
+    from .lowering import lower
+    cm = compile_mjcf(path)
+    set_constants(cm)
+    lower(cm)
+    return Model(cm.arrays, cm.names, path)
+
+
+_ASSETS = {"myohand_pose": "myohand_pose", "myofinger_v0": "myofinger_v0"}
+
+
+def load_asset(name) -> Model:
+    """Load a committed compiled model by stem (e.g. 'myohand_pose')."""
+    stem = os.path.join(ASSET_DIR, name)
+    if not os.path.exists(stem + ".myob"):
+        raise FileNotFoundError(f"compiled model {name!r} not found under {ASSET_DIR}; run tools/compile_models.py")
+    return Model.load(stem)

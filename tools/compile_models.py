@@ -1,0 +1,24 @@
+"""Compile the reference's MJCF config models into committed MYOB blobs.
+
+Runs in the build container only (reads the model *data* files under /root/reference;
+they do not travel to the GPU box).  Usage: python tools/compile_models.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from myosuite_mjx_amd import model as M  # noqa: E402
+
+REF = os.environ.get("MYO_REFERENCE", "/root/reference")
+MODELS = {
+    "myohand_pose": "myosuite/envs/myo/assets/hand/myohand_pose.xml",
+    "myofinger_v0": "myosuite/simhive/myo_sim/finger/myofinger_v0.xml",
+}
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    for stem, rel in MODELS.items():
+        if only and stem not in only:
+            continue
+        m = M.from_mjcf(os.path.join(REF, rel))
+        m.save(os.path.join(M.ASSET_DIR, stem))
+        print(stem, dict(nq=m.nq, nv=m.nv, nu=m.nu, nbody=m.nbody, ntendon=m.ntendon, bytes=len(m.blob())))
