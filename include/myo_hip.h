@@ -1,0 +1,128 @@
+/* myo_hip.h -- C ABI of libmyo_hip.so: the MI355X-native batched musculoskeletal stepper.
+ *
+ * Drop-in boundary for the reference's sim-backend / MJX step path.  Each entry point names
+ * the reference interface it replaces (paths relative to /root/reference/myosuite/):
+ *
+ *   myo_model_load   <- mjx.put_model(mj_model)                 mjx/play.py:10
+ *                       DMSimScene._load_simulation             physics/mj_sim_scene.py:28-49
+ *   myo_batch_create <- mjx.put_data(m, d) (vmapped Data)        mjx/play.py:11
+ *   myo_reset        <- Robot.reset / PoseEnvV0.reset            robot/robot.py:913-998, envs/myo/myobase/pose_v0.py:172-255
+ *   myo_set_state /
+ *   myo_get_state    <- SimScene.set_state/get_state             physics/sim_scene.py:145-166, envs/env_base.py:643-705
+ *   myo_step         <- BaseV0.step -> Robot.step -> sim.advance envs/myo/base_v0.py:83-119, robot/robot.py:844-910,
+ *                       -> Physics.step(substeps)                physics/mj_sim_scene.py:51-65 ; jit(mjx.step) mjx/play.py:41,47
+ *   myo_obs          <- MujocoEnv.get_obs / get_obs_dict / get_reward_dict / obsdict2obsvec
+ *                       envs/env_base.py:392-417, envs/myo/myobase/pose_v0.py:98-138, reach_v0.py:88-144,
+ *                       envs/obs_vec_dict.py:86-98
+ *   myo_status       <- DMSimScene.advance's exception-and-reset path  physics/mj_sim_scene.py:54-61
+ *
+ * Conventions: every function returns 0 on success or a negative MYO_E_* code and never throws
+ * or aborts; myo_last_error() gives a thread-local message.  All device arrays are env-major
+ * float32: element (env e, index i) of a field lives at ptr[e * pitch + i].  Functions taking a
+ * `stream` are asynchronous on that hipStream_t (NULL = default stream).  One host thread per
+ * myo_batch.  No torch types anywhere in this ABI.
+ */
+#ifndef MYO_HIP_H
+#define MYO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct myo_model myo_model;
+typedef struct myo_batch myo_batch;
+
+enum { MYO_OK = 0, MYO_E_ARG = -1, MYO_E_BLOB = -2, MYO_E_HIP = -3, MYO_E_UNSUPPORTED = -4, MYO_E_NOMEM = -5 };
+
+typedef struct myo_dims {
+  int nq, nv, nu, na, nbody, ntendon, nsite, nlink, obs_dim, env_lds_bytes, lanes_per_env, ncon_max;
+  float timestep;
+} myo_dims;
+
+/* per-env state / output fields (all float32 unless noted) */
+typedef enum myo_field {
+  MYO_F_QPOS = 0,    /* [B][nq] */
+  MYO_F_QVEL,        /* [B][nv] */
+  MYO_F_ACT,         /* [B][na] */
+  MYO_F_CTRL,        /* [B][nu]  last applied control (after the action map) */
+  MYO_F_WARMSTART,   /* [B][nv]  qacc_warmstart */
+  MYO_F_TIME,        /* [B][1] */
+  MYO_F_TARGET,      /* [B][ntarget] pose: target joint vector; reach: target tip positions */
+  MYO_F_OBS,         /* [B][obs_dim] */
+  MYO_F_REWARD,      /* [B][1] dense reward */
+  MYO_F_DONE,        /* [B][1] 1.0f if done */
+  MYO_F_SOLVED,      /* [B][1] 1.0f if solved */
+  MYO_F_FLAGS,       /* [B][1] int32 bit flags, see MYO_FLAG_* */
+  MYO_F_DIAG,        /* [B][8] int32 diagnostics: nefc, ncon, solver_iter(max over substeps), ncon_dropped, ... */
+  MYO_F_QACC,        /* [B][nv]  qacc of the last substep (diagnostic / parity) */
+  MYO_F_TENLEN,      /* [B][nu]  actuator (tendon) lengths of the last substep */
+  MYO_F_ACTFORCE,    /* [B][nu]  actuator forces of the last substep */
+  MYO_F_SITEXPOS,    /* [B][3*ntip] tip site world positions after the step (reach task) */
+  MYO_F_COUNT
+} myo_field;
+
+enum { MYO_FLAG_BAD_STATE = 1, MYO_FLAG_BAD_QACC = 2, MYO_FLAG_CONTACT_OVERFLOW = 4, MYO_FLAG_CAND_OVERFLOW = 8 };
+
+/* action -> control map applied inside myo_step (base_v0.py:87-91) */
+enum { MYO_ACTMAP_NONE = 0, MYO_ACTMAP_MUSCLE_SIGMOID = 1 };
+
+/* tasks understood by myo_obs / myo_reset */
+typedef enum myo_task { MYO_TASK_NONE = 0, MYO_TASK_POSE = 1, MYO_TASK_REACH = 2 } myo_task;
+
+typedef struct myo_task_config {
+  int task;              /* myo_task */
+  int frame_skip;        /* substeps per env step; obs scales qvel by frame_skip*timestep */
+  int reset_random;      /* pose: 1 = qpos ~ U(jnt_range) (reset_type "random"), 0 = init_qpos */
+  int target_generate;   /* 1 = sample target ~ U(target_lo, target_hi) on reset, 0 = fixed (target_lo) */
+  int ntarget;           /* pose: nq; reach: 3*ntip */
+  int ntip;              /* reach: number of tip sites */
+  int tip_site[8];       /* reach: site ids (compiled-model numbering) */
+  float pose_thd, far_th, near_th;
+  float w_pose, w_bonus, w_act_reg, w_penalty, w_reach;
+  const float* target_lo; /* host pointers, ntarget floats each (copied) */
+  const float* target_hi;
+  const float* init_qpos; /* host pointer, nq floats (copied); NULL = qpos0 */
+} myo_task_config;
+
+const char* myo_last_error(void);
+int myo_version(void);
+
+int myo_model_load(const void* blob, size_t nbytes, int device, myo_model** out);
+void myo_model_free(myo_model*);
+int myo_model_dims(const myo_model*, myo_dims* out);
+/* test switches mirroring the oracle's (disable contacts / limits / ellipsoid pairs) */
+int myo_model_set_switch(myo_model*, int disable_contact, int disable_limit, int disable_ellipsoid);
+
+int myo_batch_create(const myo_model*, int B, myo_batch** out);
+void myo_batch_free(myo_batch*);
+int myo_batch_size(const myo_batch*);
+int myo_batch_configure(myo_batch*, const myo_task_config* cfg);
+/* device pointer + pitch (elements per env row) of a field */
+int myo_batch_field(myo_batch*, int field, void** dev_ptr, size_t* pitch, size_t* width);
+/* synchronous host copies (tests / plumbing without torch); host buffers are [B][width] */
+int myo_batch_read(myo_batch*, int field, void* host, size_t nbytes);
+int myo_batch_write(myo_batch*, int field, const void* host, size_t nbytes);
+
+/* reset envs whose mask byte is nonzero (mask == NULL: all); mask is a DEVICE pointer, B bytes */
+int myo_reset(myo_batch*, const uint8_t* mask_dev, uint64_t seed, void* stream);
+/* overwrite state from device arrays [B][n] (NULL = leave field unchanged) */
+int myo_set_state(myo_batch*, const float* qpos, const float* qvel, const float* act, const float* time, void* stream);
+/* one env step: ctrl = actmap(action[B][nu]) (action == NULL: keep MYO_F_CTRL), then nsubsteps physics substeps */
+int myo_step(myo_batch*, const float* action_dev, int actmap, int nsubsteps, void* stream);
+/* observation / reward / done for the configured task into MYO_F_OBS / REWARD / DONE / SOLVED */
+int myo_obs(myo_batch*, void* stream);
+/* copy per-env int32 flags to host and clear them */
+int myo_status(myo_batch*, int32_t* host_flags);
+/* fill action[B][nu] with U(-1,1) from a counter-based generator (seed, step, global env id) */
+int myo_random_action(myo_batch*, float* action_dev, uint64_t seed, uint64_t step, int env_offset, void* stream);
+int myo_sync(void* stream);
+
+/* timing helper for bench.py: run `steps` env steps (random actions, fused) on `stream` bracketed by HIP
+ * events recorded on that same stream; returns elapsed milliseconds in *ms_out */
+int myo_bench_rollout(myo_batch*, int steps, int nsubsteps, uint64_t seed, int with_obs, void* stream, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

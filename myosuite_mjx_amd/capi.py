@@ -1,0 +1,191 @@
+"""ctypes binding of libmyo_hip.so (include/myo_hip.h).  There is no CPU fallback: if the
+library is missing or no MI355X is visible, loading / model upload raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmyo_hip.so")
+SRC_PATH = os.path.join(_HERE, "csrc", "myo_hip.hip")
+
+# field ids (myo_field)
+(F_QPOS, F_QVEL, F_ACT, F_CTRL, F_WARMSTART, F_TIME, F_TARGET, F_OBS, F_REWARD, F_DONE, F_SOLVED, F_FLAGS, F_DIAG,
+ F_QACC, F_TENLEN, F_ACTFORCE, F_SITEXPOS) = range(17)
+INT_FIELDS = (F_FLAGS, F_DIAG)
+ACTMAP_NONE, ACTMAP_MUSCLE_SIGMOID = 0, 1
+TASK_NONE, TASK_POSE, TASK_REACH = 0, 1, 2
+FLAG_BAD_STATE, FLAG_BAD_QACC, FLAG_CONTACT_OVERFLOW, FLAG_CAND_OVERFLOW = 1, 2, 4, 8
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("nq", "nv", "nu", "na", "nbody", "ntendon", "nsite", "nlink", "obs_dim",
+                                       "env_lds_bytes", "lanes_per_env", "ncon_max")] + [("timestep", C.c_float)]
+
+
+class TaskConfig(C.Structure):
+    _fields_ = [("task", C.c_int), ("frame_skip", C.c_int), ("reset_random", C.c_int), ("target_generate", C.c_int),
+                ("ntarget", C.c_int), ("ntip", C.c_int), ("tip_site", C.c_int * 8),
+                ("pose_thd", C.c_float), ("far_th", C.c_float), ("near_th", C.c_float),
+                ("w_pose", C.c_float), ("w_bonus", C.c_float), ("w_act_reg", C.c_float), ("w_penalty", C.c_float),
+                ("w_reach", C.c_float),
+                ("target_lo", C.POINTER(C.c_float)), ("target_hi", C.POINTER(C.c_float)), ("init_qpos", C.POINTER(C.c_float))]
+
+
+def build_library(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> libmyo_hip.so next to this file (cross-compiles without a GPU)."""
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= os.path.getmtime(SRC_PATH):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH, SRC_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                               "(the HIP stepper has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.myo_last_error.restype = C.c_char_p
+        L.myo_model_load.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+        L.myo_model_free.argtypes = [C.c_void_p]
+        L.myo_model_dims.argtypes = [C.c_void_p, C.POINTER(Dims)]
+        L.myo_model_set_switch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.myo_batch_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.myo_batch_free.argtypes = [C.c_void_p]
+        L.myo_batch_size.argtypes = [C.c_void_p]
+        L.myo_batch_configure.argtypes = [C.c_void_p, C.POINTER(TaskConfig)]
+        L.myo_batch_field.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.myo_batch_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.myo_batch_write.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.myo_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.myo_set_state.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_void_p]
+        L.myo_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.myo_obs.argtypes = [C.c_void_p, C.c_void_p]
+        L.myo_status.argtypes = [C.c_void_p, C.c_void_p]
+        L.myo_random_action.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+        L.myo_sync.argtypes = [C.c_void_p]
+        L.myo_bench_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+        _lib = L
+    return _lib
+
+
+class MyoError(RuntimeError):
+    pass
+
+
+def _chk(rc):
+    if rc != 0:
+        raise MyoError(f"libmyo_hip error {rc}: {lib().myo_last_error().decode()}")
+
+
+class HipModel:
+    """Device-resident model (mjx.put_model counterpart, mjx/play.py:10)."""
+
+    def __init__(self, blob: bytes, device: int = 0):
+        self.h = C.c_void_p()
+        _chk(lib().myo_model_load(blob, len(blob), device, C.byref(self.h)))
+        self.dims = Dims()
+        _chk(lib().myo_model_dims(self.h, C.byref(self.dims)))
+        self.device = device
+
+    def set_switch(self, disable_contact=0, disable_limit=0, disable_ellipsoid=0):
+        _chk(lib().myo_model_set_switch(self.h, disable_contact, disable_limit, disable_ellipsoid))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().myo_model_free(self.h)
+        except Exception:
+            pass
+
+
+class HipBatch:
+    """B environments' state on the device (vmapped mjx.Data counterpart, mjx/play.py:11)."""
+
+    def __init__(self, model: HipModel, B: int):
+        self.model = model
+        self.B = B
+        self.h = C.c_void_p()
+        _chk(lib().myo_batch_create(model.h, B, C.byref(self.h)))
+        self._keep = None
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().myo_batch_free(self.h)
+        except Exception:
+            pass
+
+    def configure(self, task=TASK_NONE, frame_skip=1, reset_random=0, target_generate=0, target_lo=None, target_hi=None,
+                  init_qpos=None, tip_sites=(), pose_thd=0.35, far_th=2 * np.pi, near_th=0.0,
+                  w_pose=1.0, w_bonus=4.0, w_act_reg=1.0, w_penalty=50.0, w_reach=1.0):
+        c = TaskConfig()
+        c.task, c.frame_skip, c.reset_random, c.target_generate = task, frame_skip, int(reset_random), int(target_generate)
+        lo = np.ascontiguousarray(target_lo if target_lo is not None else [], np.float32)
+        hi = np.ascontiguousarray(target_hi if target_hi is not None else lo, np.float32)
+        c.ntarget = lo.size
+        c.ntip = len(tip_sites)
+        for i, s in enumerate(tip_sites):
+            c.tip_site[i] = int(s)
+        c.pose_thd, c.far_th, c.near_th = pose_thd, far_th, near_th
+        c.w_pose, c.w_bonus, c.w_act_reg, c.w_penalty, c.w_reach = w_pose, w_bonus, w_act_reg, w_penalty, w_reach
+        iq = np.ascontiguousarray(init_qpos, np.float32) if init_qpos is not None else None
+        self._keep = (lo, hi, iq)
+        c.target_lo = lo.ctypes.data_as(C.POINTER(C.c_float)) if lo.size else None
+        c.target_hi = hi.ctypes.data_as(C.POINTER(C.c_float)) if hi.size else None
+        c.init_qpos = iq.ctypes.data_as(C.POINTER(C.c_float)) if iq is not None else None
+        _chk(lib().myo_batch_configure(self.h, C.byref(c)))
+
+    def field_ptr(self, field):
+        p, pitch, width = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        _chk(lib().myo_batch_field(self.h, field, C.byref(p), C.byref(pitch), C.byref(width)))
+        return p.value, pitch.value, width.value
+
+    def read(self, field) -> np.ndarray:
+        _, _, width = self.field_ptr(field)
+        out = np.empty((self.B, width), np.int32 if field in INT_FIELDS else np.float32)
+        _chk(lib().myo_batch_read(self.h, field, out.ctypes.data, out.nbytes))
+        return out
+
+    def write(self, field, arr):
+        _, _, width = self.field_ptr(field)
+        a = np.ascontiguousarray(arr, np.int32 if field in INT_FIELDS else np.float32).reshape(self.B, width)
+        _chk(lib().myo_batch_write(self.h, field, a.ctypes.data, a.nbytes))
+
+    def reset(self, mask_ptr=None, seed=0, stream=None):
+        _chk(lib().myo_reset(self.h, mask_ptr, seed, stream))
+
+    def step(self, action_ptr=None, actmap=ACTMAP_NONE, nsub=1, stream=None):
+        _chk(lib().myo_step(self.h, action_ptr, actmap, nsub, stream))
+
+    def obs(self, stream=None):
+        _chk(lib().myo_obs(self.h, stream))
+
+    def status(self) -> np.ndarray:
+        out = np.zeros(self.B, np.int32)
+        _chk(lib().myo_status(self.h, out.ctypes.data))
+        return out
+
+    def random_action(self, action_ptr, seed, step, env_offset=0, stream=None):
+        _chk(lib().myo_random_action(self.h, action_ptr, seed, step, env_offset, stream))
+
+    def bench_rollout(self, steps, nsub, seed=0, with_obs=True, stream=None) -> float:
+        ms = C.c_float()
+        _chk(lib().myo_bench_rollout(self.h, steps, nsub, seed, int(with_obs), stream, C.byref(ms)))
+        return ms.value
+
+
+def sync(stream=None):
+    _chk(lib().myo_sync(stream))

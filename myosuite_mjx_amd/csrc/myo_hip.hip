@@ -1,0 +1,1863 @@
+// myo_hip.hip -- MI355X (gfx950) batched musculoskeletal stepper: kernels + C ABI (include/myo_hip.h).
+//
+// Execution model: one environment is stepped by a group of G=16 adjacent
+// lanes (one DPP row); a 64-lane wavefront therefore carries 4 environments and a workgroup is
+// exactly one wavefront, so every cross-lane hand-off is wave-synchronous.  The whole working set
+// of an environment (link frames, sparse tendon Jacobian rows, spatial inertias, mass matrix,
+// contact rows, Newton vectors) lives in that group's slice of LDS for all `nsubsteps` substeps;
+// HBM is read once (state + action) and written once (state) per env step.  Model constants are
+// shared by all lanes and are read through the scalar / L1 caches from `DevModel` tables produced
+// by myosuite_mjx_amd/lowering.py.
+//
+// Physics restated per substep (reference: third-party MuJoCo reached at
+// myosuite/physics/mj_sim_scene.py:55; algorithms per MuJoCo documentation [3P]):
+//   kinematics -> spatial tendons w/ wrapping -> muscle FLV forces -> CRB mass matrix + RNE bias ->
+//   collision (capsule/ellipsoid) -> joint-limit + pyramidal contact rows -> Newton solver ->
+//   semi-implicit Euler with implicit joint damping.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/myo_hip.h"
+
+#define MINVALF 1e-15f
+#define MAXVALF 1e10f
+#define MINIMPF 0.0001f
+#define MAXIMPF 0.9999f
+#define NCON 32   // contact slots per env
+#define NCAND 128 // broad-phase survivors per env
+#define KCMAX 8   // max dofs in a contact pair's jacobian (checked against the model at load)
+#define GEOM_SPHERE 2
+#define GEOM_CAPSULE 3
+#define GEOM_ELLIPSOID 4
+
+// ------------------------------------------------------------------------------------------------
+// device-side model: sizes + device pointers + LDS layout; passed by value as a kernel argument
+struct Lay {
+  int qpos, qvel, act, ctrl, warm;                       // persistent state
+  int lpos, lmat, lquat, axis, anchor;                   // kinematics
+  int tJ, tlen, tforce, actdot;                          // tendons / muscles
+  int cdof, cinert, crb, cvel, cacc, cfrc;               // spatial dynamics
+  int qfa, smooth, qas, qacc, Ma, grad, search, Mv, qfc; // nv-vectors
+  int Mp, Hp;                                            // packed lower-triangular matrices
+  int gpos, gmat, cand;                                  // collision geoms (world), broad-phase list
+  int cdist, cpos, cnrm, cpair, cJ, caref, cD, cjar, cjv, cimp; // contacts and their rows
+  int lsign, laref, lD, ljar, ljv;                       // joint-limit rows
+  int total;                                             // floats per env (padded)
+};
+
+struct DevModel {
+  int nl, nlevel, nv, nu, ngt, nseg, maxnnz, nwg, ncg, npair, maxkc, ns, nM;
+  int iterations, ls_iterations;
+  int disable_contact, disable_limit, disable_ellipsoid;
+  float timestep, grav[3], tolerance, ls_tolerance, meaninertia, c0[3];
+  const int *level_adr, *link_parent, *link_dofadr, *link_dofnum, *child_adr, *child, *dof_link, *dof_type, *dof_parent;
+  const int *site_link, *wg_link, *gt_seg_adr, *gt_seg_num, *gt_dofs, *seg, *dl, *col_adr, *col;
+  const int *cg_link, *cg_type, *pair_i, *pair_dl;
+  const float *link_pos, *link_quat, *link_mass, *link_com, *link_inertia, *dof_pos, *dof_axis, *qpos0, *dof_damping,
+      *dof_armature;
+  const float *site_lpos, *wg_lpos, *wg_lmat, *wg_radius, *seg_div, *act, *cg_lpos, *cg_lmat, *cg_size, *cg_rbound,
+      *pair_f, *jl;
+  Lay lay;
+};
+
+// per-batch device pointers (env-major, pitch = row length)
+struct DevBatch {
+  int B;
+  float *qpos, *qvel, *act, *ctrl, *warm, *time, *target, *obs, *reward, *done, *solved, *qacc, *tenlen, *actforce, *sitexpos;
+  int *flags, *diag;
+};
+
+struct TaskDev {
+  int task, frame_skip, reset_random, target_generate, ntarget, ntip, obs_dim;
+  int tip_site[8];
+  float pose_thd, far_th, near_th, w_pose, w_bonus, w_act_reg, w_penalty, w_reach;
+  const float *target_lo, *target_hi, *init_qpos, *jnt_lo, *jnt_hi;
+};
+
+// ------------------------------------------------------------------------------------------------
+// small device math
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void cross3(float* r, const float* a, const float* b) {
+  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ float norm3(const float* a) { return sqrtf(dot3(a, a)); }
+__device__ __forceinline__ float normalize3(float* a) {
+  float n = norm3(a);
+  if (n < MINVALF) { a[0] = 1; a[1] = 0; a[2] = 0; } else { float i = 1.0f / n; a[0] *= i; a[1] *= i; a[2] *= i; }
+  return n;
+}
+__device__ __forceinline__ float clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+__device__ __forceinline__ void quat2mat(float* R, const float* q) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = w * w + x * x - y * y - z * z; R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z); R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = w * w - x * x - y * y + z * z;
+}
+__device__ __forceinline__ void mulquat(float* r, const float* a, const float* b) {
+  float t0 = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  float t1 = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  float t2 = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  float t3 = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = t0; r[1] = t1; r[2] = t2; r[3] = t3;
+}
+__device__ __forceinline__ void matvec(float* r, const float* R, const float* v) {
+  float a = R[0] * v[0] + R[1] * v[1] + R[2] * v[2], b = R[3] * v[0] + R[4] * v[1] + R[5] * v[2],
+        c = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  r[0] = a; r[1] = b; r[2] = c;
+}
+__device__ __forceinline__ void matTvec(float* r, const float* R, const float* v) {
+  float a = R[0] * v[0] + R[3] * v[1] + R[6] * v[2], b = R[1] * v[0] + R[4] * v[1] + R[7] * v[2],
+        c = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+  r[0] = a; r[1] = b; r[2] = c;
+}
+__device__ __forceinline__ void matmul3(float* C, const float* A, const float* B) {
+  float t[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; i++) C[i] = t[i];
+}
+__device__ __forceinline__ int tri(int i, int j) { return (i * (i + 1)) / 2 + j; }  // j <= i
+
+template <int G> __device__ __forceinline__ float grp_sum(float x) {
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) x += __shfl_xor(x, m, G);
+  return x;
+}
+template <int G> __device__ __forceinline__ int grp_sumi(int x) {
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) x += __shfl_xor(x, m, G);
+  return x;
+}
+template <int G> __device__ __forceinline__ int grp_maxi(int x) {
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) x = max(x, __shfl_xor(x, m, G));
+  return x;
+}
+#define SYNC() __syncthreads()
+#define GFOR(i, n) for (int i = sub; i < (n); i += G)
+
+// 10-element spatial inertia times a motion vector (ang, lin)
+__device__ __forceinline__ void mul_inert_vec(float* r, const float* i, const float* v) {
+  float a0 = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  float a1 = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  float a2 = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  float a3 = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  float a4 = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  float a5 = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+  r[0] = a0; r[1] = a1; r[2] = a2; r[3] = a3; r[4] = a4; r[5] = a5;
+}
+__device__ __forceinline__ void cross_motion(float* r, const float* vel, const float* v) {
+  float a[3], b[3];
+  cross3(r, vel, v);
+  cross3(a, vel, v + 3);
+  cross3(b, vel + 3, v);
+  r[3] = a[0] + b[0]; r[4] = a[1] + b[1]; r[5] = a[2] + b[2];
+}
+__device__ __forceinline__ void cross_force(float* r, const float* vel, const float* f) {
+  float a[3], b[3];
+  cross3(a, vel, f);
+  cross3(b, vel + 3, f + 3);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2];
+  cross3(r + 3, vel, f + 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// tendon wrapping (2-D circle wrap, inside wrap, sphere / cylinder lifting) -- float twin of the oracle
+__device__ __forceinline__ bool is_intersect(const float* p1, const float* p2, const float* p3, const float* p4) {
+  float det = (p4[1] - p3[1]) * (p2[0] - p1[0]) - (p4[0] - p3[0]) * (p2[1] - p1[1]);
+  if (fabsf(det) < MINVALF) return false;
+  float a = ((p4[0] - p3[0]) * (p1[1] - p3[1]) - (p4[1] - p3[1]) * (p1[0] - p3[0])) / det;
+  float b = ((p2[0] - p1[0]) * (p1[1] - p3[1]) - (p2[1] - p1[1]) * (p1[0] - p3[0])) / det;
+  return a >= 0 && a <= 1 && b >= 0 && b <= 1;
+}
+
+__device__ float wrap_circle(float* pnt, const float* d, const float* sd, bool has_side, float rad) {
+  float sq0 = d[0] * d[0] + d[1] * d[1], sq1 = d[2] * d[2] + d[3] * d[3], sqr = rad * rad;
+  if (sq0 < sqr || sq1 < sqr || rad < MINVALF) return -1;
+  float dif[2] = {d[2] - d[0], d[3] - d[1]};
+  float dd = dif[0] * dif[0] + dif[1] * dif[1];
+  if (dd < MINVALF) return -1;
+  float a = clipf(-(dif[0] * d[0] + dif[1] * d[1]) / dd, 0.f, 1.f);
+  float tmp[2] = {a * dif[0] + d[0], a * dif[1] + d[1]};
+  if (tmp[0] * tmp[0] + tmp[1] * tmp[1] > sqr && (!has_side || sd[0] * tmp[0] + sd[1] * tmp[1] >= 0)) return -1;
+  float s0 = sqrtf(sq0 - sqr), s1 = sqrtf(sq1 - sqr);
+  float sol[2][4], good[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    float sgn = i == 0 ? 1.f : -1.f;
+    sol[i][0] = (d[0] * sqr + sgn * rad * d[1] * s0) / sq0;
+    sol[i][1] = (d[1] * sqr - sgn * rad * d[0] * s0) / sq0;
+    sol[i][2] = (d[2] * sqr - sgn * rad * d[3] * s1) / sq1;
+    sol[i][3] = (d[3] * sqr + sgn * rad * d[2] * s1) / sq1;
+    if (has_side) {
+      float t0 = sol[i][0] + sol[i][2], t1 = sol[i][1] + sol[i][3];
+      float n = sqrtf(t0 * t0 + t1 * t1);
+      if (n > MINVALF) { t0 /= n; t1 /= n; }
+      good[i] = t0 * sd[0] + t1 * sd[1];
+    } else {
+      float t0 = sol[i][0] - sol[i][2], t1 = sol[i][1] - sol[i][3];
+      good[i] = -(t0 * t0 + t1 * t1);
+    }
+    // a grazing solution (tangent points closer than 1e-3 rad) makes the segment-intersection test
+    // meaningless in float; skip it there (changes the length by O(r*1e-9), see DESIGN.md "float safeguards")
+    float gz0 = sol[i][0] - sol[i][2], gz1 = sol[i][1] - sol[i][3];
+    bool grazing = gz0 * gz0 + gz1 * gz1 < 1e-6f * sqr;
+    if (!grazing && is_intersect(d, sol[i], d + 2, sol[i] + 2)) good[i] = -10000.f;
+  }
+  int i = good[0] > good[1] ? 0 : 1;
+#pragma unroll
+  for (int k = 0; k < 4; k++) pnt[k] = i == 0 ? sol[0][k] : sol[1][k];
+  bool grazing = (pnt[0] - pnt[2]) * (pnt[0] - pnt[2]) + (pnt[1] - pnt[3]) * (pnt[1] - pnt[3]) < 1e-6f * sqr;
+  if (!grazing && is_intersect(d, pnt, d + 2, pnt + 2)) return -1;
+  return rad * acosf(clipf((pnt[0] * pnt[2] + pnt[1] * pnt[3]) / sqr, -1.f, 1.f));
+}
+
+__device__ float wrap_inside(float* pnt, const float* d, float rad) {
+  const float zinit = 1.f - 1e-7f, tolerance = 1e-6f;
+  float len0 = sqrtf(d[0] * d[0] + d[1] * d[1]), len1 = sqrtf(d[2] * d[2] + d[3] * d[3]);
+  float dif[2] = {d[2] - d[0], d[3] - d[1]};
+  float dd = dif[0] * dif[0] + dif[1] * dif[1];
+  if (len0 <= rad || len1 <= rad || rad < MINVALF || len0 < MINVALF || len1 < MINVALF) return -1;
+  if (dd > MINVALF) {
+    float a = -(dif[0] * d[0] + dif[1] * d[1]) / dd;
+    if (a > 0 && a < 1) {
+      float t0 = a * dif[0] + d[0], t1 = a * dif[1] + d[1];
+      if (sqrtf(t0 * t0 + t1 * t1) <= rad) return -1;
+    }
+  }
+  pnt[0] = 0.5f * (d[0] + d[2]); pnt[1] = 0.5f * (d[1] + d[3]);
+  float n = sqrtf(pnt[0] * pnt[0] + pnt[1] * pnt[1]);
+  if (n > MINVALF) { pnt[0] *= rad / n; pnt[1] *= rad / n; }
+  pnt[2] = pnt[0]; pnt[3] = pnt[1];
+  float A = rad / len0, B = rad / len1;
+  float cosG = (len0 * len0 + len1 * len1 - dd) / (2 * len0 * len1);
+  if (cosG < -1 + MINVALF) return -1;
+  if (cosG > 1 - MINVALF) return 0;
+  float Gang = acosf(cosG);
+  // Newton on theta = asin(z): same root as MuJoCo's iteration in z, but well conditioned in float near z -> 1
+  (void)zinit;
+  float th = 1.57079632679f - 4.4721360e-4f;
+  float sn = sinf(th), f = asinf(A * sn) + asinf(B * sn) - 2 * th + Gang;
+  if (f > 0) return 0;
+  for (int iter = 0; iter < 20 && fabsf(f) > tolerance; iter++) {
+    float cs = cosf(th);
+    float df = A * cs / fmaxf(MINVALF, sqrtf(1 - A * A * sn * sn)) + B * cs / fmaxf(MINVALF, sqrtf(1 - B * B * sn * sn)) - 2;
+    th = clipf(th - f / df, 1e-6f, 1.57079632679f);
+    sn = sinf(th);
+    f = asinf(A * sn) + asinf(B * sn) - 2 * th + Gang;
+  }
+  float vec[2], ang;
+  if (d[0] * d[3] - d[1] * d[2] > 0) { vec[0] = d[0] / len0; vec[1] = d[1] / len0; ang = th - asinf(A * sn); }
+  else { vec[0] = d[2] / len1; vec[1] = d[3] / len1; ang = th - asinf(B * sn); }
+  float sa, ca;
+  sincosf(ang, &sa, &ca);
+  pnt[0] = rad * (ca * vec[0] - sa * vec[1]);
+  pnt[1] = rad * (sa * vec[0] + ca * vec[1]);
+  pnt[2] = pnt[0]; pnt[3] = pnt[1];
+  return 0;
+}
+
+// returns wrap length (<0: no wrap); wpnt = two world points
+__device__ float wrap_geom(float* wpnt, const float* x0, const float* x1, const float* xpos, const float* xmat, float radius,
+                           bool cylinder, const float* side, bool has_side) {
+  float p[6], s[3] = {0, 0, 0}, tmp[3], axis[6], d[4], sd[2] = {0, 0}, pnt[4], res[6];
+  tmp[0] = x0[0] - xpos[0]; tmp[1] = x0[1] - xpos[1]; tmp[2] = x0[2] - xpos[2];
+  matTvec(p, xmat, tmp);
+  tmp[0] = x1[0] - xpos[0]; tmp[1] = x1[1] - xpos[1]; tmp[2] = x1[2] - xpos[2];
+  matTvec(p + 3, xmat, tmp);
+  if (norm3(p) < MINVALF || norm3(p + 3) < MINVALF) return -1;
+  if (has_side) {
+    tmp[0] = side[0] - xpos[0]; tmp[1] = side[1] - xpos[1]; tmp[2] = side[2] - xpos[2];
+    matTvec(s, xmat, tmp);
+  }
+  if (!cylinder) {
+    axis[0] = p[0]; axis[1] = p[1]; axis[2] = p[2];
+    normalize3(axis);
+    float nrmv[3];
+    cross3(nrmv, p, p + 3);
+    float nrm = norm3(nrmv);
+    if (nrm < MINVALF) {
+      int i = 0;
+      if (fabsf(axis[1]) > fabsf(axis[0]) && fabsf(axis[1]) > fabsf(axis[2])) i = 1;
+      if (fabsf(axis[2]) > fabsf(axis[0]) && fabsf(axis[2]) > fabsf(axis[1])) i = 2;
+      float t[3] = {i == 0 ? 0.f : 1.f, i == 1 ? 0.f : 1.f, i == 2 ? 0.f : 1.f};
+      cross3(nrmv, axis, t);
+      nrm = norm3(nrmv);
+    }
+    float inv = 1.0f / nrm;
+    nrmv[0] *= inv; nrmv[1] *= inv; nrmv[2] *= inv;
+    cross3(axis + 3, nrmv, axis);
+    normalize3(axis + 3);
+    d[0] = dot3(p, axis); d[1] = dot3(p, axis + 3); d[2] = dot3(p + 3, axis); d[3] = dot3(p + 3, axis + 3);
+    if (has_side) { sd[0] = dot3(s, axis); sd[1] = dot3(s, axis + 3); }
+  } else {
+    d[0] = p[0]; d[1] = p[1]; d[2] = p[3]; d[3] = p[4];
+    if (has_side) { sd[0] = s[0]; sd[1] = s[1]; }
+  }
+  float wlen;
+  float sdn = sqrtf(sd[0] * sd[0] + sd[1] * sd[1]);
+  if (has_side && sdn < radius) {
+    wlen = wrap_inside(pnt, d, radius);
+  } else {
+    if (has_side && sdn > MINVALF) { sd[0] /= sdn; sd[1] /= sdn; }
+    wlen = wrap_circle(pnt, d, sd, has_side, radius);
+  }
+  if (wlen < 0) return -1;
+  if (!cylinder) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      res[k] = axis[k] * pnt[0] + axis[3 + k] * pnt[1];
+      res[3 + k] = axis[k] * pnt[2] + axis[3 + k] * pnt[3];
+    }
+  } else {
+    float L0 = sqrtf((p[0] - pnt[0]) * (p[0] - pnt[0]) + (p[1] - pnt[1]) * (p[1] - pnt[1]));
+    float L1 = sqrtf((p[3] - pnt[2]) * (p[3] - pnt[2]) + (p[4] - pnt[3]) * (p[4] - pnt[3]));
+    float tot = L0 + wlen + L1;
+    res[0] = pnt[0]; res[1] = pnt[1]; res[3] = pnt[2]; res[4] = pnt[3];
+    res[2] = p[2] + (p[5] - p[2]) * L0 / tot;
+    res[5] = p[2] + (p[5] - p[2]) * (L0 + wlen) / tot;
+    float h = res[5] - res[2];
+    wlen = sqrtf(wlen * wlen + h * h);
+  }
+  matvec(wpnt, xmat, res);
+  matvec(wpnt + 3, xmat, res + 3);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { wpnt[k] += xpos[k]; wpnt[3 + k] += xpos[k]; }
+  return wlen;
+}
+
+// ------------------------------------------------------------------------------------------------
+// muscle model (MuJoCo mju_muscleGain / Bias / Dynamics) on an actuator record (lowering.ACT_FLTS)
+__device__ __forceinline__ float muscle_fl(float L, float lmin, float lmax) {
+  if (lmin <= L && L <= lmax) {
+    float a = 0.5f * (lmin + 1), b = 0.5f * (1 + lmax), x;
+    if (L <= a) { x = (L - lmin) / fmaxf(MINVALF, a - lmin); return 0.5f * x * x; }
+    else if (L <= 1) { x = (1 - L) / fmaxf(MINVALF, 1 - a); return 1 - 0.5f * x * x; }
+    else if (L <= b) { x = (L - 1) / fmaxf(MINVALF, b - 1); return 1 - 0.5f * x * x; }
+    else { x = (lmax - L) / fmaxf(MINVALF, lmax - b); return 0.5f * x * x; }
+  }
+  return 0;
+}
+__device__ __forceinline__ void muscle(const float* A, float len, float vel, float act, float ctrl, float* force, float* actdot) {
+  float r0 = A[0], r1 = A[1], F0 = A[2], lmin = A[3], lmax = A[4], vmax = A[5], fpmax = A[6], fvmax = A[7], lr0 = A[8], lr1 = A[9];
+  float L0 = (lr1 - lr0) / fmaxf(MINVALF, r1 - r0);
+  float L = r0 + (len - lr0) / fmaxf(MINVALF, L0);
+  float V = vel / fmaxf(MINVALF, L0 * vmax);
+  float FL = muscle_fl(L, lmin, lmax), FV, y = fvmax - 1;
+  if (V <= -1) FV = 0;
+  else if (V <= 0) FV = (V + 1) * (V + 1);
+  else if (V <= y) FV = fvmax - (y - V) * (y - V) / fmaxf(MINVALF, y);
+  else FV = fvmax;
+  float gain = -F0 * FL * FV;
+  float b = 0.5f * (1 + lmax), bias, x;
+  if (L <= 1) bias = 0;
+  else if (L <= b) { x = (L - 1) / fmaxf(MINVALF, b - 1); bias = -F0 * fpmax * 0.5f * x * x; }
+  else { x = (L - b) / fmaxf(MINVALF, b - 1); bias = -F0 * fpmax * (0.5f + x); }
+  *force = gain * act + bias;
+  float cc = clipf(clipf(ctrl, A[12], A[13]), 0.f, 1.f), ac = clipf(act, 0.f, 1.f);
+  float tau_act = A[10] * (0.5f + 1.5f * ac), tau_deact = A[11] / (0.5f + 1.5f * ac);
+  float dctrl = cc - act;
+  *actdot = dctrl / fmaxf(MINVALF, dctrl > 0 ? tau_act : tau_deact);
+}
+
+__device__ __forceinline__ float impedance(const float* solimp, float pos, float margin) {
+  float dmin = clipf(solimp[0], MINIMPF, MAXIMPF), dmax = clipf(solimp[1], MINIMPF, MAXIMPF);
+  float width = fmaxf(MINVALF, solimp[2]), mid = clipf(solimp[3], MINIMPF, MAXIMPF), power = fmaxf(1.f, solimp[4]);
+  if (dmin == dmax || width <= MINVALF) return 0.5f * (dmin + dmax);
+  float x = fabsf((pos - margin) / width);
+  if (x >= 1) return dmax;
+  if (x == 0) return dmin;
+  float y;
+  if (power == 1) y = x;
+  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1);
+  else y = 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
+  return dmin + y * (dmax - dmin);
+}
+__device__ __forceinline__ void kbi(float solref0, float solref1, float dmax_in, float timestep, float* K, float* B) {
+  float dmax = clipf(dmax_in, MINIMPF, MAXIMPF);
+  if (solref0 > 0) {
+    float tc = fmaxf(solref0, 2 * timestep);
+    *K = 1.0f / fmaxf(MINVALF, dmax * dmax * tc * tc * solref1 * solref1);
+    *B = 2.0f / fmaxf(MINVALF, dmax * tc);
+  } else {
+    *K = -solref0 / fmaxf(MINVALF, dmax * dmax);
+    *B = -solref1 / fmaxf(MINVALF, dmax);
+  }
+}
+
+__device__ __forceinline__ void make_frame(const float* n, float* t1, float* t2) {  // mju_makeFrame
+  t1[0] = 0; t1[1] = 0; t1[2] = 0;
+  if (n[1] < 0.5f && n[1] > -0.5f) t1[1] = 1; else t1[2] = 1;
+  float t = dot3(n, t1);
+  t1[0] -= t * n[0]; t1[1] -= t * n[1]; t1[2] -= t * n[2];
+  normalize3(t1);
+  cross3(t2, n, t1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// convex collision for ellipsoid pads: margin-inflated MPR (float twin of the oracle's mpr_penetration)
+struct CObj { const float *pos, *mat, *size; int type; float margin; };
+__device__ void support_world(const CObj& o, const float* dir, float* out) {
+  float dl[3], pl[3];
+  matTvec(dl, o.mat, dir);
+  if (o.type == GEOM_ELLIPSOID) {
+    float s[3] = {o.size[0] * dl[0], o.size[1] * dl[1], o.size[2] * dl[2]};
+    float n = norm3(s);
+    float inv = n > MINVALF ? 1.0f / n : 0.f;
+    pl[0] = o.size[0] * s[0] * inv; pl[1] = o.size[1] * s[1] * inv; pl[2] = o.size[2] * s[2] * inv;
+  } else {  // sphere / capsule
+    float n = norm3(dl);
+    float inv = n > MINVALF ? o.size[0] / n : 0.f;
+    pl[0] = dl[0] * inv; pl[1] = dl[1] * inv; pl[2] = dl[2] * inv;
+    if (o.type == GEOM_CAPSULE) pl[2] += dl[2] >= 0 ? o.size[1] : -o.size[1];
+  }
+  matvec(out, o.mat, pl);
+  float n = norm3(dir);
+  float sc = n > MINVALF ? o.margin / n : 0.f;
+  out[0] += o.pos[0] + dir[0] * sc; out[1] += o.pos[1] + dir[1] * sc; out[2] += o.pos[2] + dir[2] * sc;
+}
+struct Sup { float v[3], v1[3], v2[3]; };
+__device__ void mink_support(const CObj& a, const CObj& b, const float* dir, Sup& s) {
+  float nd[3] = {-dir[0], -dir[1], -dir[2]};
+  support_world(a, dir, s.v1);
+  support_world(b, nd, s.v2);
+  s.v[0] = s.v1[0] - s.v2[0]; s.v[1] = s.v1[1] - s.v2[1]; s.v[2] = s.v1[2] - s.v2[2];
+}
+__device__ __forceinline__ void portal_dir(const Sup* p, float* dir) {
+  float a[3] = {p[2].v[0] - p[1].v[0], p[2].v[1] - p[1].v[1], p[2].v[2] - p[1].v[2]};
+  float b[3] = {p[3].v[0] - p[1].v[0], p[3].v[1] - p[1].v[1], p[3].v[2] - p[1].v[2]};
+  cross3(dir, a, b);
+  normalize3(dir);
+}
+__device__ __forceinline__ void expand_portal(Sup* p, const Sup& v4) {
+  float va[3];
+  cross3(va, v4.v, p[0].v);
+  if (dot3(p[1].v, va) > 0) { if (dot3(p[2].v, va) > 0) p[1] = v4; else p[3] = v4; }
+  else { if (dot3(p[3].v, va) > 0) p[2] = v4; else p[1] = v4; }
+}
+__device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout) {
+  Sup p[4];
+  float dir[3], va[3], vb[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { p[0].v1[k] = o1.pos[k]; p[0].v2[k] = o2.pos[k]; p[0].v[k] = o1.pos[k] - o2.pos[k]; }
+  if (norm3(p[0].v) < MINVALF) p[0].v[0] += 1e-5f;
+  dir[0] = -p[0].v[0]; dir[1] = -p[0].v[1]; dir[2] = -p[0].v[2];
+  normalize3(dir);
+  mink_support(o1, o2, dir, p[1]);
+  if (dot3(p[1].v, dir) < 0) return false;
+  cross3(dir, p[0].v, p[1].v);
+  if (norm3(dir) < 1e-12f) {
+    *depth = norm3(p[1].v);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { dirout[k] = p[1].v[k]; posout[k] = 0.5f * (p[1].v1[k] + p[1].v2[k]); }
+    normalize3(dirout);
+    return true;
+  }
+  normalize3(dir);
+  mink_support(o1, o2, dir, p[2]);
+  if (dot3(p[2].v, dir) < 0) return false;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { va[k] = p[1].v[k] - p[0].v[k]; vb[k] = p[2].v[k] - p[0].v[k]; }
+  cross3(dir, va, vb);
+  normalize3(dir);
+  if (dot3(dir, p[0].v) > 0) { Sup t = p[1]; p[1] = p[2]; p[2] = t; dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
+  for (int it = 0;; it++) {
+    if (it > maxit) return false;
+    mink_support(o1, o2, dir, p[3]);
+    if (dot3(p[3].v, dir) < 0) return false;
+    bool cont = false;
+    cross3(va, p[1].v, p[3].v);
+    if (dot3(va, p[0].v) < -MINVALF) { p[2] = p[3]; cont = true; }
+    if (!cont) {
+      cross3(va, p[3].v, p[2].v);
+      if (dot3(va, p[0].v) < -MINVALF) { p[1] = p[3]; cont = true; }
+    }
+    if (!cont) break;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { va[k] = p[1].v[k] - p[0].v[k]; vb[k] = p[2].v[k] - p[0].v[k]; }
+    cross3(dir, va, vb);
+    normalize3(dir);
+  }
+  for (int it = 0;; it++) {
+    if (it > maxit) return false;
+    portal_dir(p, dir);
+    if (dot3(dir, p[1].v) >= 0) break;
+    Sup v4;
+    mink_support(o1, o2, dir, v4);
+    float dv4 = dot3(v4.v, dir);
+    float dmin = fminf(fminf(dv4 - dot3(p[1].v, dir), dv4 - dot3(p[2].v, dir)), dv4 - dot3(p[3].v, dir));
+    if (dv4 < 0 || dmin <= tol) return false;
+    expand_portal(p, v4);
+  }
+  Sup v4;
+  for (int it = 0;; it++) {
+    portal_dir(p, dir);
+    mink_support(o1, o2, dir, v4);
+    float dv4 = dot3(v4.v, dir);
+    float dmin = fminf(fminf(dv4 - dot3(p[1].v, dir), dv4 - dot3(p[2].v, dir)), dv4 - dot3(p[3].v, dir));
+    if (dmin <= tol || it > maxit) break;
+    expand_portal(p, v4);
+  }
+  // output from the final support plane (see the oracle's mpr_penetration for the rationale)
+  *depth = dot3(v4.v, dir);
+  // contact position: barycentric coordinates of the origin in the tetrahedron (v0, portal) (libccd findPos)
+  float bw[4], cr[3];
+  cross3(cr, p[1].v, p[2].v); bw[0] = dot3(cr, p[3].v);
+  cross3(cr, p[3].v, p[2].v); bw[1] = dot3(cr, p[0].v);
+  cross3(cr, p[0].v, p[1].v); bw[2] = dot3(cr, p[3].v);
+  cross3(cr, p[2].v, p[1].v); bw[3] = dot3(cr, p[0].v);
+  float sum = bw[0] + bw[1] + bw[2] + bw[3];
+  if (sum <= 0) {
+    bw[0] = 0;
+    cross3(cr, p[2].v, p[3].v); bw[1] = dot3(cr, dir);
+    cross3(cr, p[3].v, p[1].v); bw[2] = dot3(cr, dir);
+    cross3(cr, p[1].v, p[2].v); bw[3] = dot3(cr, dir);
+    sum = bw[1] + bw[2] + bw[3];
+  }
+  float inv = 1.0f / sum;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    dirout[k] = dir[k];
+    posout[k] = 0.5f * inv * (bw[0] * (p[0].v1[k] + p[0].v2[k]) + bw[1] * (p[1].v1[k] + p[1].v2[k]) +
+                              bw[2] * (p[2].v1[k] + p[2].v2[k]) + bw[3] * (p[3].v1[k] + p[3].v2[k]));
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense packed-lower-triangular Cholesky / solves on G lanes (matrix in LDS); all lanes must call
+template <int G> __device__ void chol_packed(float* H, int n, int sub) {
+  for (int j = 0; j < n; j++) {
+    SYNC();
+    float d = sqrtf(fmaxf(H[tri(j, j)], MINVALF));
+    float inv = 1.0f / d;
+    SYNC();
+    for (int i = j + 1 + sub; i < n; i += G) H[tri(i, j)] *= inv;
+    if (sub == 0) H[tri(j, j)] = d;
+    SYNC();
+    for (int i = j + 1 + sub; i < n; i += G) {
+      float lij = H[tri(i, j)];
+      for (int k = j + 1; k <= i; k++) H[tri(i, k)] -= lij * H[tri(k, j)];
+    }
+  }
+  SYNC();
+}
+// x <- (L L^T)^-1 x, x in LDS
+template <int G> __device__ void chol_solve(const float* L, float* x, int n, int sub) {
+  for (int j = 0; j < n; j++) {
+    SYNC();
+    float xj = x[j] / L[tri(j, j)];
+    SYNC();
+    if (sub == 0) x[j] = xj;
+    for (int i = j + 1 + sub; i < n; i += G) x[i] -= L[tri(i, j)] * xj;
+  }
+  for (int j = n - 1; j >= 0; j--) {
+    SYNC();
+    float xj = x[j] / L[tri(j, j)];
+    SYNC();
+    if (sub == 0) x[j] = xj;
+    for (int i = sub; i < j; i += G) x[i] -= L[tri(j, i)] * xj;
+  }
+  SYNC();
+}
+// y = M x for packed symmetric M (rows distributed over lanes); y, x in LDS
+template <int G> __device__ void symv_packed(const float* Mp, const float* x, float* y, int n, int sub) {
+  GFOR(i, n) {
+    float s = 0;
+    for (int j = 0; j <= i; j++) s += Mp[tri(i, j)] * x[j];
+    for (int j = i + 1; j < n; j++) s += Mp[tri(j, i)] * x[j];
+    y[i] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// position stage pieces
+template <int G> __device__ void stage_kinematics(const DevModel& M, float* E, int sub) {
+  const Lay& Y = M.lay;
+  for (int L = 0; L < M.nlevel; L++) {
+    int a = M.level_adr[L], b = M.level_adr[L + 1];
+    for (int l = a + sub; l < b; l += G) {
+      float pos[3], q[4], R[9];
+      int par = M.link_parent[l];
+      const float* lp = M.link_pos + 3 * l;
+      const float* lq = M.link_quat + 4 * l;
+      if (par < 0) {
+        pos[0] = lp[0]; pos[1] = lp[1]; pos[2] = lp[2];
+        q[0] = lq[0]; q[1] = lq[1]; q[2] = lq[2]; q[3] = lq[3];
+      } else {
+        float v[3];
+        matvec(v, E + Y.lmat + 9 * par, lp);
+        pos[0] = E[Y.lpos + 3 * par] + v[0]; pos[1] = E[Y.lpos + 3 * par + 1] + v[1]; pos[2] = E[Y.lpos + 3 * par + 2] + v[2];
+        mulquat(q, E + Y.lquat + 4 * par, lq);
+      }
+      int da = M.link_dofadr[l], dn = M.link_dofnum[l];
+      for (int k = 0; k < dn; k++) {
+        int d = da + k;
+        quat2mat(R, q);
+        float ax[3], an[3];
+        matvec(ax, R, M.dof_axis + 3 * d);
+        matvec(an, R, M.dof_pos + 3 * d);
+        an[0] += pos[0]; an[1] += pos[1]; an[2] += pos[2];
+        E[Y.axis + 3 * d] = ax[0]; E[Y.axis + 3 * d + 1] = ax[1]; E[Y.axis + 3 * d + 2] = ax[2];
+        E[Y.anchor + 3 * d] = an[0]; E[Y.anchor + 3 * d + 1] = an[1]; E[Y.anchor + 3 * d + 2] = an[2];
+        float ang = E[Y.qpos + d] - M.qpos0[d];
+        if (M.dof_type[d] == 3) {
+          float s, c;
+          sincosf(0.5f * ang, &s, &c);
+          float ql[4] = {c, M.dof_axis[3 * d] * s, M.dof_axis[3 * d + 1] * s, M.dof_axis[3 * d + 2] * s};
+          mulquat(q, q, ql);
+          quat2mat(R, q);
+          float v[3];
+          matvec(v, R, M.dof_pos + 3 * d);
+          pos[0] = an[0] - v[0]; pos[1] = an[1] - v[1]; pos[2] = an[2] - v[2];
+        } else {
+          pos[0] += ax[0] * ang; pos[1] += ax[1] * ang; pos[2] += ax[2] * ang;
+        }
+      }
+      float n = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      q[0] *= n; q[1] *= n; q[2] *= n; q[3] *= n;
+      quat2mat(R, q);
+#pragma unroll
+      for (int k = 0; k < 3; k++) E[Y.lpos + 3 * l + k] = pos[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) E[Y.lquat + 4 * l + k] = q[k];
+#pragma unroll
+      for (int k = 0; k < 9; k++) E[Y.lmat + 9 * l + k] = R[k];
+    }
+    SYNC();
+  }
+}
+
+__device__ __forceinline__ void site_world(const DevModel& M, const float* E, int s, float* out) {
+  int l = M.site_link[s];
+  const float* lp = M.site_lpos + 3 * s;
+  if (l < 0) { out[0] = lp[0]; out[1] = lp[1]; out[2] = lp[2]; return; }
+  float v[3];
+  matvec(v, E + M.lay.lmat + 9 * l, lp);
+  out[0] = E[M.lay.lpos + 3 * l] + v[0]; out[1] = E[M.lay.lpos + 3 * l + 1] + v[1]; out[2] = E[M.lay.lpos + 3 * l + 2] + v[2];
+}
+
+// straight tendon piece pa->pb: add its length and its sparse moment arms (dof list adr,n)
+__device__ __forceinline__ float add_straight(const DevModel& M, float* E, float* Jrow, const float* pa, const float* pb, int adr,
+                                              int n, float invdiv) {
+  float dif[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+  float dist = norm3(dif);
+  if (n > 0 && dist > MINVALF) {
+    float inv = 1.0f / dist;
+    dif[0] *= inv; dif[1] *= inv; dif[2] *= inv;
+    for (int k = 0; k < n; k++) {
+      const int* e = M.dl + 3 * (adr + k);
+      int d = e[0];
+      const float* ax = E + M.lay.axis + 3 * d;
+      float col;
+      if (M.dof_type[d] == 3) {
+        const float* an = E + M.lay.anchor + 3 * d;
+        float r[3] = {pb[0] - an[0], pb[1] - an[1], pb[2] - an[2]}, c[3];
+        cross3(c, ax, r);
+        col = dot3(dif, c);
+      } else {
+        col = dot3(dif, ax);
+      }
+      Jrow[e[2]] += (float)e[1] * col * invdiv;
+    }
+  }
+  return dist * invdiv;
+}
+
+template <int G> __device__ void stage_tendon(const DevModel& M, float* E, int sub) {
+  const Lay& Y = M.lay;
+  for (int gt = sub; gt < M.ngt; gt += G) {
+    float* Jrow = E + Y.tJ + gt * M.maxnnz;
+    for (int k = 0; k < M.maxnnz; k++) Jrow[k] = 0;
+    float L = 0;
+    int s0 = M.gt_seg_adr[gt], sn = M.gt_seg_num[gt];
+    for (int si = s0; si < s0 + sn; si++) {
+      const int* S = M.seg + 12 * si;
+      float invdiv = 1.0f / M.seg_div[si];
+      float p0[3], p1[3];
+      site_world(M, E, S[0], p0);
+      site_world(M, E, S[1], p1);
+      float wlen = -1, wp[6];
+      if (S[2] >= 0) {
+        int g = S[2], gl = M.wg_link[g];
+        float gpos[3], gmat[9], side[3] = {0, 0, 0};
+        if (gl < 0) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) gpos[k] = M.wg_lpos[3 * g + k];
+#pragma unroll
+          for (int k = 0; k < 9; k++) gmat[k] = M.wg_lmat[9 * g + k];
+        } else {
+          float v[3];
+          matvec(v, E + Y.lmat + 9 * gl, M.wg_lpos + 3 * g);
+#pragma unroll
+          for (int k = 0; k < 3; k++) gpos[k] = E[Y.lpos + 3 * gl + k] + v[k];
+          matmul3(gmat, E + Y.lmat + 9 * gl, M.wg_lmat + 9 * g);
+        }
+        if (S[3] >= 0) site_world(M, E, S[3], side);
+        wlen = wrap_geom(wp, p0, p1, gpos, gmat, M.wg_radius[g], S[10] != 0, side, S[3] >= 0);
+      }
+      if (wlen < 0) {
+        L += add_straight(M, E, Jrow, p0, p1, S[4], S[5], invdiv);
+      } else {
+        L += add_straight(M, E, Jrow, p0, wp, S[6], S[7], invdiv);
+        L += wlen * invdiv;
+        L += add_straight(M, E, Jrow, wp + 3, p1, S[8], S[9], invdiv);
+      }
+    }
+    E[Y.tlen + gt] = L;
+    if (gt < M.nu) {
+      const float* A = M.act + 16 * gt;
+      float vel = 0;
+      for (int k = 0; k < M.maxnnz; k++) {
+        int d = M.gt_dofs[gt * M.maxnnz + k];
+        if (d >= 0) vel += Jrow[k] * E[Y.qvel + d];
+      }
+      float f, ad;
+      muscle(A, A[14] * L, A[14] * vel, E[Y.act + gt], E[Y.ctrl + gt], &f, &ad);
+      E[Y.tforce + gt] = f * A[14];
+      E[Y.actdot + gt] = ad;
+    }
+  }
+  SYNC();
+  GFOR(d, M.nv) {
+    float s = 0;
+    for (int k = M.col_adr[d]; k < M.col_adr[d + 1]; k++) {
+      int t = M.col[2 * k], slot = M.col[2 * k + 1];
+      s += E[Y.tJ + t * M.maxnnz + slot] * E[Y.tforce + t];
+    }
+    E[Y.qfa + d] = s;
+  }
+}
+
+// composite inertia (CRB) mass matrix + RNE bias; leaves Mp (packed) and smooth = passive - bias + actuator
+template <int G> __device__ void stage_dynamics(const DevModel& M, float* E, int sub) {
+  const Lay& Y = M.lay;
+  GFOR(l, M.nl) {
+    const float* R = E + Y.lmat + 9 * l;
+    const float* I = M.link_inertia + 6 * l;
+    float Il[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}, T[9], Iw[9], com[3];
+    matmul3(T, R, Il);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) Iw[3 * i + j] = T[3 * i] * R[3 * j] + T[3 * i + 1] * R[3 * j + 1] + T[3 * i + 2] * R[3 * j + 2];
+    matvec(com, R, M.link_com + 3 * l);
+    float mass = M.link_mass[l];
+    float dif[3] = {E[Y.lpos + 3 * l] + com[0] - M.c0[0], E[Y.lpos + 3 * l + 1] + com[1] - M.c0[1], E[Y.lpos + 3 * l + 2] + com[2] - M.c0[2]};
+    float ci[10];
+    ci[0] = Iw[0] + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
+    ci[1] = Iw[4] + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
+    ci[2] = Iw[8] + mass * (dif[0] * dif[0] + dif[1] * dif[1]);
+    ci[3] = Iw[1] - mass * dif[0] * dif[1];
+    ci[4] = Iw[2] - mass * dif[0] * dif[2];
+    ci[5] = Iw[5] - mass * dif[1] * dif[2];
+    ci[6] = mass * dif[0]; ci[7] = mass * dif[1]; ci[8] = mass * dif[2]; ci[9] = mass;
+#pragma unroll
+    for (int k = 0; k < 10; k++) { E[Y.cinert + 10 * l + k] = ci[k]; E[Y.crb + 10 * l + k] = ci[k]; }
+  }
+  GFOR(d, M.nv) {
+    const float* ax = E + Y.axis + 3 * d;
+    float c[6];
+    if (M.dof_type[d] == 3) {
+      float off[3] = {M.c0[0] - E[Y.anchor + 3 * d], M.c0[1] - E[Y.anchor + 3 * d + 1], M.c0[2] - E[Y.anchor + 3 * d + 2]};
+      c[0] = ax[0]; c[1] = ax[1]; c[2] = ax[2];
+      cross3(c + 3, ax, off);
+    } else {
+      c[0] = c[1] = c[2] = 0; c[3] = ax[0]; c[4] = ax[1]; c[5] = ax[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) E[Y.cdof + 6 * d + k] = c[k];
+  }
+  GFOR(i, (M.nv * (M.nv + 1)) / 2) E[Y.Mp + i] = 0;
+  SYNC();
+  // RNE forward pass, one tree level per phase
+  for (int L = 0; L < M.nlevel; L++) {
+    int a = M.level_adr[L], b = M.level_adr[L + 1];
+    for (int l = a + sub; l < b; l += G) {
+      int par = M.link_parent[l];
+      float cvel[6], cacc[6];
+      if (par < 0) {
+        cvel[0] = cvel[1] = cvel[2] = cvel[3] = cvel[4] = cvel[5] = 0;
+        cacc[0] = cacc[1] = cacc[2] = 0; cacc[3] = -M.grav[0]; cacc[4] = -M.grav[1]; cacc[5] = -M.grav[2];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) { cvel[k] = E[Y.cvel + 6 * par + k]; cacc[k] = E[Y.cacc + 6 * par + k]; }
+      }
+      int da = M.link_dofadr[l], dn = M.link_dofnum[l];
+      for (int j = 0; j < dn; j++) {
+        int d = da + j;
+        float cd[6], cdd[6], qv = E[Y.qvel + d];
+#pragma unroll
+        for (int k = 0; k < 6; k++) cd[k] = E[Y.cdof + 6 * d + k];
+        cross_motion(cdd, cvel, cd);
+#pragma unroll
+        for (int k = 0; k < 6; k++) { cacc[k] += cdd[k] * qv; cvel[k] += cd[k] * qv; }
+      }
+      float ci[10], f[6], t[6], t1[6];
+#pragma unroll
+      for (int k = 0; k < 10; k++) ci[k] = E[Y.cinert + 10 * l + k];
+      mul_inert_vec(f, ci, cacc);
+      mul_inert_vec(t, ci, cvel);
+      cross_force(t1, cvel, t);
+#pragma unroll
+      for (int k = 0; k < 6; k++) { E[Y.cvel + 6 * l + k] = cvel[k]; E[Y.cacc + 6 * l + k] = cacc[k]; E[Y.cfrc + 6 * l + k] = f[k] + t1[k]; }
+    }
+    SYNC();
+  }
+  // backward accumulation of forces and composite inertias
+  for (int L = M.nlevel - 2; L >= 0; L--) {
+    int a = M.level_adr[L], b = M.level_adr[L + 1];
+    for (int l = a + sub; l < b; l += G) {
+      for (int ci = M.child_adr[l]; ci < M.child_adr[l + 1]; ci++) {
+        int c = M.child[ci];
+#pragma unroll
+        for (int k = 0; k < 6; k++) E[Y.cfrc + 6 * l + k] += E[Y.cfrc + 6 * c + k];
+#pragma unroll
+        for (int k = 0; k < 10; k++) E[Y.crb + 10 * l + k] += E[Y.crb + 10 * c + k];
+      }
+    }
+    SYNC();
+  }
+  GFOR(d, M.nv) {
+    int l = M.dof_link[d];
+    float cd[6], buf[6], crb[10];
+#pragma unroll
+    for (int k = 0; k < 6; k++) cd[k] = E[Y.cdof + 6 * d + k];
+#pragma unroll
+    for (int k = 0; k < 10; k++) crb[k] = E[Y.crb + 10 * l + k];
+    float bias = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) bias += cd[k] * E[Y.cfrc + 6 * l + k];
+    mul_inert_vec(buf, crb, cd);
+    int a = d;
+    while (a >= 0) {
+      float s = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) s += E[Y.cdof + 6 * a + k] * buf[k];
+      if (a == d) s += M.dof_armature[d];
+      E[Y.Mp + tri(d, a)] = s;
+      a = M.dof_parent[a];
+    }
+    E[Y.smooth + d] = -M.dof_damping[d] * E[Y.qvel + d] - bias + E[Y.qfa + d];
+  }
+  SYNC();
+}
+
+// collision: world geom frames, broad phase (bounding spheres), narrow phase -> contact list. returns ncon (group-uniform)
+template <int G> __device__ int stage_collision(const DevModel& M, float* E, int sub, int grp, int* flags) {
+  const Lay& Y = M.lay;
+  if (M.disable_contact) return 0;
+  GFOR(g, M.ncg) {
+    int l = M.cg_link[g];
+    if (l < 0) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) E[Y.gpos + 3 * g + k] = M.cg_lpos[3 * g + k];
+#pragma unroll
+      for (int k = 0; k < 9; k++) E[Y.gmat + 9 * g + k] = M.cg_lmat[9 * g + k];
+    } else {
+      float v[3], R[9];
+      matvec(v, E + Y.lmat + 9 * l, M.cg_lpos + 3 * g);
+#pragma unroll
+      for (int k = 0; k < 3; k++) E[Y.gpos + 3 * g + k] = E[Y.lpos + 3 * l + k] + v[k];
+      matmul3(R, E + Y.lmat + 9 * l, M.cg_lmat + 9 * g);
+#pragma unroll
+      for (int k = 0; k < 9; k++) E[Y.gmat + 9 * g + k] = R[k];
+    }
+  }
+  SYNC();
+  const unsigned long long gm = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
+  int ncand = 0;
+  int* cand = (int*)(E + Y.cand);
+  for (int base = 0; base < M.npair; base += G) {
+    int p = base + sub;
+    bool hit = false;
+    if (p < M.npair) {
+      const int* P = M.pair_i + 6 * p;
+      if (!(M.disable_ellipsoid && !P[4])) {
+        const float* x1 = E + Y.gpos + 3 * P[0];
+        const float* x2 = E + Y.gpos + 3 * P[1];
+        float dif[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
+        float bound = M.cg_rbound[P[0]] + M.cg_rbound[P[1]] + M.pair_f[12 * p];
+        hit = dot3(dif, dif) <= bound * bound;
+      }
+    }
+    unsigned long long bal = __ballot(hit);
+    unsigned int g16 = (unsigned int)((bal >> (grp * G)) & gm);
+    int pos = ncand + __popc(g16 & ((1u << sub) - 1u));
+    if (hit && pos < NCAND) cand[pos] = p;
+    ncand += __popc(g16);
+  }
+  if (ncand > NCAND) { *flags |= MYO_FLAG_CAND_OVERFLOW; ncand = NCAND; }
+  SYNC();
+  int ncon = 0;
+  int maxc = ncand;
+#pragma unroll
+  for (int m = 32; m >= G; m >>= 1) maxc = max(maxc, __shfl_xor(maxc, m, 64));  // wave-uniform trip count
+  for (int base = 0; base < maxc; base += G) {
+    int ci = base + sub;
+    bool hit = false;
+    float dist = 0, cpos[3] = {0, 0, 0}, nrm[3] = {1, 0, 0};
+    int p = -1;
+    if (ci < ncand) {
+      p = cand[ci];
+      const int* P = M.pair_i + 6 * p;
+      int g1 = P[0], g2 = P[1];
+      float margin = M.pair_f[12 * p];
+      const float *x1 = E + Y.gpos + 3 * g1, *x2 = E + Y.gpos + 3 * g2, *R1 = E + Y.gmat + 9 * g1, *R2 = E + Y.gmat + 9 * g2;
+      const float *sz1 = M.cg_size + 3 * g1, *sz2 = M.cg_size + 3 * g2;
+      if (P[4]) {  // capsule-capsule (mjraw_CapsuleCapsule)
+        float a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]};
+        float dif[3] = {x1[0] - x2[0], x1[1] - x2[1], x1[2] - x2[2]};
+        float mb = -dot3(a1, a2), u = -dot3(a1, dif), v = dot3(a2, dif), det = 1 - mb * mb, xa, xb;
+        if (fabsf(det) >= MINVALF) {
+          xa = (u - mb * v) / det;
+          xb = (v - mb * u) / det;
+          if (xa > sz1[1]) { xa = sz1[1]; xb = v - mb * sz1[1]; }
+          else if (xa < -sz1[1]) { xa = -sz1[1]; xb = v + mb * sz1[1]; }
+          if (xb > sz2[1]) { xb = sz2[1]; xa = clipf(u - mb * sz2[1], -sz1[1], sz1[1]); }
+          else if (xb < -sz2[1]) { xb = -sz2[1]; xa = clipf(u + mb * sz2[1], -sz1[1], sz1[1]); }
+        } else {
+          xa = clipf(u, -sz1[1], sz1[1]);
+          xb = clipf(v - mb * xa, -sz2[1], sz2[1]);
+          xa = clipf(u - mb * xb, -sz1[1], sz1[1]);
+        }
+        float v1[3] = {x1[0] + a1[0] * xa, x1[1] + a1[1] * xa, x1[2] + a1[2] * xa};
+        float v2[3] = {x2[0] + a2[0] * xb, x2[1] + a2[1] * xb, x2[2] + a2[2] * xb};
+        float dd[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
+        float cd = norm3(dd);
+        if (cd <= margin + sz1[0] + sz2[0]) {
+          if (cd < MINVALF) { dd[0] = 1; dd[1] = 0; dd[2] = 0; } else { float inv = 1.0f / cd; dd[0] *= inv; dd[1] *= inv; dd[2] *= inv; }
+          dist = cd - sz1[0] - sz2[0];
+#pragma unroll
+          for (int k = 0; k < 3; k++) { cpos[k] = v1[k] + dd[k] * (sz1[0] + 0.5f * dist); nrm[k] = dd[k]; }
+          hit = true;
+        }
+      } else {
+        // MPR in coordinates relative to geom1's centre (float resolution ~1e-9 m), converged tolerance
+        const float zero3[3] = {0.f, 0.f, 0.f};
+        float rel[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
+        CObj o1 = {zero3, R1, sz1, M.cg_type[g1], 0.5f * margin}, o2 = {rel, R2, sz2, M.cg_type[g2], 0.5f * margin};
+        float depth, dir[3], pos[3];
+        if (mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos)) {
+          dist = margin - depth;
+          normalize3(dir);
+#pragma unroll
+          for (int k = 0; k < 3; k++) { cpos[k] = pos[k] + x1[k]; nrm[k] = dir[k]; }
+          hit = true;
+        }
+      }
+      // contacts at or beyond the inclusion margin generate no rows (margin - gap)
+      if (hit && !(dist < margin - M.pair_f[12 * p + 1])) hit = false;
+    }
+    unsigned long long bal = __ballot(hit);
+    unsigned int g16 = (unsigned int)((bal >> (grp * G)) & gm);
+    int pos = ncon + __popc(g16 & ((1u << sub) - 1u));
+    if (hit && pos < NCON) {
+      E[Y.cdist + pos] = dist;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { E[Y.cpos + 3 * pos + k] = cpos[k]; E[Y.cnrm + 3 * pos + k] = nrm[k]; }
+      ((int*)(E + Y.cpair))[pos] = p;
+    }
+    ncon += __popc(g16);
+  }
+  if (ncon > NCON) { *flags |= MYO_FLAG_CONTACT_OVERFLOW; ncon = NCON; }
+  SYNC();
+  return ncon;
+}
+
+// constraint rows: joint limits (one row per violated side) and pyramidal contact rows (4 per contact)
+template <int G> __device__ void stage_constraints(const DevModel& M, float* E, int sub, int ncon) {
+  const Lay& Y = M.lay;
+  GFOR(d, M.nv) {
+    const float* J = M.jl + 12 * d;
+    float sign = 0, aref = 0, D = 0;
+    if (J[0] != 0 && !M.disable_limit) {
+      float q = E[Y.qpos + d], margin = J[3];
+      float dlo = q - J[1], dhi = J[2] - q, dist = 0;
+      if (dlo < margin && dlo <= dhi) { sign = 1; dist = dlo; }
+      else if (dhi < margin) { sign = -1; dist = dhi; }
+      if (sign != 0) {
+        float imp = impedance(J + 6, dist, margin), K, B;
+        float R = fmaxf(MINVALF, (1 - imp) / imp * J[11]);
+        kbi(J[4], J[5], J[7], M.timestep, &K, &B);
+        aref = -B * (sign * E[Y.qvel + d]) - K * imp * (dist - margin);
+        D = 1.0f / R;
+      }
+    }
+    E[Y.lsign + d] = sign; E[Y.laref + d] = aref; E[Y.lD + d] = D;
+  }
+  GFOR(c, ncon) {
+    int p = ((const int*)(E + Y.cpair))[c];
+    const int* P = M.pair_i + 6 * p;
+    const float* F = M.pair_f + 12 * p;
+    float n[3] = {E[Y.cnrm + 3 * c], E[Y.cnrm + 3 * c + 1], E[Y.cnrm + 3 * c + 2]}, t1[3], t2[3];
+    float cp[3] = {E[Y.cpos + 3 * c], E[Y.cpos + 3 * c + 1], E[Y.cpos + 3 * c + 2]};
+    make_frame(n, t1, t2);
+    float vn = 0, vt1 = 0, vt2 = 0;
+    float* cJ = E + Y.cJ + c * 3 * KCMAX;
+    for (int k = 0; k < P[3]; k++) {
+      int d = M.pair_dl[2 * (P[2] + k)];
+      float sg = (float)M.pair_dl[2 * (P[2] + k) + 1];
+      const float* ax = E + Y.axis + 3 * d;
+      float col[3];
+      if (M.dof_type[d] == 3) {
+        float r[3] = {cp[0] - E[Y.anchor + 3 * d], cp[1] - E[Y.anchor + 3 * d + 1], cp[2] - E[Y.anchor + 3 * d + 2]};
+        cross3(col, ax, r);
+      } else { col[0] = ax[0]; col[1] = ax[1]; col[2] = ax[2]; }
+      float jn = sg * dot3(n, col), j1 = sg * dot3(t1, col), j2 = sg * dot3(t2, col), qv = E[Y.qvel + d];
+      cJ[k] = jn; cJ[KCMAX + k] = j1; cJ[2 * KCMAX + k] = j2;
+      vn += jn * qv; vt1 += j1 * qv; vt2 += j2 * qv;
+    }
+    float dist = E[Y.cdist + c], incl = F[0] - F[1], mu = F[2];
+    float imp = impedance(F + 6, dist, incl), K, B;
+    kbi(F[4], F[5], F[7], M.timestep, &K, &B);
+    float R0 = fmaxf(MINVALF, (1 - imp) / imp * F[3] * (1 + mu * mu));
+    float Rpy = fmaxf(MINVALF, 2 * mu * mu * R0);
+    E[Y.cD + c] = 1.0f / Rpy;
+    float pos = -K * imp * (dist - incl);
+    E[Y.caref + 4 * c + 0] = -B * (vn + mu * vt1) + pos;
+    E[Y.caref + 4 * c + 1] = -B * (vn - mu * vt1) + pos;
+    E[Y.caref + 4 * c + 2] = -B * (vn + mu * vt2) + pos;
+    E[Y.caref + 4 * c + 3] = -B * (vn - mu * vt2) + pos;
+    E[Y.cimp + c] = mu;
+  }
+  SYNC();
+}
+
+// rows' J*x - aref for x in LDS; writes ljar/cjar (or ljv/cjv when dst_is_jv, without subtracting aref)
+template <int G> __device__ void rows_apply(const DevModel& M, float* E, int sub, int ncon, const float* x, bool jv) {
+  const Lay& Y = M.lay;
+  GFOR(d, M.nv) {
+    float s = E[Y.lsign + d];
+    if (jv) E[Y.ljv + d] = s * x[d]; else E[Y.ljar + d] = s * x[d] - E[Y.laref + d];
+  }
+  GFOR(c, ncon) {
+    int p = ((const int*)(E + Y.cpair))[c];
+    const int* P = M.pair_i + 6 * p;
+    const float* cJ = E + Y.cJ + c * 3 * KCMAX;
+    float an = 0, a1 = 0, a2 = 0, mu = E[Y.cimp + c];
+    for (int k = 0; k < P[3]; k++) {
+      float xv = x[M.pair_dl[2 * (P[2] + k)]];
+      an += cJ[k] * xv; a1 += cJ[KCMAX + k] * xv; a2 += cJ[2 * KCMAX + k] * xv;
+    }
+    float r[4] = {an + mu * a1, an - mu * a1, an + mu * a2, an - mu * a2};
+    if (jv) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) E[Y.cjv + 4 * c + k] = r[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) E[Y.cjar + 4 * c + k] = r[k] - E[Y.caref + 4 * c + k];
+    }
+  }
+}
+
+// constraint cost of the rows for jar currently in LDS (group-reduced)
+template <int G> __device__ float rows_cost(const DevModel& M, const float* E, int sub, int ncon) {
+  const Lay& Y = M.lay;
+  float c = 0;
+  GFOR(d, M.nv) { float j = E[Y.ljar + d]; if (E[Y.lsign + d] != 0 && j < 0) c += 0.5f * E[Y.lD + d] * j * j; }
+  GFOR(k, 4 * ncon) { float j = E[Y.cjar + k]; if (j < 0) c += 0.5f * E[Y.cD + (k >> 2)] * j * j; }
+  return grp_sum<G>(c);
+}
+
+// qfc = J^T f for the current jar (f = -D*jar on active rows); also adds J^T D J (active) into Hp when Hp != null
+template <int G> __device__ void rows_force_hessian(const DevModel& M, float* E, int sub, int ncon, int maxncon, bool hess) {
+  const Lay& Y = M.lay;
+  GFOR(d, M.nv) {
+    float s = E[Y.lsign + d], j = E[Y.ljar + d], D = E[Y.lD + d];
+    bool act = s != 0 && j < 0;
+    E[Y.qfc + d] = act ? -s * D * j : 0.f;
+    if (hess && act) E[Y.Hp + tri(d, d)] += D;
+  }
+  SYNC();
+  for (int c = 0; c < maxncon; c++) {
+    if (c < ncon) {
+      int p = ((const int*)(E + Y.cpair))[c];
+      const int* P = M.pair_i + 6 * p;
+      int kc = P[3];
+      const float* cJ = E + Y.cJ + c * 3 * KCMAX;
+      float D = E[Y.cD + c], mu = E[Y.cimp + c];
+      float j0 = E[Y.cjar + 4 * c], j1 = E[Y.cjar + 4 * c + 1], j2 = E[Y.cjar + 4 * c + 2], j3 = E[Y.cjar + 4 * c + 3];
+      float w0 = j0 < 0 ? D : 0.f, w1 = j1 < 0 ? D : 0.f, w2 = j2 < 0 ? D : 0.f, w3 = j3 < 0 ? D : 0.f;
+      float f0 = -w0 * j0, f1 = -w1 * j1, f2 = -w2 * j2, f3 = -w3 * j3;
+      float Fn = f0 + f1 + f2 + f3, Ft1 = mu * (f0 - f1), Ft2 = mu * (f2 - f3);
+      if (sub < kc) {
+        int d = M.pair_dl[2 * (P[2] + sub)];
+        E[Y.qfc + d] += Fn * cJ[sub] + Ft1 * cJ[KCMAX + sub] + Ft2 * cJ[2 * KCMAX + sub];
+      }
+      if (hess) {
+        float W = w0 + w1 + w2 + w3, A1 = mu * (w0 - w1), A2 = mu * (w2 - w3), B1 = mu * mu * (w0 + w1), B2 = mu * mu * (w2 + w3);
+        for (int t = sub; t < kc * kc; t += G) {
+          int a = t / kc, b = t - a * kc;
+          int da = M.pair_dl[2 * (P[2] + a)], db = M.pair_dl[2 * (P[2] + b)];
+          if (da >= db) {
+            float na = cJ[a], nb = cJ[b], ta = cJ[KCMAX + a], tb = cJ[KCMAX + b], ua = cJ[2 * KCMAX + a], ub = cJ[2 * KCMAX + b];
+            E[Y.Hp + tri(da, db)] += W * na * nb + A1 * (na * tb + ta * nb) + A2 * (na * ub + ua * nb) + B1 * ta * tb + B2 * ua * ub;
+          }
+        }
+      }
+    }
+    SYNC();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the fused env-step kernel
+template <int G>
+__global__ void __launch_bounds__(64) step_kernel(DevModel M, DevBatch Bt, const float* __restrict__ action, int actmap, int nsub) {
+  extern __shared__ __align__(16) float smem[];
+  const Lay& Y = M.lay;
+  const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
+  const int EPW = 64 / G;
+  int env = blockIdx.x * EPW + grp;
+  const bool valid = env < Bt.B;
+  if (!valid) env = Bt.B - 1;  // duplicate work, never stored
+  float* E = smem + grp * Y.total;
+  const int nv = M.nv, nu = M.nu;
+  // ---- load state, map action to control
+  GFOR(i, nv) {
+    E[Y.qpos + i] = Bt.qpos[(size_t)env * nv + i];
+    E[Y.qvel + i] = Bt.qvel[(size_t)env * nv + i];
+    E[Y.warm + i] = Bt.warm[(size_t)env * nv + i];
+  }
+  GFOR(i, nu) {
+    E[Y.act + i] = Bt.act[(size_t)env * nu + i];
+    float c;
+    if (action) {
+      c = action[(size_t)env * nu + i];
+      if (actmap == MYO_ACTMAP_MUSCLE_SIGMOID) c = 1.0f / (1.0f + expf(-5.0f * (c - 0.5f)));
+    } else c = Bt.ctrl[(size_t)env * nu + i];
+    E[Y.ctrl + i] = c;
+  }
+  float time = Bt.time[env];
+  int flags = 0, d_nefc = 0, d_ncon = 0, d_iter = 0;
+  bool alive = true;
+  SYNC();
+  const float h = M.timestep;
+  const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
+  for (int step = 0; step < nsub; step++) {
+    // mj_checkPos / mj_checkVel
+    {
+      int bad = 0;
+      GFOR(i, nv) { float a = E[Y.qpos + i], b = E[Y.qvel + i]; if (!(a == a) || fabsf(a) > MAXVALF || !(b == b) || fabsf(b) > MAXVALF) bad = 1; }
+      bad = grp_maxi<G>(bad);
+      if (bad && alive) { flags |= MYO_FLAG_BAD_STATE; alive = false; }
+    }
+    stage_kinematics<G>(M, E, sub);
+    stage_tendon<G>(M, E, sub);
+    SYNC();
+    stage_dynamics<G>(M, E, sub);
+    int ncon = stage_collision<G>(M, E, sub, grp, &flags);
+    stage_constraints<G>(M, E, sub, ncon);
+    // ---- unconstrained acceleration: qas = M^-1 smooth
+    GFOR(i, (nv * (nv + 1)) / 2) E[Y.Hp + i] = E[Y.Mp + i];
+    GFOR(i, nv) E[Y.qas + i] = E[Y.smooth + i];
+    chol_packed<G>(E + Y.Hp, nv, sub);
+    chol_solve<G>(E + Y.Hp, E + Y.qas, nv, sub);
+    // ---- constraint solver
+    int nlim = 0;
+    GFOR(d, nv) nlim += E[Y.lsign + d] != 0 ? 1 : 0;
+    nlim = grp_sumi<G>(nlim);
+    int nefc = nlim + 4 * ncon;
+    int maxncon = ncon;
+#pragma unroll
+    for (int m = 32; m >= G; m >>= 1) maxncon = max(maxncon, __shfl_xor(maxncon, m, 64));
+    int iters = 0;
+    if (__any(nefc > 0)) {
+      bool solving = nefc > 0;
+      // warmstart: compare cost(qacc_warmstart) with cost(qacc_smooth)
+      rows_apply<G>(M, E, sub, ncon, E + Y.warm, false);
+      symv_packed<G>(E + Y.Mp, E + Y.warm, E + Y.Ma, nv, sub);
+      SYNC();
+      float cw = 0;
+      GFOR(i, nv) cw += 0.5f * (E[Y.Ma + i] - E[Y.smooth + i]) * (E[Y.warm + i] - E[Y.qas + i]);
+      cw = grp_sum<G>(cw) + rows_cost<G>(M, E, sub, ncon);
+      SYNC();
+      rows_apply<G>(M, E, sub, ncon, E + Y.qas, false);
+      SYNC();
+      float cs = rows_cost<G>(M, E, sub, ncon);
+      bool use_smooth = cw > cs || !(cw == cw);
+      GFOR(i, nv) E[Y.qacc + i] = use_smooth ? E[Y.qas + i] : E[Y.warm + i];
+      SYNC();
+      if (!use_smooth) rows_apply<G>(M, E, sub, ncon, E + Y.qacc, false);  // jar currently holds the qas version
+      symv_packed<G>(E + Y.Mp, E + Y.qacc, E + Y.Ma, nv, sub);
+      SYNC();
+      float cost = 0;
+      GFOR(i, nv) cost += 0.5f * (E[Y.Ma + i] - E[Y.smooth + i]) * (E[Y.qacc + i] - E[Y.qas + i]);
+      cost = grp_sum<G>(cost) + rows_cost<G>(M, E, sub, ncon);
+      for (int it = 0; it < M.iterations; it++) {
+        if (!__any(solving)) break;
+        // gradient, Hessian, Newton direction
+        GFOR(i, (nv * (nv + 1)) / 2) E[Y.Hp + i] = E[Y.Mp + i];
+        SYNC();
+        rows_force_hessian<G>(M, E, sub, ncon, maxncon, true);
+        GFOR(i, nv) { float g = E[Y.Ma + i] - E[Y.smooth + i] - E[Y.qfc + i]; E[Y.grad + i] = g; E[Y.search + i] = -g; }
+        chol_packed<G>(E + Y.Hp, nv, sub);
+        chol_solve<G>(E + Y.Hp, E + Y.search, nv, sub);
+        symv_packed<G>(E + Y.Mp, E + Y.search, E + Y.Mv, nv, sub);
+        rows_apply<G>(M, E, sub, ncon, E + Y.search, true);
+        SYNC();
+        // exact line search on the piecewise-quadratic cost along `search`
+        float g1 = 0, g2 = 0, sn = 0;
+        GFOR(i, nv) { float s = E[Y.search + i]; g1 += s * (E[Y.Ma + i] - E[Y.smooth + i]); g2 += 0.5f * s * E[Y.Mv + i]; sn += s * s; }
+        g1 = grp_sum<G>(g1); g2 = grp_sum<G>(g2); sn = sqrtf(grp_sum<G>(sn));
+        float alpha = 0, lo = 0, hi = -1, dlo = 0, d2lo = 0, dhi = 0, d2hi = 0, d1init = 0;
+        bool ls_on = solving && sn >= MINVALF;
+        for (int lsit = -1; lsit < M.ls_iterations; lsit++) {
+          if (!__any(ls_on)) break;
+          float a = (lsit < 0) ? 0.f : alpha;
+          float d1 = 0, d2 = 0;
+          GFOR(d, nv) {
+            if (E[Y.lsign + d] != 0) {
+              float jv = E[Y.ljv + d], x = E[Y.ljar + d] + a * jv, D = E[Y.lD + d];
+              if (x < 0) { d1 += D * x * jv; d2 += D * jv * jv; }
+            }
+          }
+          GFOR(k, 4 * ncon) {
+            float jv = E[Y.cjv + k], x = E[Y.cjar + k] + a * jv, D = E[Y.cD + (k >> 2)];
+            if (x < 0) { d1 += D * x * jv; d2 += D * jv * jv; }
+          }
+          d1 = grp_sum<G>(d1) + g1 + 2 * a * g2;
+          d2 = grp_sum<G>(d2) + 2 * g2;
+          if (!ls_on) continue;
+          if (lsit < 0) {
+            if (d1 >= 0 || d2 <= 0) { ls_on = false; alpha = 0; continue; }
+            dlo = d1; d2lo = d2; d1init = fabsf(d1);
+            alpha = -d1 / d2;
+            continue;
+          }
+          float gtol = fmaxf(M.tolerance * M.ls_tolerance * sn / scale, 1e-6f * d1init);
+          if (fabsf(d1) < gtol) { ls_on = false; continue; }
+          if (d1 < 0) { lo = alpha; dlo = d1; d2lo = d2; } else { hi = alpha; dhi = d1; d2hi = d2; }
+          float cand = alpha - d1 / d2;
+          if (hi < 0) {
+            if (!(cand > lo)) { ls_on = false; continue; }
+            alpha = cand;
+          } else {
+            if (!(cand > lo && cand < hi)) {
+              float c2 = d1 < 0 ? hi - dhi / d2hi : lo - dlo / d2lo;
+              cand = (c2 > lo && c2 < hi) ? c2 : 0.5f * (lo + hi);
+            }
+            if (cand == alpha || hi - lo <= 1e-7f * hi) { ls_on = false; continue; }
+            alpha = cand;
+          }
+        }
+        bool moved = solving && alpha > 0;
+        if (solving && !moved) solving = false;
+        SYNC();
+        if (moved) {
+          GFOR(i, nv) { E[Y.qacc + i] += alpha * E[Y.search + i]; E[Y.Ma + i] += alpha * E[Y.Mv + i]; E[Y.ljar + i] += alpha * E[Y.ljv + i]; }
+          GFOR(k, 4 * ncon) E[Y.cjar + k] += alpha * E[Y.cjv + k];
+        }
+        SYNC();
+        float newcost = 0;
+        GFOR(i, nv) newcost += 0.5f * (E[Y.Ma + i] - E[Y.smooth + i]) * (E[Y.qacc + i] - E[Y.qas + i]);
+        newcost = grp_sum<G>(newcost) + rows_cost<G>(M, E, sub, ncon);
+        if (moved) {
+          float improvement = scale * (cost - newcost);
+          cost = newcost;
+          iters++;
+          float gn = 0;
+          GFOR(i, nv) gn += E[Y.grad + i] * E[Y.grad + i];
+          gn = scale * sqrtf(grp_sum<G>(gn));
+          if (improvement < fmaxf(M.tolerance, 1e-6f * scale * fabsf(cost)) || gn < M.tolerance) solving = false;
+        }
+      }
+      // final constraint force for the converged qacc
+      SYNC();
+      rows_force_hessian<G>(M, E, sub, ncon, maxncon, false);
+      if (nefc == 0) { GFOR(i, nv) { E[Y.qacc + i] = E[Y.qas + i]; E[Y.qfc + i] = 0; } }
+    } else {
+      GFOR(i, nv) { E[Y.qacc + i] = E[Y.qas + i]; E[Y.qfc + i] = 0; }
+    }
+    SYNC();
+    d_nefc = nefc; d_ncon = ncon; d_iter = max(d_iter, iters);
+    // mj_checkAcc
+    {
+      int bad = 0;
+      GFOR(i, nv) { float a = E[Y.qacc + i]; if (!(a == a) || fabsf(a) > MAXVALF) bad = 1; }
+      bad = grp_maxi<G>(bad);
+      if (bad && alive) { flags |= MYO_FLAG_BAD_QACC; alive = false; }
+    }
+    // ---- Euler with implicit joint damping: (M + h*B) qaccE = smooth + qfc
+    GFOR(i, (nv * (nv + 1)) / 2) E[Y.Hp + i] = E[Y.Mp + i];
+    GFOR(i, nv) { E[Y.warm + i] = E[Y.qacc + i]; E[Y.search + i] = E[Y.smooth + i] + E[Y.qfc + i]; }
+    SYNC();
+    GFOR(i, nv) E[Y.Hp + tri(i, i)] += h * M.dof_damping[i];
+    chol_packed<G>(E + Y.Hp, nv, sub);
+    chol_solve<G>(E + Y.Hp, E + Y.search, nv, sub);
+    if (alive) {
+      GFOR(i, nu) E[Y.act + i] += h * E[Y.actdot + i];
+      GFOR(i, nv) { float v = E[Y.qvel + i] + h * E[Y.search + i]; E[Y.qvel + i] = v; E[Y.qpos + i] += h * v; }
+      time += h;
+    }
+    SYNC();
+  }
+  // a bad env is reset like mj_resetData (mj_sim_scene.py:56-61)
+  if (!alive) {
+    GFOR(i, nv) { E[Y.qpos + i] = M.qpos0[i]; E[Y.qvel + i] = 0; E[Y.warm + i] = 0; }
+    GFOR(i, nu) { E[Y.act + i] = 0; E[Y.ctrl + i] = 0; }
+    time = 0;
+  }
+  SYNC();
+  if (valid) {
+    GFOR(i, nv) {
+      Bt.qpos[(size_t)env * nv + i] = E[Y.qpos + i];
+      Bt.qvel[(size_t)env * nv + i] = E[Y.qvel + i];
+      Bt.warm[(size_t)env * nv + i] = E[Y.warm + i];
+      Bt.qacc[(size_t)env * nv + i] = E[Y.qacc + i];
+    }
+    GFOR(i, nu) {
+      Bt.act[(size_t)env * nu + i] = E[Y.act + i];
+      Bt.ctrl[(size_t)env * nu + i] = E[Y.ctrl + i];
+      Bt.tenlen[(size_t)env * nu + i] = E[Y.tlen + i];
+      Bt.actforce[(size_t)env * nu + i] = E[Y.tforce + i];
+    }
+    if (sub == 0) {
+      Bt.time[env] = time;
+      Bt.flags[env] |= flags;
+      Bt.diag[(size_t)env * 8 + 0] = d_nefc; Bt.diag[(size_t)env * 8 + 1] = d_ncon; Bt.diag[(size_t)env * 8 + 2] = d_iter;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// counter-based RNG (splitmix64 of (seed, stream, counter)) -> U[0,1)
+__device__ __host__ inline float u01(uint64_t seed, uint64_t a, uint64_t b) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (a + 1) + 0xBF58476D1CE4E5B9ull * (b + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__global__ void random_action_kernel(float* action, int B, int nu, uint64_t seed, uint64_t step, int env_offset) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * nu) return;
+  size_t e = i / nu, k = i % nu;
+  action[i] = 2.0f * u01(seed, (uint64_t)(e + env_offset) * 1024 + k, step) - 1.0f;
+}
+
+__global__ void reset_kernel(DevBatch Bt, TaskDev T, int nv, int nu, const float* qpos0, const uint8_t* mask, uint64_t seed, int env_offset) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Bt.B) return;
+  if (mask && !mask[e]) return;
+  uint64_t ge = (uint64_t)(e + env_offset);
+  for (int i = 0; i < nv; i++) {
+    float q = T.init_qpos ? T.init_qpos[i] : qpos0[i];
+    if (T.reset_random) q = T.jnt_lo[i] + (T.jnt_hi[i] - T.jnt_lo[i]) * u01(seed, ge * 4096 + i, 1);
+    Bt.qpos[(size_t)e * nv + i] = q;
+    Bt.qvel[(size_t)e * nv + i] = 0;
+    Bt.warm[(size_t)e * nv + i] = 0;
+  }
+  for (int i = 0; i < nu; i++) { Bt.act[(size_t)e * nu + i] = 0; Bt.ctrl[(size_t)e * nu + i] = 0; }
+  Bt.time[e] = 0;
+  for (int i = 0; i < T.ntarget; i++) {
+    float lo = T.target_lo[i], hi = T.target_hi[i];
+    Bt.target[(size_t)e * T.ntarget + i] = T.target_generate ? lo + (hi - lo) * u01(seed, ge * 4096 + 2048 + i, 2) : lo;
+  }
+}
+
+// observation + reward (pose_v0.py:98-138, reach_v0.py:88-144, obs_vec_dict.py:86-98); one lane per env
+__global__ void obs_kernel(DevModel M, DevBatch Bt, TaskDev T) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Bt.B) return;
+  const int nv = M.nv, nu = M.nu;
+  float dt = (float)T.frame_skip * M.timestep;
+  float* o = Bt.obs + (size_t)e * T.obs_dim;
+  const float* q = Bt.qpos + (size_t)e * nv;
+  const float* v = Bt.qvel + (size_t)e * nv;
+  const float* a = Bt.act + (size_t)e * nu;
+  float actn = 0;
+  for (int i = 0; i < nu; i++) actn += a[i] * a[i];
+  actn = sqrtf(actn) / (float)(nu > 0 ? nu : 1);
+  if (T.task == MYO_TASK_POSE) {
+    float err2 = 0;
+    for (int i = 0; i < nv; i++) {
+      float pe = Bt.target[(size_t)e * T.ntarget + i] - q[i];
+      o[i] = q[i]; o[nv + i] = v[i] * dt; o[2 * nv + i] = pe;
+      err2 += pe * pe;
+    }
+    for (int i = 0; i < nu; i++) o[3 * nv + i] = a[i];
+    float dist = sqrtf(err2);
+    float bonus = (dist < T.pose_thd ? 1.f : 0.f) + (dist < 1.5f * T.pose_thd ? 1.f : 0.f);
+    float pen = dist > T.far_th ? -1.f : 0.f;
+    Bt.reward[e] = T.w_pose * (-dist) + T.w_bonus * bonus + T.w_act_reg * (-actn) + T.w_penalty * pen;
+    Bt.solved[e] = dist < T.pose_thd ? 1.f : 0.f;
+    Bt.done[e] = dist > T.far_th ? 1.f : 0.f;
+  }
+}
+
+// reach task needs tip positions: per-env group kernel reusing the kinematics stage
+template <int G>
+__global__ void __launch_bounds__(64) reach_obs_kernel(DevModel M, DevBatch Bt, TaskDev T) {
+  extern __shared__ __align__(16) float smem[];
+  const Lay& Y = M.lay;
+  const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
+  int env = blockIdx.x * (64 / G) + grp;
+  const bool valid = env < Bt.B;
+  if (!valid) env = Bt.B - 1;
+  float* E = smem + grp * Y.total;
+  const int nv = M.nv, nu = M.nu;
+  GFOR(i, nv) E[Y.qpos + i] = Bt.qpos[(size_t)env * nv + i];
+  SYNC();
+  stage_kinematics<G>(M, E, sub);
+  float dt = (float)T.frame_skip * M.timestep;
+  float* o = Bt.obs + (size_t)env * T.obs_dim;
+  float err2 = 0;
+  GFOR(i, T.ntip) {
+    float p[3];
+    site_world(M, E, T.tip_site[i], p);
+    for (int k = 0; k < 3; k++) {
+      float tg = Bt.target[(size_t)env * T.ntarget + 3 * i + k];
+      float re = tg - p[k];
+      err2 += re * re;
+      if (valid) {
+        o[2 * nv + 3 * i + k] = p[k];
+        o[2 * nv + 3 * T.ntip + 3 * i + k] = re;
+        Bt.sitexpos[(size_t)env * 3 * T.ntip + 3 * i + k] = p[k];
+      }
+    }
+  }
+  err2 = grp_sum<G>(err2);
+  float actn = 0;
+  GFOR(i, nu) { float a = Bt.act[(size_t)env * nu + i]; actn += a * a; if (valid) o[2 * nv + 6 * T.ntip + i] = a; }
+  actn = sqrtf(grp_sum<G>(actn)) / (float)(nu > 0 ? nu : 1);
+  if (valid) {
+    GFOR(i, nv) { o[i] = E[Y.qpos + i]; o[nv + i] = Bt.qvel[(size_t)env * nv + i] * dt; }
+    if (sub == 0) {
+      float dist = sqrtf(err2);
+      float near_th = T.near_th, far_th = Bt.time[env] > 2 * dt ? T.far_th : 1e30f;
+      float bonus = (dist < 2 * near_th ? 1.f : 0.f) + (dist < near_th ? 1.f : 0.f);
+      float pen = dist > far_th ? -1.f : 0.f;
+      Bt.reward[env] = T.w_reach * (-dist) + T.w_bonus * bonus + T.w_act_reg * (-actn) + T.w_penalty * pen;
+      Bt.solved[env] = dist < near_th ? 1.f : 0.f;
+      Bt.done[env] = dist > far_th ? 1.f : 0.f;
+    }
+  }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MYO_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct BlobRec { char name[32]; uint32_t dtype, ndim, shape[4]; uint64_t nbytes, offset; };
+
+struct myo_model {
+  int device = 0;
+  DevModel dm{};
+  myo_dims dims{};
+  std::vector<void*> dev_allocs;
+  std::vector<float> qpos0, jnt_lo, jnt_hi;
+  float* d_qpos0 = nullptr;
+  int env_lds_bytes = 0;
+};
+
+struct myo_batch {
+  const myo_model* model = nullptr;
+  DevBatch db{};
+  TaskDev task{};
+  int ntarget_alloc = 0, obs_alloc = 0;
+  std::vector<void*> dev_allocs;
+  float *d_tlo = nullptr, *d_thi = nullptr, *d_init = nullptr, *d_jlo = nullptr, *d_jhi = nullptr, *d_action = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static const BlobRec* blob_find(const uint8_t* blob, const char* name) {
+  uint32_t n;
+  memcpy(&n, blob + 8, 4);
+  for (uint32_t i = 0; i < n; i++) {
+    const BlobRec* r = (const BlobRec*)(blob + 16 + (size_t)i * sizeof(BlobRec));
+    if (!strncmp(r->name, name, 32)) return r;
+  }
+  return nullptr;
+}
+
+template <typename T> static int upload(myo_model* m, const std::vector<T>& v, const T** out) {
+  void* p = nullptr;
+  size_t nb = (v.size() + 4) * sizeof(T);
+  HIPCHK(hipMalloc(&p, nb));
+  HIPCHK(hipMemset(p, 0, nb));
+  if (!v.empty()) HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  m->dev_allocs.push_back(p);
+  *out = (const T*)p;
+  return 0;
+}
+static int load_f(myo_model* m, const uint8_t* blob, const char* name, const float** out, std::vector<float>* keep = nullptr) {
+  const BlobRec* r = blob_find(blob, name);
+  if (!r || r->dtype != 0) return fail(MYO_E_BLOB, std::string("model blob lacks f64 array ") + name);
+  size_t n = r->nbytes / 8;
+  std::vector<float> v(n);
+  const double* src = (const double*)(blob + r->offset);
+  for (size_t i = 0; i < n; i++) v[i] = (float)src[i];
+  if (keep) *keep = v;
+  return upload<float>(m, v, out);
+}
+static int load_i(myo_model* m, const uint8_t* blob, const char* name, const int** out, std::vector<int>* keep = nullptr) {
+  const BlobRec* r = blob_find(blob, name);
+  if (!r || r->dtype != 1) return fail(MYO_E_BLOB, std::string("model blob lacks i32 array ") + name);
+  size_t n = r->nbytes / 4;
+  std::vector<int> v(n);
+  memcpy(v.data(), blob + r->offset, n * 4);
+  if (keep) *keep = v;
+  return upload<int>(m, v, out);
+}
+
+static void build_layout(DevModel& d) {
+  Lay& Y = d.lay;
+  int o = 0;
+  auto take = [&](int n) { int r = o; o += n; return r; };
+  int nv = d.nv, nu = d.nu, nl = d.nl, ntri = nv * (nv + 1) / 2;
+  Y.qpos = take(nv); Y.qvel = take(nv); Y.act = take(nu); Y.ctrl = take(nu); Y.warm = take(nv);
+  Y.lpos = take(3 * nl); Y.lmat = take(9 * nl); Y.lquat = take(4 * nl); Y.axis = take(3 * nv); Y.anchor = take(3 * nv);
+  Y.tJ = take(d.ngt * d.maxnnz); Y.tlen = take(d.ngt); Y.tforce = take(nu); Y.actdot = take(nu);
+  Y.qfa = take(nv); Y.smooth = take(nv); Y.qas = take(nv); Y.qacc = take(nv); Y.Ma = take(nv); Y.grad = take(nv);
+  Y.search = take(nv); Y.Mv = take(nv); Y.qfc = take(nv);
+  Y.Mp = take(ntri); Y.Hp = take(ntri);
+  Y.lsign = take(nv); Y.laref = take(nv); Y.lD = take(nv); Y.ljar = take(nv); Y.ljv = take(nv);
+  // region A (spatial dynamics) is dead once Mp / smooth exist; region B (collision + contact rows) aliases it
+  int regA = o;
+  Y.cdof = take(6 * nv); Y.cinert = take(10 * nl); Y.crb = take(10 * nl); Y.cvel = take(6 * nl); Y.cacc = take(6 * nl); Y.cfrc = take(6 * nl);
+  int endA = o;
+  o = regA;
+  Y.gpos = take(3 * d.ncg); Y.gmat = take(9 * d.ncg); Y.cand = take(NCAND);
+  Y.cdist = take(NCON); Y.cpos = take(3 * NCON); Y.cnrm = take(3 * NCON); Y.cpair = take(NCON); Y.cJ = take(NCON * 3 * KCMAX);
+  Y.caref = take(4 * NCON); Y.cD = take(NCON); Y.cjar = take(4 * NCON); Y.cjv = take(4 * NCON); Y.cimp = take(NCON);
+  if (o < endA) o = endA;
+  // pad so that the 64/G env slices start on different LDS banks
+  o = (o + 31) / 32 * 32 + 8;
+  Y.total = o;
+}
+
+extern "C" {
+
+const char* myo_last_error(void) { return g_err.c_str(); }
+int myo_version(void) { return 1; }
+
+int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out) {
+  if (!blobv || !out || nbytes < 16) return fail(MYO_E_ARG, "myo_model_load: bad arguments");
+  const uint8_t* blob = (const uint8_t*)blobv;
+  uint32_t ver;
+  memcpy(&ver, blob + 4, 4);
+  if (memcmp(blob, "MYOB", 4) || ver != 3) return fail(MYO_E_BLOB, "myo_model_load: not a MYOB v3 blob");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(MYO_E_HIP, "myo_model_load: no such HIP device (a GPU is required; there is no CPU fallback)");
+  HIPCHK(hipSetDevice(device));
+  myo_model* m = new myo_model();
+  m->device = device;
+  DevModel& d = m->dm;
+  const BlobRec* hs = blob_find(blob, "hip_sizes");
+  const BlobRec* sz = blob_find(blob, "sizes");
+  const BlobRec* op = blob_find(blob, "opt");
+  if (!hs || !sz || !op) { delete m; return fail(MYO_E_BLOB, "myo_model_load: blob lacks hip_* tables (run lowering)"); }
+  const int* H = (const int*)(blob + hs->offset);
+  const int* S = (const int*)(blob + sz->offset);
+  const double* O = (const double*)(blob + op->offset);
+  d.nl = H[0]; d.nlevel = H[1]; d.nv = H[2]; d.nu = H[3]; d.ngt = H[4]; d.nseg = H[5]; d.maxnnz = H[7]; d.nwg = H[8];
+  d.ncg = H[9]; d.npair = H[10]; d.maxkc = H[11]; d.ns = H[12]; d.nM = S[11];
+  if (d.maxkc > KCMAX) { delete m; return fail(MYO_E_UNSUPPORTED, "contact pair spans more dofs than KCMAX"); }
+  if (d.ngt != d.nu) { delete m; return fail(MYO_E_UNSUPPORTED, "limited-only tendons are not supported by the HIP path yet"); }
+  d.timestep = (float)O[0]; d.grav[0] = (float)O[1]; d.grav[1] = (float)O[2]; d.grav[2] = (float)O[3];
+  d.tolerance = (float)O[4]; d.iterations = (int)O[5]; d.ls_iterations = (int)O[6]; d.ls_tolerance = (float)O[7];
+  d.meaninertia = (float)O[9];
+  int rc = 0;
+  std::vector<float> c0, jl;
+  const float* tmp;
+#define LF(field, name) if ((rc = load_f(m, blob, name, &d.field))) { myo_model_free(m); return rc; }
+#define LI(field, name) if ((rc = load_i(m, blob, name, &d.field))) { myo_model_free(m); return rc; }
+  LI(level_adr, "hip_level_adr") LI(link_parent, "hip_link_parent") LI(link_dofadr, "hip_link_dofadr") LI(link_dofnum, "hip_link_dofnum")
+  LI(child_adr, "hip_child_adr") LI(child, "hip_child") LI(dof_link, "hip_dof_link") LI(dof_type, "hip_dof_type")
+  LI(dof_parent, "dof_parentid") LI(site_link, "hip_site_link") LI(wg_link, "hip_wg_link") LI(gt_seg_adr, "hip_gt_seg_adr")
+  LI(gt_seg_num, "hip_gt_seg_num") LI(gt_dofs, "hip_gt_dofs") LI(seg, "hip_seg") LI(dl, "hip_dl") LI(col_adr, "hip_col_adr")
+  LI(col, "hip_col") LI(cg_link, "hip_cg_link") LI(cg_type, "hip_cg_type") LI(pair_i, "hip_pair_i") LI(pair_dl, "hip_pair_dl")
+  LF(link_pos, "hip_link_pos") LF(link_quat, "hip_link_quat") LF(link_mass, "hip_link_mass") LF(link_com, "hip_link_com")
+  LF(link_inertia, "hip_link_inertia") LF(dof_pos, "hip_dof_pos") LF(dof_axis, "hip_dof_axis") LF(dof_damping, "dof_damping")
+  LF(dof_armature, "dof_armature") LF(site_lpos, "hip_site_lpos") LF(wg_lpos, "hip_wg_lpos") LF(wg_lmat, "hip_wg_lmat")
+  LF(wg_radius, "hip_wg_radius") LF(seg_div, "hip_seg_div") LF(act, "hip_act") LF(cg_lpos, "hip_cg_lpos") LF(cg_lmat, "hip_cg_lmat")
+  LF(cg_size, "hip_cg_size") LF(cg_rbound, "hip_cg_rbound") LF(pair_f, "hip_pair_f")
+#undef LF
+#undef LI
+  if ((rc = load_f(m, blob, "qpos0", &d.qpos0, &m->qpos0))) { myo_model_free(m); return rc; }
+  if ((rc = load_f(m, blob, "hip_jl", &d.jl, &jl))) { myo_model_free(m); return rc; }
+  if ((rc = load_f(m, blob, "hip_c0", &tmp, &c0))) { myo_model_free(m); return rc; }
+  d.c0[0] = c0[0]; d.c0[1] = c0[1]; d.c0[2] = c0[2];
+  m->jnt_lo.resize(d.nv); m->jnt_hi.resize(d.nv);
+  for (int i = 0; i < d.nv; i++) { m->jnt_lo[i] = jl[12 * i + 1]; m->jnt_hi[i] = jl[12 * i + 2]; }
+  build_layout(d);
+  m->env_lds_bytes = d.lay.total * 4;
+  m->dims = myo_dims{S[0], S[1], S[2], S[3], S[4], S[8], S[7], d.nl, 0, m->env_lds_bytes, 16, NCON, d.timestep};
+  if (4 * m->env_lds_bytes > 160 * 1024) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "model working set exceeds 160 KB of LDS per workgroup"); }
+  *out = m;
+  return MYO_OK;
+}
+
+void myo_model_free(myo_model* m) {
+  if (!m) return;
+  for (void* p : m->dev_allocs) (void)hipFree(p);
+  delete m;
+}
+
+int myo_model_dims(const myo_model* m, myo_dims* out) {
+  if (!m || !out) return fail(MYO_E_ARG, "myo_model_dims: null");
+  *out = m->dims;
+  return MYO_OK;
+}
+
+int myo_model_set_switch(myo_model* m, int dc, int dl, int de) {
+  if (!m) return fail(MYO_E_ARG, "null model");
+  m->dm.disable_contact = dc; m->dm.disable_limit = dl; m->dm.disable_ellipsoid = de;
+  return MYO_OK;
+}
+
+static int balloc(myo_batch* b, void** p, size_t nbytes) {
+  HIPCHK(hipMalloc(p, nbytes));
+  HIPCHK(hipMemset(*p, 0, nbytes));
+  b->dev_allocs.push_back(*p);
+  return 0;
+}
+
+int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
+  if (!m || !out || B <= 0) return fail(MYO_E_ARG, "myo_batch_create: bad arguments");
+  HIPCHK(hipSetDevice(m->device));
+  myo_batch* b = new myo_batch();
+  b->model = m;
+  DevBatch& d = b->db;
+  d.B = B;
+  int nv = m->dm.nv, nu = m->dm.nu, rc;
+  b->ntarget_alloc = nv > 24 ? nv : 24;
+  b->obs_alloc = 3 * nv + 2 * nu + 64;
+#define BA(ptr, n) if ((rc = balloc(b, (void**)&ptr, (size_t)(n) * 4))) { myo_batch_free(b); return rc; }
+  BA(d.qpos, (size_t)B * nv) BA(d.qvel, (size_t)B * nv) BA(d.act, (size_t)B * nu) BA(d.ctrl, (size_t)B * nu) BA(d.warm, (size_t)B * nv)
+  BA(d.time, B) BA(d.target, (size_t)B * b->ntarget_alloc) BA(d.obs, (size_t)B * b->obs_alloc) BA(d.reward, B) BA(d.done, B)
+  BA(d.solved, B) BA(d.qacc, (size_t)B * nv) BA(d.tenlen, (size_t)B * nu) BA(d.actforce, (size_t)B * nu) BA(d.sitexpos, (size_t)B * 24)
+  BA(d.flags, B) BA(d.diag, (size_t)B * 8)
+  BA(b->d_tlo, b->ntarget_alloc) BA(b->d_thi, b->ntarget_alloc) BA(b->d_init, nv) BA(b->d_jlo, nv) BA(b->d_jhi, nv)
+  BA(b->d_action, (size_t)B * nu)
+#undef BA
+  HIPCHK(hipMemcpy(b->d_jlo, m->jnt_lo.data(), nv * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->d_jhi, m->jnt_hi.data(), nv * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->d_init, m->qpos0.data(), nv * 4, hipMemcpyHostToDevice));
+  // default: every env at qpos0
+  std::vector<float> q((size_t)B * nv);
+  for (int e = 0; e < B; e++) memcpy(&q[(size_t)e * nv], m->qpos0.data(), nv * 4);
+  HIPCHK(hipMemcpy(d.qpos, q.data(), q.size() * 4, hipMemcpyHostToDevice));
+  b->task.task = MYO_TASK_NONE; b->task.frame_skip = 1; b->task.obs_dim = 0; b->task.ntarget = 0;
+  b->task.jnt_lo = b->d_jlo; b->task.jnt_hi = b->d_jhi; b->task.init_qpos = b->d_init; b->task.target_lo = b->d_tlo; b->task.target_hi = b->d_thi;
+  HIPCHK(hipEventCreate(&b->ev0));
+  HIPCHK(hipEventCreate(&b->ev1));
+  *out = b;
+  return MYO_OK;
+}
+
+void myo_batch_free(myo_batch* b) {
+  if (!b) return;
+  for (void* p : b->dev_allocs) (void)hipFree(p);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  delete b;
+}
+
+int myo_batch_size(const myo_batch* b) { return b ? b->db.B : 0; }
+
+int myo_batch_configure(myo_batch* b, const myo_task_config* c) {
+  if (!b || !c) return fail(MYO_E_ARG, "myo_batch_configure: null");
+  const DevModel& dm = b->model->dm;
+  TaskDev& T = b->task;
+  int nv = dm.nv, nu = dm.nu;
+  if (c->ntarget > b->ntarget_alloc || c->ntip > 8) return fail(MYO_E_ARG, "myo_batch_configure: ntarget/ntip too large");
+  T.task = c->task; T.frame_skip = c->frame_skip; T.reset_random = c->reset_random; T.target_generate = c->target_generate;
+  T.ntarget = c->ntarget; T.ntip = c->ntip;
+  for (int i = 0; i < 8; i++) T.tip_site[i] = c->tip_site[i];
+  T.pose_thd = c->pose_thd; T.far_th = c->far_th; T.near_th = c->near_th;
+  T.w_pose = c->w_pose; T.w_bonus = c->w_bonus; T.w_act_reg = c->w_act_reg; T.w_penalty = c->w_penalty; T.w_reach = c->w_reach;
+  if (c->task == MYO_TASK_POSE) { if (c->ntarget != nv) return fail(MYO_E_ARG, "pose task: ntarget must equal nq"); T.obs_dim = 3 * nv + nu; }
+  else if (c->task == MYO_TASK_REACH) { if (c->ntarget != 3 * c->ntip) return fail(MYO_E_ARG, "reach task: ntarget must be 3*ntip"); T.obs_dim = 2 * nv + 6 * c->ntip + nu; }
+  else T.obs_dim = 0;
+  if (T.obs_dim > b->obs_alloc) return fail(MYO_E_ARG, "obs_dim too large");
+  if (c->ntarget > 0) {
+    if (!c->target_lo) return fail(MYO_E_ARG, "target_lo required");
+    HIPCHK(hipMemcpy(b->d_tlo, c->target_lo, c->ntarget * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->d_thi, c->target_hi ? c->target_hi : c->target_lo, c->ntarget * 4, hipMemcpyHostToDevice));
+  }
+  HIPCHK(hipMemcpy(b->d_init, c->init_qpos ? c->init_qpos : b->model->qpos0.data(), nv * 4, hipMemcpyHostToDevice));
+  return MYO_OK;
+}
+
+static int field_info(myo_batch* b, int f, void** p, size_t* pitch, size_t* width) {
+  const DevModel& dm = b->model->dm;
+  DevBatch& d = b->db;
+  size_t nv = dm.nv, nu = dm.nu;
+  switch (f) {
+    case MYO_F_QPOS: *p = d.qpos; *pitch = *width = nv; break;
+    case MYO_F_QVEL: *p = d.qvel; *pitch = *width = nv; break;
+    case MYO_F_ACT: *p = d.act; *pitch = *width = nu; break;
+    case MYO_F_CTRL: *p = d.ctrl; *pitch = *width = nu; break;
+    case MYO_F_WARMSTART: *p = d.warm; *pitch = *width = nv; break;
+    case MYO_F_TIME: *p = d.time; *pitch = *width = 1; break;
+    case MYO_F_TARGET: *p = d.target; *pitch = *width = b->task.ntarget > 0 ? b->task.ntarget : 1; break;
+    case MYO_F_OBS: *p = d.obs; *pitch = *width = b->task.obs_dim > 0 ? b->task.obs_dim : 1; break;
+    case MYO_F_REWARD: *p = d.reward; *pitch = *width = 1; break;
+    case MYO_F_DONE: *p = d.done; *pitch = *width = 1; break;
+    case MYO_F_SOLVED: *p = d.solved; *pitch = *width = 1; break;
+    case MYO_F_FLAGS: *p = d.flags; *pitch = *width = 1; break;
+    case MYO_F_DIAG: *p = d.diag; *pitch = *width = 8; break;
+    case MYO_F_QACC: *p = d.qacc; *pitch = *width = nv; break;
+    case MYO_F_TENLEN: *p = d.tenlen; *pitch = *width = nu; break;
+    case MYO_F_ACTFORCE: *p = d.actforce; *pitch = *width = nu; break;
+    case MYO_F_SITEXPOS: *p = d.sitexpos; *pitch = *width = b->task.ntip > 0 ? 3 * b->task.ntip : 1; break;
+    default: return fail(MYO_E_ARG, "unknown field");
+  }
+  return MYO_OK;
+}
+
+int myo_batch_field(myo_batch* b, int field, void** dev_ptr, size_t* pitch, size_t* width) {
+  if (!b || !dev_ptr || !pitch || !width) return fail(MYO_E_ARG, "myo_batch_field: null");
+  return field_info(b, field, dev_ptr, pitch, width);
+}
+
+int myo_batch_read(myo_batch* b, int field, void* host, size_t nbytes) {
+  void* p; size_t pitch, width;
+  if (!b || !host) return fail(MYO_E_ARG, "myo_batch_read: null");
+  int rc = field_info(b, field, &p, &pitch, &width);
+  if (rc) return rc;
+  if (nbytes != (size_t)b->db.B * width * 4) return fail(MYO_E_ARG, "myo_batch_read: size mismatch");
+  HIPCHK(hipSetDevice(b->model->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(host, p, nbytes, hipMemcpyDeviceToHost));
+  return MYO_OK;
+}
+
+int myo_batch_write(myo_batch* b, int field, const void* host, size_t nbytes) {
+  void* p; size_t pitch, width;
+  if (!b || !host) return fail(MYO_E_ARG, "myo_batch_write: null");
+  int rc = field_info(b, field, &p, &pitch, &width);
+  if (rc) return rc;
+  if (nbytes != (size_t)b->db.B * width * 4) return fail(MYO_E_ARG, "myo_batch_write: size mismatch");
+  HIPCHK(hipSetDevice(b->model->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(p, host, nbytes, hipMemcpyHostToDevice));
+  return MYO_OK;
+}
+
+int myo_reset(myo_batch* b, const uint8_t* mask_dev, uint64_t seed, void* stream) {
+  if (!b) return fail(MYO_E_ARG, "myo_reset: null");
+  const DevModel& dm = b->model->dm;
+  HIPCHK(hipSetDevice(b->model->device));
+  int B = b->db.B;
+  hipLaunchKernelGGL(reset_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->db, b->task, dm.nv, dm.nu, dm.qpos0, mask_dev, seed, 0);
+  HIPCHK(hipGetLastError());
+  return MYO_OK;
+}
+
+int myo_set_state(myo_batch* b, const float* qpos, const float* qvel, const float* act, const float* time, void* stream) {
+  if (!b) return fail(MYO_E_ARG, "myo_set_state: null");
+  const DevModel& dm = b->model->dm;
+  size_t B = b->db.B;
+  hipStream_t s = (hipStream_t)stream;
+  if (qpos) HIPCHK(hipMemcpyAsync(b->db.qpos, qpos, B * dm.nv * 4, hipMemcpyDeviceToDevice, s));
+  if (qvel) HIPCHK(hipMemcpyAsync(b->db.qvel, qvel, B * dm.nv * 4, hipMemcpyDeviceToDevice, s));
+  if (act) HIPCHK(hipMemcpyAsync(b->db.act, act, B * dm.nu * 4, hipMemcpyDeviceToDevice, s));
+  if (time) HIPCHK(hipMemcpyAsync(b->db.time, time, B * 4, hipMemcpyDeviceToDevice, s));
+  return MYO_OK;
+}
+
+static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, hipStream_t s) {
+  const myo_model* m = b->model;
+  const int G = 16, EPW = 64 / G;
+  int grid = (b->db.B + EPW - 1) / EPW;
+  size_t lds = (size_t)EPW * m->env_lds_bytes;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute((const void*)step_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)reach_obs_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(step_kernel<16>, dim3(grid), dim3(64), lds, s, m->dm, b->db, action, actmap, nsub);
+  HIPCHK(hipGetLastError());
+  return MYO_OK;
+}
+
+int myo_step(myo_batch* b, const float* action_dev, int actmap, int nsubsteps, void* stream) {
+  if (!b || nsubsteps < 0) return fail(MYO_E_ARG, "myo_step: bad arguments");
+  HIPCHK(hipSetDevice(b->model->device));
+  return launch_step(b, action_dev, actmap, nsubsteps, (hipStream_t)stream);
+}
+
+static int launch_obs(myo_batch* b, hipStream_t s) {
+  const myo_model* m = b->model;
+  int B = b->db.B;
+  if (b->task.task == MYO_TASK_POSE) {
+    hipLaunchKernelGGL(obs_kernel, dim3((B + 63) / 64), dim3(64), 0, s, m->dm, b->db, b->task);
+  } else if (b->task.task == MYO_TASK_REACH) {
+    const int EPW = 4;
+    hipLaunchKernelGGL(reach_obs_kernel<16>, dim3((B + EPW - 1) / EPW), dim3(64), (size_t)EPW * m->env_lds_bytes, s, m->dm, b->db, b->task);
+  } else {
+    return fail(MYO_E_ARG, "myo_obs: no task configured");
+  }
+  HIPCHK(hipGetLastError());
+  return MYO_OK;
+}
+
+int myo_obs(myo_batch* b, void* stream) {
+  if (!b) return fail(MYO_E_ARG, "myo_obs: null");
+  HIPCHK(hipSetDevice(b->model->device));
+  return launch_obs(b, (hipStream_t)stream);
+}
+
+int myo_status(myo_batch* b, int32_t* host_flags) {
+  if (!b || !host_flags) return fail(MYO_E_ARG, "myo_status: null");
+  HIPCHK(hipSetDevice(b->model->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(host_flags, b->db.flags, (size_t)b->db.B * 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(b->db.flags, 0, (size_t)b->db.B * 4));
+  return MYO_OK;
+}
+
+int myo_random_action(myo_batch* b, float* action_dev, uint64_t seed, uint64_t step, int env_offset, void* stream) {
+  if (!b || !action_dev) return fail(MYO_E_ARG, "myo_random_action: null");
+  size_t n = (size_t)b->db.B * b->model->dm.nu;
+  hipLaunchKernelGGL(random_action_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, action_dev, b->db.B,
+                     b->model->dm.nu, seed, step, env_offset);
+  HIPCHK(hipGetLastError());
+  return MYO_OK;
+}
+
+int myo_sync(void* stream) {
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return MYO_OK;
+}
+
+int myo_bench_rollout(myo_batch* b, int steps, int nsubsteps, uint64_t seed, int with_obs, void* stream, float* ms_out) {
+  if (!b || steps <= 0 || !ms_out) return fail(MYO_E_ARG, "myo_bench_rollout: bad arguments");
+  HIPCHK(hipSetDevice(b->model->device));
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipEventRecord(b->ev0, s));
+  for (int i = 0; i < steps; i++) {
+    int rc = myo_random_action(b, b->d_action, seed, (uint64_t)i, 0, stream);
+    if (rc) return rc;
+    rc = launch_step(b, b->d_action, MYO_ACTMAP_MUSCLE_SIGMOID, nsubsteps, s);
+    if (rc) return rc;
+    if (with_obs && b->task.task != MYO_TASK_NONE) { rc = launch_obs(b, s); if (rc) return rc; }
+  }
+  HIPCHK(hipEventRecord(b->ev1, s));
+  HIPCHK(hipEventSynchronize(b->ev1));
+  HIPCHK(hipEventElapsedTime(ms_out, b->ev0, b->ev1));
+  return MYO_OK;
+}
+
+}  // extern "C"

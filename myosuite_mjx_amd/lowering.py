@@ -1,6 +1,401 @@
-"""Lowering of the compiled model into the tables the HIP kernels consume (placeholder
-until the kernel-side layout is fixed; see lower())."""
+"""Lowering: compiled model (mjModel-style arrays) -> tables for the HIP kernels.
+
+The HIP stepper does not walk MuJoCo's generic body/geom/site arrays.  At model-compile
+time this pass
+  * folds every jointless body into the nearest jointed ancestor ("link"): the MyoHand's
+    38 bodies become 17 links carrying the 23 hinge DoF; world-welded bodies become
+    constants (their sites / wrap geoms / collision geoms get world coordinates);
+  * renumbers links breadth-first so that each tree level is a contiguous range (the
+    kernels process one level per phase, lanes = links of that level);
+  * turns each actuated / limited spatial tendon into a list of segments
+    (site, [wrap geom, side site], site) with precomputed sparse moment-arm DoF lists, so
+    the tendon Jacobian is never materialised densely (SURVEY.md section 7 design notes);
+  * builds the collision pair table over capsule/ellipsoid geoms with the DoF list of each
+    pair, pruning static plane / cylinder geoms that the moving geoms provably cannot reach.
+
+All `hip_*` arrays are added to the model's array dict and travel in the MYOB blob.
+Element layouts are documented next to the C structs in csrc/myo_kernels.hip.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .mjcf import (GEOM_CAPSULE, GEOM_CYLINDER, GEOM_ELLIPSOID, GEOM_PLANE, GEOM_SPHERE, JNT_HINGE, JNT_SLIDE,
+                   WRAP_CYLINDER, WRAP_PULLEY, WRAP_SITE, WRAP_SPHERE, mat2quat, quat2mat, quat_mul)
+from . import setconst as sc
+
+SEG_INTS = 12   # ints per tendon segment record
+PAIR_INTS = 6   # ints per collision pair record
+PAIR_FLTS = 12  # floats per collision pair record
+ACT_FLTS = 16   # floats per actuator record
+
+
+def _rel_transforms(m):
+    """For every body: (link head body id or 0 for static, R_rel 3x3, p_rel 3) expressing the
+    body frame in its link's head-body frame (or in the world frame for static bodies)."""
+    nb = len(m.body_parentid)
+    head = np.zeros(nb, int)
+    R = [np.eye(3) for _ in range(nb)]
+    p = [np.zeros(3) for _ in range(nb)]
+    for b in range(1, nb):
+        par = m.body_parentid[b]
+        Rb = quat2mat(m.body_quat[b])
+        if m.body_jntnum[b] > 0:
+            head[b] = b
+        else:
+            head[b] = head[par]
+            R[b] = R[par] @ Rb
+            p[b] = p[par] + R[par] @ m.body_pos[b]
+    return head, R, p
 
 
 def lower(cm):
+    m = cm
+    A = cm.arrays
+    nb = len(m.body_parentid)
+    nv = len(m.dof_bodyid)
+    for j in range(len(m.jnt_type)):
+        if m.jnt_type[j] not in (JNT_HINGE, JNT_SLIDE):
+            raise NotImplementedError("HIP path: only hinge/slide joints so far")
+    head, Rrel, prel = _rel_transforms(m)
+    heads = [b for b in range(1, nb) if m.body_jntnum[b] > 0]
+    # parent link of each head body
+    def parent_head(b):
+        return head[m.body_parentid[b]]
+    depth = {}
+    for b in heads:
+        ph = parent_head(b)
+        depth[b] = 1 if ph == 0 else depth[ph] + 1
+    order = sorted(heads, key=lambda b: (depth[b], b))
+    lid = {b: i for i, b in enumerate(order)}      # head body -> link id (BFS order)
+    nl = len(order)
+    nlevel = max(depth.values()) if depth else 0
+    level_adr = np.zeros(nlevel + 1, np.int32)
+    for b in order:
+        level_adr[depth[b]] += 1
+    level_adr = np.concatenate([[0], np.cumsum(level_adr[1:])]).astype(np.int32)
+    link_parent = np.full(nl, -1, np.int32)
+    link_pos = np.zeros((nl, 3))
+    link_quat = np.zeros((nl, 4))
+    link_dofadr = np.zeros(nl, np.int32)
+    link_dofnum = np.zeros(nl, np.int32)
+    link_mass = np.zeros(nl)
+    link_com = np.zeros((nl, 3))
+    link_inertia = np.zeros((nl, 6))
+    # static world poses of all world-welded bodies
+    xpos0, xquat0, _, _ = sc.forward_kinematics(m, m.qpos0)
+    body_link = np.full(nb, -1, np.int32)
+    for b in range(1, nb):
+        if head[b]:
+            body_link[b] = lid[head[b]]
+    for b in order:
+        l = lid[b]
+        par = m.body_parentid[b]
+        Rb = quat2mat(m.body_quat[b])
+        if head[par] == 0:     # parent is static: world pose of this link's (pre-joint) frame
+            Rw = quat2mat(xquat0[par])
+            link_pos[l] = xpos0[par] + Rw @ m.body_pos[b]
+            link_quat[l] = mat2quat(Rw @ Rb)
+        else:
+            link_parent[l] = lid[head[par]]
+            link_pos[l] = prel[par] + Rrel[par] @ m.body_pos[b]
+            link_quat[l] = mat2quat(Rrel[par] @ Rb)
+        link_dofadr[l] = m.body_dofadr[b]
+        link_dofnum[l] = m.body_dofnum[b]
+    # merged inertias
+    for l, hb in enumerate(order):
+        members = [b for b in range(1, nb) if head[b] == hb]
+        mass = sum(m.body_mass[b] for b in members)
+        com = sum(m.body_mass[b] * (prel[b] + Rrel[b] @ m.body_ipos[b]) for b in members) / mass
+        I = np.zeros((3, 3))
+        for b in members:
+            Ri = Rrel[b] @ quat2mat(m.body_iquat[b])
+            d = prel[b] + Rrel[b] @ m.body_ipos[b] - com
+            I += Ri @ np.diag(m.body_inertia[b]) @ Ri.T + m.body_mass[b] * (d @ d * np.eye(3) - np.outer(d, d))
+        link_mass[l], link_com[l] = mass, com
+        link_inertia[l] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
+    # children CSR
+    child_adr = np.zeros(nl + 1, np.int32)
+    childs = []
+    for l in range(nl):
+        child_adr[l] = len(childs)
+        childs += [c for c in range(nl) if link_parent[c] == l]
+    child_adr[nl] = len(childs)
+    # dofs (hinge/slide: dof id == joint id ordering, qpos adr == dof adr)
+    dof_link = np.array([lid[m.dof_bodyid[d]] for d in range(nv)], np.int32)
+    assert all(m.jnt_qposadr[j] == m.jnt_dofadr[j] for j in range(len(m.jnt_type)))
+    dof_type = m.jnt_type[m.dof_jntid].astype(np.int32)
+    dof_pos = m.jnt_pos[m.dof_jntid]
+    dof_axis = m.jnt_axis[m.dof_jntid]
+    # ancestors (dof chains) helpers
+    def dof_chain(link):  # all dofs from root to this link (inclusive), as a set
+        s = []
+        l = link
+        while l >= 0:
+            s += list(range(link_dofadr[l], link_dofadr[l] + link_dofnum[l]))
+            l = link_parent[l]
+        return set(s)
+
+    def dof_list(link_a, link_b):
+        """(dof, sign) for the Jacobian difference J_b - J_a restricted to non-common dofs."""
+        ca = dof_chain(link_a) if link_a >= 0 else set()
+        cb = dof_chain(link_b) if link_b >= 0 else set()
+        out = [(d, +1) for d in sorted(cb - ca)] + [(d, -1) for d in sorted(ca - cb)]
+        return out
+
+    # ---- sites
+    ns = len(m.site_bodyid)
+    site_link = np.full(ns, -1, np.int32)
+    site_lpos = np.zeros((ns, 3))
+    for s in range(ns):
+        b = m.site_bodyid[s]
+        if b == 0 or head[b] == 0:
+            site_lpos[s] = xpos0[b] + quat2mat(xquat0[b]) @ m.site_pos[s]
+        else:
+            site_link[s] = lid[head[b]]
+            site_lpos[s] = prel[b] + Rrel[b] @ m.site_pos[s]
+    # ---- geoms in link frames
+    ng = len(m.geom_type)
+    geom_link = np.full(ng, -1, np.int32)
+    geom_lpos = np.zeros((ng, 3))
+    geom_lmat = np.zeros((ng, 9))
+    for g in range(ng):
+        b = m.geom_bodyid[g]
+        Rg = quat2mat(m.geom_quat[g])
+        if b == 0 or head[b] == 0:
+            Rw = quat2mat(xquat0[b])
+            geom_lpos[g] = xpos0[b] + Rw @ m.geom_pos[g]
+            geom_lmat[g] = (Rw @ Rg).ravel()
+        else:
+            geom_link[g] = lid[head[b]]
+            geom_lpos[g] = prel[b] + Rrel[b] @ m.geom_pos[g]
+            geom_lmat[g] = (Rrel[b] @ Rg).ravel()
+    # ---- tendons driven by actuators (gt index == actuator index), then limited-only tendons
+    nu = len(m.actuator_trnid)
+    gt_tendon = []
+    for i in range(nu):
+        if m.actuator_trntype[i] != 1:
+            raise NotImplementedError("HIP path: joint-transmission actuators")
+        gt_tendon.append(int(m.actuator_trnid[i]))
+    if len(set(gt_tendon)) != len(gt_tendon):
+        raise NotImplementedError("HIP path: two actuators on one tendon")
+    for t in range(len(m.tendon_adr)):
+        if t not in gt_tendon and (m.tendon_limited[t] or m.tendon_stiffness[t] or m.tendon_damping[t]):
+            gt_tendon.append(t)
+    segs, seg_div, dls = [], [], []
+    gt_seg_adr, gt_seg_num, gt_dofs = [], [], []
+    wg_ids = {}     # geom id -> wrap geom index
+
+    def wrap_index(g):
+        if g not in wg_ids:
+            wg_ids[g] = len(wg_ids)
+        return wg_ids[g]
+
+    for t in gt_tendon:
+        adr, num = m.tendon_adr[t], m.tendon_num[t]
+        gt_seg_adr.append(len(segs))
+        row = []       # dofs of this tendon's sparse Jacobian row
+
+        def add_list(la, lb):
+            lst = dof_list(la, lb)
+            a0 = len(dls)
+            for d, sgn in lst:
+                if d not in row:
+                    row.append(d)
+                dls.append((d, sgn, row.index(d)))
+            return a0, len(lst)
+
+        div = 1.0
+        j = 0
+        while j < num - 1:
+            t0, t1 = m.wrap_type[adr + j], m.wrap_type[adr + j + 1]
+            if t0 == WRAP_PULLEY or t1 == WRAP_PULLEY:
+                if t0 == WRAP_PULLEY:
+                    div = float(m.wrap_prm[adr + j])
+                j += 1
+                continue
+            s0 = int(m.wrap_objid[adr + j])
+            if t1 in (WRAP_SPHERE, WRAP_CYLINDER):
+                g = int(m.wrap_objid[adr + j + 1])
+                s1 = int(m.wrap_objid[adr + j + 2])
+                side = int(round(m.wrap_prm[adr + j + 1]))
+                d_adr, d_n = add_list(site_link[s0], site_link[s1])
+                a_adr, a_n = add_list(site_link[s0], geom_link[g])
+                b_adr, b_n = add_list(geom_link[g], site_link[s1])
+                segs.append([s0, s1, wrap_index(g), side, d_adr, d_n, a_adr, a_n, b_adr, b_n,
+                             1 if t1 == WRAP_CYLINDER else 0, 0])
+                j += 2
+            else:
+                s1 = int(m.wrap_objid[adr + j + 1])
+                d_adr, d_n = add_list(site_link[s0], site_link[s1])
+                segs.append([s0, s1, -1, -1, d_adr, d_n, 0, 0, 0, 0, 0, 0])
+                j += 1
+            seg_div.append(div)
+        gt_seg_num.append(len(segs) - gt_seg_adr[-1])
+        gt_dofs.append(row)
+    maxnnz = max([len(r) for r in gt_dofs] + [1])
+    ngt = len(gt_tendon)
+    gt_dof_tab = np.full((ngt, maxnnz), -1, np.int32)
+    for i, r in enumerate(gt_dofs):
+        gt_dof_tab[i, :len(r)] = r
+    # column CSR (per dof: which (tendon, slot) touch it), actuated tendons only
+    col_adr = np.zeros(nv + 1, np.int32)
+    cols = []
+    for d in range(nv):
+        col_adr[d] = len(cols)
+        for i in range(nu):
+            if d in gt_dofs[i]:
+                cols.append((i, gt_dofs[i].index(d)))
+    col_adr[nv] = len(cols)
+    wgs = sorted(wg_ids, key=lambda g: wg_ids[g])
+    # ---- actuator records
+    act = np.zeros((nu, ACT_FLTS))
+    for i in range(nu):
+        gp, bp = m.actuator_gainprm[i], m.actuator_biasprm[i]
+        if not np.allclose(gp, bp):
+            raise NotImplementedError("HIP path: muscle gainprm != biasprm")
+        force = gp[2] if gp[2] >= 0 else gp[3] / max(1e-15, m.actuator_acc0[i])
+        lr = m.actuator_lengthrange[i]
+        cr = m.actuator_ctrlrange[i] if m.actuator_ctrllimited[i] else (-1e30, 1e30)
+        if m.actuator_forcelimited[i]:
+            raise NotImplementedError("HIP path: forcelimited muscles")
+        if m.actuator_dynprm[i, 2] != 0:
+            raise NotImplementedError("HIP path: muscle tausmooth")
+        act[i] = [gp[0], gp[1], force, gp[4], gp[5], gp[6], gp[7], gp[8], lr[0], lr[1],
+                  m.actuator_dynprm[i, 0], m.actuator_dynprm[i, 1], cr[0], cr[1], m.actuator_gear[i], 0.0]
+    # ---- collision geoms + pair table
+    moving_links = nl > 0
+    reach = np.zeros(nl)
+    for l in range(nl):
+        jp = sum(np.linalg.norm(dof_pos[d]) for d in range(link_dofadr[l], link_dofadr[l] + link_dofnum[l]))
+        reach[l] = (reach[link_parent[l]] + np.linalg.norm(link_pos[l]) if link_parent[l] >= 0 else 0.0) + 2 * jp
+    cg_ids = {}
+    pairs_i, pairs_f, pair_dl = [], [], []
+
+    def cg_index(g):
+        if g not in cg_ids:
+            cg_ids[g] = len(cg_ids)
+        return cg_ids[g]
+
+    def geom_reach(g):   # (centre, radius) of a world sphere containing geom g in every pose
+        l = geom_link[g]
+        root = l
+        while link_parent[root] >= 0:
+            root = link_parent[root]
+        return link_pos[root], reach[l] + np.linalg.norm(geom_lpos[g]) + m.geom_rbound[g]
+
+    pruned = 0
+    for g1, g2 in m.pair_geom:
+        t1, t2 = m.geom_type[g1], m.geom_type[g2]
+        margin = max(m.geom_margin[g1], m.geom_margin[g2])
+        if geom_link[g1] < 0 and geom_link[g2] < 0:
+            continue
+        stat, mov = (g1, g2) if geom_link[g1] < 0 else ((g2, g1) if geom_link[g2] < 0 else (None, None))
+        if stat is not None and m.geom_type[stat] in (GEOM_PLANE, GEOM_CYLINDER):
+            c, r = geom_reach(mov)
+            R = geom_lmat[stat].reshape(3, 3)
+            axis = R[:, 2]
+            top = geom_lpos[stat] + (axis * m.geom_size[stat, 1] if m.geom_type[stat] == GEOM_CYLINDER else 0)
+            if (c - top) @ axis - r > margin:
+                pruned += 1
+                continue
+            raise NotImplementedError(f"HIP path: cannot prune static geom {stat} against moving geom {mov}")
+        ok = (GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_SPHERE)
+        if t1 not in ok or t2 not in ok:
+            raise NotImplementedError(f"HIP path: geom pair types {t1},{t2}")
+        lst = dof_list(geom_link[g1], geom_link[g2])
+        # contact parameter mixing (mj_contactParam), equal priorities
+        if m.geom_priority[g1] != m.geom_priority[g2]:
+            gsel = g1 if m.geom_priority[g1] > m.geom_priority[g2] else g2
+            solref, solimp, fric, condim = m.geom_solref[gsel], m.geom_solimp[gsel], m.geom_friction[gsel], m.geom_condim[gsel]
+        else:
+            s1, s2 = m.geom_solmix[g1], m.geom_solmix[g2]
+            mix = s1 / (s1 + s2) if (s1 >= 1e-15 and s2 >= 1e-15) else (0.5 if (s1 < 1e-15 and s2 < 1e-15) else (0.0 if s1 < 1e-15 else 1.0))
+            r1, r2 = m.geom_solref[g1], m.geom_solref[g2]
+            solref = mix * r1 + (1 - mix) * r2 if (r1[0] > 0 and r2[0] > 0) else np.minimum(r1, r2)
+            solimp = mix * m.geom_solimp[g1] + (1 - mix) * m.geom_solimp[g2]
+            fric = np.maximum(m.geom_friction[g1], m.geom_friction[g2])
+            condim = max(m.geom_condim[g1], m.geom_condim[g2])
+        if condim != 3:
+            raise NotImplementedError("HIP path: condim != 3")
+        b1, b2 = m.geom_bodyid[g1], m.geom_bodyid[g2]
+        invw = m.body_invweight0[b1, 0] + m.body_invweight0[b2, 0]
+        pairs_i.append([cg_index(g1), cg_index(g2), len(pair_dl), len(lst), int(t1 == GEOM_CAPSULE and t2 == GEOM_CAPSULE), 0])
+        pairs_f.append([margin, max(m.geom_gap[g1], m.geom_gap[g2]), fric[0], invw, solref[0], solref[1],
+                        solimp[0], solimp[1], solimp[2], solimp[3], solimp[4], 0.0])
+        pair_dl += lst
+    cgs = sorted(cg_ids, key=lambda g: cg_ids[g])
+    maxkc = max([p[3] for p in pairs_i] + [1])
+    # ---- joint limits
+    jl = np.zeros((nv, 12))
+    for d in range(nv):
+        j = m.dof_jntid[d]
+        jl[d] = [m.jnt_limited[j], m.jnt_range[j, 0], m.jnt_range[j, 1], m.jnt_margin[j], m.jnt_solref[j, 0],
+                 m.jnt_solref[j, 1], *m.jnt_solimp[j], m.dof_invweight0[d]]
+    tl = np.zeros((ngt, 12))
+    for i, t in enumerate(gt_tendon):
+        tl[i] = [m.tendon_limited[t], m.tendon_range[t, 0], m.tendon_range[t, 1], m.tendon_margin[t],
+                 m.tendon_solref[t, 0], m.tendon_solref[t, 1], *m.tendon_solimp[t], m.tendon_invweight0[t]]
+        if m.tendon_stiffness[t] or m.tendon_damping[t]:
+            raise NotImplementedError("HIP path: tendon spring/damper")
+    # ---- reference point for spatial quantities: COM of the moving bodies at qpos0
+    mv = [b for b in range(1, nb) if head[b]]
+    c0 = sum(m.body_mass[b] * (xpos0[b] + quat2mat(xquat0[b]) @ m.body_ipos[b]) for b in mv) / sum(m.body_mass[b] for b in mv)
+    # shift the world origin to c0: float coordinates stay < ~0.3 m instead of ~1.4 m (free precision);
+    # everything is translation invariant, outputs that are world positions add hip_origin back
+    for l in range(nl):
+        if link_parent[l] < 0:
+            link_pos[l] = link_pos[l] - c0
+    site_lpos[site_link < 0] -= c0
+    geom_lpos[geom_link < 0] -= c0
+    A["hip_origin"] = np.asarray(c0).copy()
+    c0 = np.zeros(3)
+    A["hip_sizes"] = np.array([nl, nlevel, nv, nu, ngt, len(segs), len(dls), maxnnz, len(wgs), len(cgs), len(pairs_i),
+                               maxkc, ns, len(cols), len(childs), pruned], np.int32)
+    A["hip_level_adr"] = level_adr
+    A["hip_link_parent"] = link_parent
+    A["hip_link_pos"] = link_pos
+    A["hip_link_quat"] = link_quat
+    A["hip_link_dofadr"] = link_dofadr
+    A["hip_link_dofnum"] = link_dofnum
+    A["hip_link_mass"] = link_mass
+    A["hip_link_com"] = link_com
+    A["hip_link_inertia"] = link_inertia
+    A["hip_child_adr"] = child_adr
+    A["hip_child"] = np.array(childs, np.int32)
+    A["hip_dof_link"] = dof_link
+    A["hip_dof_type"] = dof_type
+    A["hip_dof_pos"] = dof_pos
+    A["hip_dof_axis"] = dof_axis
+    A["hip_site_link"] = site_link
+    A["hip_site_lpos"] = site_lpos
+    A["hip_wg_link"] = geom_link[wgs] if wgs else np.zeros(0, np.int32)
+    A["hip_wg_lpos"] = geom_lpos[wgs] if wgs else np.zeros((0, 3))
+    A["hip_wg_lmat"] = geom_lmat[wgs] if wgs else np.zeros((0, 9))
+    A["hip_wg_radius"] = m.geom_size[wgs, 0] if wgs else np.zeros(0)
+    A["hip_gt_tendon"] = np.array(gt_tendon, np.int32)
+    A["hip_gt_seg_adr"] = np.array(gt_seg_adr, np.int32)
+    A["hip_gt_seg_num"] = np.array(gt_seg_num, np.int32)
+    A["hip_gt_dofs"] = gt_dof_tab
+    A["hip_seg"] = np.array(segs, np.int32).reshape(-1, SEG_INTS)
+    A["hip_seg_div"] = np.array(seg_div)
+    A["hip_dl"] = np.array(dls, np.int32).reshape(-1, 3)
+    A["hip_col_adr"] = col_adr
+    A["hip_col"] = np.array(cols, np.int32).reshape(-1, 2)
+    A["hip_act"] = act
+    A["hip_cg_link"] = geom_link[cgs] if cgs else np.zeros(0, np.int32)
+    A["hip_cg_type"] = m.geom_type[cgs] if cgs else np.zeros(0, np.int32)
+    A["hip_cg_lpos"] = geom_lpos[cgs] if cgs else np.zeros((0, 3))
+    A["hip_cg_lmat"] = geom_lmat[cgs] if cgs else np.zeros((0, 9))
+    A["hip_cg_size"] = m.geom_size[cgs] if cgs else np.zeros((0, 3))
+    A["hip_cg_rbound"] = m.geom_rbound[cgs] if cgs else np.zeros(0)
+    A["hip_cg_geom"] = np.array(cgs, np.int32)
+    A["hip_pair_i"] = np.array(pairs_i, np.int32).reshape(-1, PAIR_INTS)
+    A["hip_pair_f"] = np.array(pairs_f).reshape(-1, PAIR_FLTS)
+    A["hip_pair_dl"] = np.array(pair_dl, np.int32).reshape(-1, 2)
+    A["hip_jl"] = jl
+    A["hip_tl"] = tl
+    A["hip_c0"] = np.asarray(c0)
     return cm

@@ -505,10 +505,19 @@ static real wrap_circle(real* pnt, const real* d, const real* sd, real rad) {
       real t[2] = {sol[i][0] - sol[i][2], sol[i][1] - sol[i][3]};
       good[i] = -(t[0] * t[0] + t[1] * t[1]);
     }
+#ifdef MYOO_FLOAT
+    /* float build (mirrors the HIP kernel): a grazing solution (tangent points closer than 1e-3 rad)
+     * makes the segment-intersection test meaningless in float; skip it there */
+    real gz0 = sol[i][0] - sol[i][2], gz1 = sol[i][1] - sol[i][3];
+    if (gz0 * gz0 + gz1 * gz1 < (real)1e-6 * sqr) continue;
+#endif
     if (is_intersect(d, sol[i], d + 2, sol[i] + 2)) good[i] = -10000;
   }
   int i = good[0] > good[1] ? 0 : 1;
   memcpy(pnt, sol[i], 4 * sizeof(real));
+#ifdef MYOO_FLOAT
+  if ((pnt[0] - pnt[2]) * (pnt[0] - pnt[2]) + (pnt[1] - pnt[3]) * (pnt[1] - pnt[3]) >= (real)1e-6 * sqr)
+#endif
   if (is_intersect(d, pnt, d + 2, pnt + 2)) return -1;
   return rad * acos(clipr((pnt[0] * pnt[2] + pnt[1] * pnt[3]) / sqr, -1, 1));
 }
@@ -536,6 +545,23 @@ static real wrap_inside(real* pnt, const real* d, real rad) {
   if (cosG < -1 + MINVAL) return -1;
   if (cosG > 1 - MINVAL) return 0;
   real G = acos(cosG);
+#ifdef MYOO_FLOAT
+  /* float build: Newton on theta = asin(z) (same root, well conditioned near z -> 1); mirrors the HIP kernel */
+  (void)zinit;
+  real th = (real)1.5707963267948966 - (real)4.4721360e-4;
+  real sn = sin(th), f = asin(A * sn) + asin(B * sn) - 2 * th + G;
+  if (f > 0) return 0;
+  for (int iter = 0; iter < maxiter && fabs(f) > tolerance; iter++) {
+    real cs = cos(th);
+    real df = A * cs / maxr(MINVAL, sqrt(1 - A * A * sn * sn)) + B * cs / maxr(MINVAL, sqrt(1 - B * B * sn * sn)) - 2;
+    th = clipr(th - f / df, (real)1e-6, (real)1.5707963267948966);
+    sn = sin(th);
+    f = asin(A * sn) + asin(B * sn) - 2 * th + G;
+  }
+  real vec[2], ang;
+  if (d[0] * d[3] - d[1] * d[2] > 0) { vec[0] = d[0] / len0; vec[1] = d[1] / len0; ang = th - asin(A * sn); }
+  else { vec[0] = d[2] / len1; vec[1] = d[3] / len1; ang = th - asin(B * sn); }
+#else
   real z = zinit;
   real f = asin(A * z) + asin(B * z) - 2 * asin(z) + G;
   if (f > 0) return 0;
@@ -554,6 +580,7 @@ static real wrap_inside(real* pnt, const real* d, real rad) {
   real vec[2], ang;
   if (d[0] * d[3] - d[1] * d[2] > 0) { vec[0] = d[0] / len0; vec[1] = d[1] / len0; ang = asin(z) - asin(A * z); }
   else { vec[0] = d[2] / len1; vec[1] = d[3] / len1; ang = asin(z) - asin(B * z); }
+#endif
   pnt[0] = rad * (cos(ang) * vec[0] - sin(ang) * vec[1]);
   pnt[1] = rad * (sin(ang) * vec[0] + cos(ang) * vec[1]);
   pnt[2] = pnt[0]; pnt[3] = pnt[1];
@@ -1043,9 +1070,9 @@ static int mpr_penetration(const CObj* o1, const CObj* o2, real tol, int maxit, 
     else { if (dot3(p[3].v, va) > 0) p[2] = v4; else p[1] = v4; }
   }
   /* push the portal to the surface of the Minkowski difference (libccd findPenetr) */
+  Sup v4;
   for (int it = 0;; it++) {
     portal_dir(p, dir);
-    Sup v4;
     mink_support(o1, o2, dir, &v4);
     real dv4 = dot3(v4.v, dir);
     real dmin = minr(minr(dv4 - dot3(p[1].v, dir), dv4 - dot3(p[2].v, dir)), dv4 - dot3(p[3].v, dir));
@@ -1054,40 +1081,52 @@ static int mpr_penetration(const CObj* o1, const CObj* o2, real tol, int maxit, 
     if (dot3(p[1].v, va) > 0) { if (dot3(p[2].v, va) > 0) p[1] = v4; else p[3] = v4; }
     else { if (dot3(p[3].v, va) > 0) p[2] = v4; else p[1] = v4; }
   }
-  /* penetration: distance from origin to the portal plane along its normal */
-  portal_dir(p, dir);
-  /* nearest point of the portal triangle to the origin */
-  real a[3], b[3], c0[3];
-  memcpy(a, p[1].v, sizeof a); memcpy(b, p[2].v, sizeof b); memcpy(c0, p[3].v, sizeof c0);
-  real ab[3], ac[3], ap[3];
-  for (int k = 0; k < 3; k++) { ab[k] = b[k] - a[k]; ac[k] = c0[k] - a[k]; ap[k] = -a[k]; }
-  real d1 = dot3(ab, ap), d2 = dot3(ac, ap), w0, w1, w2;
-  real bp[3] = {-b[0], -b[1], -b[2]}, cp[3] = {-c0[0], -c0[1], -c0[2]};
-  real d3 = dot3(ab, bp), d4 = dot3(ac, bp), d5 = dot3(ab, cp), d6 = dot3(ac, cp);
-  real vc = d1 * d4 - d3 * d2, vb2 = d5 * d2 - d1 * d6, va2 = d3 * d6 - d5 * d4;
-  if (d1 <= 0 && d2 <= 0) { w0 = 1; w1 = 0; w2 = 0; }
-  else if (d3 >= 0 && d4 <= d3) { w0 = 0; w1 = 1; w2 = 0; }
-  else if (vc <= 0 && d1 >= 0 && d3 <= 0) { w1 = d1 / (d1 - d3); w0 = 1 - w1; w2 = 0; }
-  else if (d6 >= 0 && d5 <= d6) { w0 = 0; w1 = 0; w2 = 1; }
-  else if (vb2 <= 0 && d2 >= 0 && d6 <= 0) { w2 = d2 / (d2 - d6); w0 = 1 - w2; w1 = 0; }
-  else if (va2 <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { w2 = (d4 - d3) / ((d4 - d3) + (d5 - d6)); w1 = 1 - w2; w0 = 0; }
-  else { real den = 1 / (va2 + vb2 + vc); w1 = vb2 * den; w2 = vc * den; w0 = 1 - w1 - w2; }
-  real q[3];
-  for (int k = 0; k < 3; k++) q[k] = w0 * a[k] + w1 * b[k] + w2 * c0[k];
-  *depth = norm3(q);
-  if (*depth > MINVAL) { for (int k = 0; k < 3; k++) dirout[k] = q[k] / *depth; }
-  else memcpy(dirout, dir, 3 * sizeof(real));
-  for (int k = 0; k < 3; k++)
-    posout[k] = (real)0.5 * (w0 * (p[1].v1[k] + p[1].v2[k]) + w1 * (p[2].v1[k] + p[2].v2[k]) + w2 * (p[3].v1[k] + p[3].v2[k]));
+  /* Output from the final SUPPORT PLANE rather than libccd's nearest point on the portal triangle: for the
+   * smooth shapes handled here the support point s(dir) has outward normal exactly `dir`, so (dir, dir.s(dir))
+   * is an exact supporting plane of the inflated Minkowski difference.  libccd's triangle-nearest-point output
+   * switches between face / edge / vertex cases when the overlap is tiny and is not a continuous function of
+   * the pose ("ellipsoid contacts"). */
+  *depth = dot3(v4.v, dir);
+  /* contact position: barycentric coordinates of the origin in the tetrahedron (v0, portal), applied to the
+   * witness points (libccd findPos) -- interpolates along flat / ruled parts such as a capsule's side */
+  real bw[4], cr[3];
+  cross3(cr, p[1].v, p[2].v); bw[0] = dot3(cr, p[3].v);
+  cross3(cr, p[3].v, p[2].v); bw[1] = dot3(cr, p[0].v);
+  cross3(cr, p[0].v, p[1].v); bw[2] = dot3(cr, p[3].v);
+  cross3(cr, p[2].v, p[1].v); bw[3] = dot3(cr, p[0].v);
+  real sum = bw[0] + bw[1] + bw[2] + bw[3];
+  if (sum <= 0) {
+    bw[0] = 0;
+    cross3(cr, p[2].v, p[3].v); bw[1] = dot3(cr, dir);
+    cross3(cr, p[3].v, p[1].v); bw[2] = dot3(cr, dir);
+    cross3(cr, p[1].v, p[2].v); bw[3] = dot3(cr, dir);
+    sum = bw[1] + bw[2] + bw[3];
+  }
+  real inv = 1 / sum;
+  for (int k = 0; k < 3; k++) {
+    dirout[k] = dir[k];
+    posout[k] = (real)0.5 * inv * (bw[0] * (p[0].v1[k] + p[0].v2[k]) + bw[1] * (p[1].v1[k] + p[1].v2[k]) +
+                                   bw[2] * (p[2].v1[k] + p[2].v2[k]) + bw[3] * (p[3].v1[k] + p[3].v2[k]));
+  }
   return 1;
 }
 
 static int convex_pair(const Model* m, const Data* d, Contact* c, real margin, int g1, int g2) {
   if (m->geom_type[g1] == GEOM_PLANE) return 0; /* plane vs non-capsule convex: pruned at compile time for config models */
-  CObj o1 = {d->geom_xpos + 3 * g1, d->geom_xmat + 9 * g1, m->geom_size + 3 * g1, m->geom_type[g1], margin * (real)0.5};
-  CObj o2 = {d->geom_xpos + 3 * g2, d->geom_xmat + 9 * g2, m->geom_size + 3 * g2, m->geom_type[g2], margin * (real)0.5};
+  /* coordinates relative to geom1's centre; tolerance converged well below MuJoCo's ccd_tolerance (1e-6) so that
+   * the result is the path-independent limit of the portal refinement ("ellipsoid contacts") */
+  const real zero3[3] = {0, 0, 0};
+  real rel[3];
+  for (int k = 0; k < 3; k++) rel[k] = d->geom_xpos[3 * g2 + k] - d->geom_xpos[3 * g1 + k];
+  CObj o1 = {zero3, d->geom_xmat + 9 * g1, m->geom_size + 3 * g1, m->geom_type[g1], margin * (real)0.5};
+  CObj o2 = {rel, d->geom_xmat + 9 * g2, m->geom_size + 3 * g2, m->geom_type[g2], margin * (real)0.5};
   real depth, dir[3], pos[3];
-  if (!mpr_penetration(&o1, &o2, (real)1e-6, 50, &depth, dir, pos)) return 0;
+#ifdef MYOO_FLOAT
+  if (!mpr_penetration(&o1, &o2, (real)1e-8, 60, &depth, dir, pos)) return 0;
+#else
+  if (!mpr_penetration(&o1, &o2, (real)1e-11, 100, &depth, dir, pos)) return 0;
+#endif
+  for (int k = 0; k < 3; k++) pos[k] += d->geom_xpos[3 * g1 + k];
   c->dist = margin - depth;
   /* dir points from the origin to the nearest boundary point of (obj1 - obj2): translating obj2 by
    * depth*dir separates the pair, so dir is the contact normal from geom1 to geom2 */
