@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched MyoSuite env.step() hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json metric): myoHandPoseRandom-v0, 4096 envs per GPU (weak scaling), one "step" = one
+batched env step = action map + 10 fused physics substeps + obs/reward + TimeLimit/done auto-reset, with
+synthetic U(-1,1) actions generated on the device by a counter RNG inside the timed region.  For N > 1 every
+step also all-gathers the observations over RCCL (the only collective the path has).  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU = 4096
+ENV_ID = "myoHandPoseRandom-v0"
+B_ALG = 1560.0          # algorithmic HBM bytes per env-step, MyoHand pose
+F_ALG_EST = 1.2e6       # flop per env-step: SURVEY.md 8d ESTIMATE (1.0-1.5 Mflop), not an instrumented count
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md
+FP32_PEAK_TFLOPS = 157.3
+
+
+def cpu_baseline(seconds_target=12.0):
+    """The f64 C oracle stepping the same workload on every host core (kind 'port'), bounded sample."""
+    import numpy as np
+    from myosuite_mjx_amd import model as M
+    from myosuite_mjx_amd.envs import REGISTRY
+    from oracle.oracle import Oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    m = M.load_asset("myohand_pose")
+    o = Oracle(m.blob())
+    spec = REGISTRY[ENV_ID]
+    rng = np.random.default_rng(0)
+    envs_per_core, nsteps = 32, 40
+    B = envs_per_core * cores
+    qpos = rng.uniform(m.jnt_range[:, 0], m.jnt_range[:, 1], (B, m.nq))
+    qvel = np.zeros((B, m.nv)); act = np.zeros((B, m.nu)); warm = np.zeros((B, m.nv)); tm = np.zeros(B)
+    t0 = time.perf_counter()
+    done_steps = 0
+    for s in range(nsteps):
+        a = rng.uniform(-1, 1, (B, m.nu))
+        ctrl = np.ascontiguousarray(1.0 / (1.0 + np.exp(-5.0 * (a - 0.5))))
+        o.step_batch(qpos, qvel, act, warm, tm, ctrl, spec["frame_skip"], cores)
+        done_steps += 1
+        if time.perf_counter() - t0 > seconds_target:
+            break
+    el = time.perf_counter() - t0
+    return {"value": B * done_steps / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{B} envs x {done_steps} env-steps (10 substeps each) of {ENV_ID}, f64 C oracle, {cores} threads, {el:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=B_PER_GPU, help="envs per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from myosuite_mjx_amd import capi
+    from myosuite_mjx_amd.envs import BatchedMyoEnv
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP stepper has no CPU fallback")
+    torch.cuda.set_device(local)
+    B = args.batch
+    env = BatchedMyoEnv(ENV_ID, num_envs=B, device=local, seed=0, env_offset=rank * B)
+    env.reset(seed=0)
+    stream = torch.cuda.current_stream(local).cuda_stream
+    mode = capi.BENCH_OBS | capi.BENCH_FRESH_ACTIONS | capi.BENCH_AUTORESET
+    obs = env.view(capi.F_OBS)
+    gathered = torch.empty((world * B, env.obs_dim), dtype=torch.float32, device=obs.device) if world > 1 else None
+
+    def run(nsteps):
+        """nsteps batched env steps; returns HIP-event milliseconds of the step work on this rank."""
+        if world == 1:
+            return env.batch.bench_rollout(nsteps, env.frame_skip, 0, mode, env.max_episode_steps, stream)
+        ms = 0.0
+        for _ in range(nsteps):
+            ms += env.batch.bench_rollout(1, env.frame_skip, 0, mode, env.max_episode_steps, stream)
+            dist.all_gather_into_tensor(gathered, obs)     # cross-GPU observation gather (RCCL over xGMI)
+        return ms
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev_ms = run(args.steps)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([el], device=obs.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    # dominant kernel alone (fused step kernel, fixed actions): HIP events on the launch stream
+    k_steps = max(10, min(args.steps, 100))
+    k_ms = env.batch.bench_rollout(k_steps, env.frame_skip, 0, 0, 0, stream) / k_steps
+    flags = env.status()
+    if rank == 0:
+        value = world * B * args.steps / el
+        achieved = B_ALG * B / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/s (whole node) myoHandPoseRandom-v0 batch 4096", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{ENV_ID}, {B} envs per GPU, frame_skip=10 (dt=0.002), U(-1,1) device-generated actions, "
+                                   "obs+reward+TimeLimit(100)/done auto-reset inside the timed region"
+                                   + (", RCCL obs all-gather per step" if world > 1 else ""),
+                       "global_batch": world * B, "parallelism": f"env-shard x{world}", "lanes_per_env": 16,
+                       "substeps_per_s": value * env.frame_skip},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "step_kernel<16>", "kernel_ms": k_ms, "alg_bytes_per_launch": B_ALG * B,
+                         "note": "path is FP32-VALU/latency bound, not HBM bound (SURVEY.md 8d); fp32 view alongside",
+                         "fp32": {"achieved_tflops_est": F_ALG_EST * B / (k_ms * 1e-3) / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
+                                  "frac_est": F_ALG_EST * B / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "flop_per_env_step": "SURVEY 8d estimate"}},
+            "event_ms_per_step_rank0": ev_ms / args.steps,
+            "flagged_envs": int((flags != 0).sum()),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

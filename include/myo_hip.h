@@ -59,6 +59,7 @@ typedef enum myo_field {
   MYO_F_TENLEN,      /* [B][nu]  actuator (tendon) lengths of the last substep */
   MYO_F_ACTFORCE,    /* [B][nu]  actuator forces of the last substep */
   MYO_F_SITEXPOS,    /* [B][3*ntip] tip site world positions after the step (reach task) */
+  MYO_F_ELAPSED,     /* [B][1] int32 env steps since the last reset (gym TimeLimit counter) */
   MYO_F_COUNT
 } myo_field;
 
@@ -112,15 +113,27 @@ int myo_set_state(myo_batch*, const float* qpos, const float* qvel, const float*
 int myo_step(myo_batch*, const float* action_dev, int actmap, int nsubsteps, void* stream);
 /* observation / reward / done for the configured task into MYO_F_OBS / REWARD / DONE / SOLVED */
 int myo_obs(myo_batch*, void* stream);
+/* observation vector only (reward / done / solved untouched): used after an auto-reset */
+int myo_obs_only(myo_batch*, void* stream);
+/* gym TimeLimit + done handling (envs/myo/myobase/__init__.py max_episode_steps): reset every env whose done flag is
+ * set or whose elapsed env-step counter reached max_episode_steps, with the configured reset / target sampling */
+int myo_autoreset(myo_batch*, int max_episode_steps, uint64_t seed, void* stream);
+/* global id of this batch's env 0 (multi-GPU sharding: RNG streams are keyed by global env id) */
+int myo_set_env_offset(myo_batch*, int env_offset);
 /* copy per-env int32 flags to host and clear them */
 int myo_status(myo_batch*, int32_t* host_flags);
 /* fill action[B][nu] with U(-1,1) from a counter-based generator (seed, step, global env id) */
 int myo_random_action(myo_batch*, float* action_dev, uint64_t seed, uint64_t step, int env_offset, void* stream);
 int myo_sync(void* stream);
+/* lanes cooperating on one env (16, 32 or 64; default 16 or $MYO_LANES) -- a tuning knob, results are identical up to float round-off */
+int myo_set_lanes(int lanes);
+/* diagnostic build (-DMYO_STAMPS=1) only: per-workgroup clock64 totals per kernel stage; returns 1 in the normal build */
+int myo_read_stamps(myo_batch*, long long* host, int nwg);
 
-/* timing helper for bench.py: run `steps` env steps (random actions, fused) on `stream` bracketed by HIP
- * events recorded on that same stream; returns elapsed milliseconds in *ms_out */
-int myo_bench_rollout(myo_batch*, int steps, int nsubsteps, uint64_t seed, int with_obs, void* stream, float* ms_out);
+/* timing helper for bench.py: run `steps` env steps on `stream` bracketed by HIP events recorded on that same
+ * stream; returns elapsed milliseconds in *ms_out.  mode bits select what runs inside the timed region. */
+enum { MYO_BENCH_OBS = 1, MYO_BENCH_FRESH_ACTIONS = 2, MYO_BENCH_AUTORESET = 4 };
+int myo_bench_rollout(myo_batch*, int steps, int nsubsteps, uint64_t seed, int mode, int max_episode_steps, void* stream, float* ms_out);
 
 #ifdef __cplusplus
 }

@@ -9,13 +9,14 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmyo_hip.so")
+LIB_PATH = os.environ.get("MYO_HIP_LIB") or os.path.join(_HERE, "libmyo_hip.so")
 SRC_PATH = os.path.join(_HERE, "csrc", "myo_hip.hip")
 
 # field ids (myo_field)
 (F_QPOS, F_QVEL, F_ACT, F_CTRL, F_WARMSTART, F_TIME, F_TARGET, F_OBS, F_REWARD, F_DONE, F_SOLVED, F_FLAGS, F_DIAG,
- F_QACC, F_TENLEN, F_ACTFORCE, F_SITEXPOS) = range(17)
-INT_FIELDS = (F_FLAGS, F_DIAG)
+ F_QACC, F_TENLEN, F_ACTFORCE, F_SITEXPOS, F_ELAPSED) = range(18)
+INT_FIELDS = (F_FLAGS, F_DIAG, F_ELAPSED)
+BENCH_OBS, BENCH_FRESH_ACTIONS, BENCH_AUTORESET = 1, 2, 4
 ACTMAP_NONE, ACTMAP_MUSCLE_SIGMOID = 0, 1
 TASK_NONE, TASK_POSE, TASK_REACH = 0, 1, 2
 FLAG_BAD_STATE, FLAG_BAD_QACC, FLAG_CONTACT_OVERFLOW, FLAG_CAND_OVERFLOW = 1, 2, 4, 8
@@ -76,7 +77,12 @@ def lib():
         L.myo_status.argtypes = [C.c_void_p, C.c_void_p]
         L.myo_random_action.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
         L.myo_sync.argtypes = [C.c_void_p]
-        L.myo_bench_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+        L.myo_bench_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+        L.myo_obs_only.argtypes = [C.c_void_p, C.c_void_p]
+        L.myo_autoreset.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
+        L.myo_set_env_offset.argtypes = [C.c_void_p, C.c_int]
+        L.myo_set_lanes.argtypes = [C.c_int]
+        L.myo_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -181,10 +187,33 @@ class HipBatch:
     def random_action(self, action_ptr, seed, step, env_offset=0, stream=None):
         _chk(lib().myo_random_action(self.h, action_ptr, seed, step, env_offset, stream))
 
-    def bench_rollout(self, steps, nsub, seed=0, with_obs=True, stream=None) -> float:
+    def obs_only(self, stream=None):
+        _chk(lib().myo_obs_only(self.h, stream))
+
+    def autoreset(self, max_episode_steps, seed=0, stream=None):
+        _chk(lib().myo_autoreset(self.h, max_episode_steps, seed, stream))
+
+    def set_env_offset(self, off):
+        _chk(lib().myo_set_env_offset(self.h, off))
+
+    def bench_rollout(self, steps, nsub, seed=0, mode=BENCH_OBS | BENCH_FRESH_ACTIONS | BENCH_AUTORESET, max_episode_steps=100,
+                      stream=None) -> float:
+        """Runs `steps` env steps on `stream`; returns the HIP-event elapsed milliseconds."""
         ms = C.c_float()
-        _chk(lib().myo_bench_rollout(self.h, steps, nsub, seed, int(with_obs), stream, C.byref(ms)))
+        _chk(lib().myo_bench_rollout(self.h, steps, nsub, seed, mode, max_episode_steps, stream, C.byref(ms)))
         return ms.value
+
+
+def set_lanes(lanes):
+    _chk(lib().myo_set_lanes(lanes))
+
+
+def read_stamps(batch, nwg):
+    out = np.zeros((nwg, 12), np.int64)
+    rc = lib().myo_read_stamps(batch.h, out.ctypes.data, nwg)
+    if rc < 0:
+        _chk(rc)
+    return out, rc == 0
 
 
 def sync(stream=None):

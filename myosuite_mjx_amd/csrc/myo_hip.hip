@@ -56,7 +56,7 @@ struct DevModel {
   int nl, nlevel, nv, nu, ngt, nseg, maxnnz, nwg, ncg, npair, maxkc, ns, nM;
   int iterations, ls_iterations;
   int disable_contact, disable_limit, disable_ellipsoid;
-  float timestep, grav[3], tolerance, ls_tolerance, meaninertia, c0[3];
+  float timestep, grav[3], tolerance, ls_tolerance, meaninertia, c0[3], origin[3];
   const int *level_adr, *link_parent, *link_dofadr, *link_dofnum, *child_adr, *child, *dof_link, *dof_type, *dof_parent;
   const int *site_link, *wg_link, *gt_seg_adr, *gt_seg_num, *gt_dofs, *seg, *dl, *col_adr, *col;
   const int *cg_link, *cg_type, *pair_i, *pair_dl;
@@ -71,7 +71,7 @@ struct DevModel {
 struct DevBatch {
   int B;
   float *qpos, *qvel, *act, *ctrl, *warm, *time, *target, *obs, *reward, *done, *solved, *qacc, *tenlen, *actforce, *sitexpos;
-  int *flags, *diag;
+  int *flags, *diag, *elapsed, *episode;
 };
 
 struct TaskDev {
@@ -145,6 +145,22 @@ template <int G> __device__ __forceinline__ int grp_maxi(int x) {
   return x;
 }
 #define SYNC() __syncthreads()
+// position of this lane among the set lanes of its G-lane group, and the group's set count
+template <int G> __device__ __forceinline__ void grp_rank(bool pred, int grp, int sub, int* rank, int* count) {
+  unsigned long long bal = __ballot(pred);
+  unsigned long long gmask = (G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull);
+  unsigned long long g = (bal >> (grp * (G & 63))) & gmask;
+  *rank = __popcll(g & ((1ull << sub) - 1ull));
+  *count = __popcll(g);
+}
+#ifndef MYO_STAMPS
+#define MYO_STAMPS 0
+#endif
+#if MYO_STAMPS
+#define STAMP(k) do { long long t1_ = clock64(); st_acc[k] += t1_ - st_t0; st_t0 = t1_; } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 #define GFOR(i, n) for (int i = sub; i < (n); i += G)
 
 // 10-element spatial inertia times a motion vector (ang, lin)
@@ -876,7 +892,6 @@ template <int G> __device__ int stage_collision(const DevModel& M, float* E, int
     }
   }
   SYNC();
-  const unsigned long long gm = (G == 64) ? ~0ull : ((1ull << G) - 1ull);
   int ncand = 0;
   int* cand = (int*)(E + Y.cand);
   for (int base = 0; base < M.npair; base += G) {
@@ -892,11 +907,11 @@ template <int G> __device__ int stage_collision(const DevModel& M, float* E, int
         hit = dot3(dif, dif) <= bound * bound;
       }
     }
-    unsigned long long bal = __ballot(hit);
-    unsigned int g16 = (unsigned int)((bal >> (grp * G)) & gm);
-    int pos = ncand + __popc(g16 & ((1u << sub) - 1u));
+    int rk, cnt;
+    grp_rank<G>(hit, grp, sub, &rk, &cnt);
+    int pos = ncand + rk;
     if (hit && pos < NCAND) cand[pos] = p;
-    ncand += __popc(g16);
+    ncand += cnt;
   }
   if (ncand > NCAND) { *flags |= MYO_FLAG_CAND_OVERFLOW; ncand = NCAND; }
   SYNC();
@@ -960,16 +975,16 @@ template <int G> __device__ int stage_collision(const DevModel& M, float* E, int
       // contacts at or beyond the inclusion margin generate no rows (margin - gap)
       if (hit && !(dist < margin - M.pair_f[12 * p + 1])) hit = false;
     }
-    unsigned long long bal = __ballot(hit);
-    unsigned int g16 = (unsigned int)((bal >> (grp * G)) & gm);
-    int pos = ncon + __popc(g16 & ((1u << sub) - 1u));
+    int rk, cnt;
+    grp_rank<G>(hit, grp, sub, &rk, &cnt);
+    int pos = ncon + rk;
     if (hit && pos < NCON) {
       E[Y.cdist + pos] = dist;
 #pragma unroll
       for (int k = 0; k < 3; k++) { E[Y.cpos + 3 * pos + k] = cpos[k]; E[Y.cnrm + 3 * pos + k] = nrm[k]; }
       ((int*)(E + Y.cpair))[pos] = p;
     }
-    ncon += __popc(g16);
+    ncon += cnt;
   }
   if (ncon > NCON) { *flags |= MYO_FLAG_CONTACT_OVERFLOW; ncon = NCON; }
   SYNC();
@@ -1115,8 +1130,13 @@ template <int G> __device__ void rows_force_hessian(const DevModel& M, float* E,
 // ------------------------------------------------------------------------------------------------
 // the fused env-step kernel
 template <int G>
-__global__ void __launch_bounds__(64) step_kernel(DevModel M, DevBatch Bt, const float* __restrict__ action, int actmap, int nsub) {
+__global__ void __launch_bounds__(64) step_kernel(DevModel M, DevBatch Bt, const float* __restrict__ action, int actmap, int nsub,
+                                                  long long* stamps) {
   extern __shared__ __align__(16) float smem[];
+#if MYO_STAMPS
+  long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long st_t0 = clock64();
+#endif
   const Lay& Y = M.lay;
   const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
   const int EPW = 64 / G;
@@ -1154,17 +1174,24 @@ __global__ void __launch_bounds__(64) step_kernel(DevModel M, DevBatch Bt, const
       bad = grp_maxi<G>(bad);
       if (bad && alive) { flags |= MYO_FLAG_BAD_STATE; alive = false; }
     }
+    STAMP(0);
     stage_kinematics<G>(M, E, sub);
+    STAMP(1);
     stage_tendon<G>(M, E, sub);
     SYNC();
+    STAMP(2);
     stage_dynamics<G>(M, E, sub);
+    STAMP(3);
     int ncon = stage_collision<G>(M, E, sub, grp, &flags);
+    STAMP(4);
     stage_constraints<G>(M, E, sub, ncon);
+    STAMP(5);
     // ---- unconstrained acceleration: qas = M^-1 smooth
     GFOR(i, (nv * (nv + 1)) / 2) E[Y.Hp + i] = E[Y.Mp + i];
     GFOR(i, nv) E[Y.qas + i] = E[Y.smooth + i];
     chol_packed<G>(E + Y.Hp, nv, sub);
     chol_solve<G>(E + Y.Hp, E + Y.qas, nv, sub);
+    STAMP(6);
     // ---- constraint solver
     int nlim = 0;
     GFOR(d, nv) nlim += E[Y.lsign + d] != 0 ? 1 : 0;
@@ -1282,6 +1309,7 @@ __global__ void __launch_bounds__(64) step_kernel(DevModel M, DevBatch Bt, const
       GFOR(i, nv) { E[Y.qacc + i] = E[Y.qas + i]; E[Y.qfc + i] = 0; }
     }
     SYNC();
+    STAMP(7);
     d_nefc = nefc; d_ncon = ncon; d_iter = max(d_iter, iters);
     // mj_checkAcc
     {
@@ -1303,6 +1331,7 @@ __global__ void __launch_bounds__(64) step_kernel(DevModel M, DevBatch Bt, const
       time += h;
     }
     SYNC();
+    STAMP(8);
   }
   // a bad env is reset like mj_resetData (mj_sim_scene.py:56-61)
   if (!alive) {
@@ -1326,10 +1355,15 @@ __global__ void __launch_bounds__(64) step_kernel(DevModel M, DevBatch Bt, const
     }
     if (sub == 0) {
       Bt.time[env] = time;
+      Bt.elapsed[env] += 1;
       Bt.flags[env] |= flags;
       Bt.diag[(size_t)env * 8 + 0] = d_nefc; Bt.diag[(size_t)env * 8 + 1] = d_ncon; Bt.diag[(size_t)env * 8 + 2] = d_iter;
     }
   }
+#if MYO_STAMPS
+  STAMP(9);
+  if (stamps && lane == 0) for (int k = 0; k < 12; k++) stamps[(size_t)blockIdx.x * 12 + k] = st_acc[k];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1349,10 +1383,16 @@ __global__ void random_action_kernel(float* action, int B, int nu, uint64_t seed
   action[i] = 2.0f * u01(seed, (uint64_t)(e + env_offset) * 1024 + k, step) - 1.0f;
 }
 
-__global__ void reset_kernel(DevBatch Bt, TaskDev T, int nv, int nu, const float* qpos0, const uint8_t* mask, uint64_t seed, int env_offset) {
+// auto_max > 0: gym TimeLimit / done auto-reset (reset iff done or elapsed >= auto_max); else mask-driven reset
+__global__ void reset_kernel(DevBatch Bt, TaskDev T, int nv, int nu, const float* qpos0, const uint8_t* mask, uint64_t seed, int env_offset,
+                             int auto_max) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= Bt.B) return;
-  if (mask && !mask[e]) return;
+  if (auto_max > 0) { if (!(Bt.done[e] > 0.f || Bt.elapsed[e] >= auto_max)) return; }
+  else if (mask && !mask[e]) return;
+  seed += 0x632BE59BD9B4E019ull * (uint64_t)(Bt.episode[e]++);  // a fresh RNG stream per (env, episode)
+  Bt.elapsed[e] = 0;
+  Bt.done[e] = 0.f;
   uint64_t ge = (uint64_t)(e + env_offset);
   for (int i = 0; i < nv; i++) {
     float q = T.init_qpos ? T.init_qpos[i] : qpos0[i];
@@ -1370,7 +1410,7 @@ __global__ void reset_kernel(DevBatch Bt, TaskDev T, int nv, int nu, const float
 }
 
 // observation + reward (pose_v0.py:98-138, reach_v0.py:88-144, obs_vec_dict.py:86-98); one lane per env
-__global__ void obs_kernel(DevModel M, DevBatch Bt, TaskDev T) {
+__global__ void obs_kernel(DevModel M, DevBatch Bt, TaskDev T, int obs_only) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= Bt.B) return;
   const int nv = M.nv, nu = M.nu;
@@ -1390,6 +1430,7 @@ __global__ void obs_kernel(DevModel M, DevBatch Bt, TaskDev T) {
       err2 += pe * pe;
     }
     for (int i = 0; i < nu; i++) o[3 * nv + i] = a[i];
+    if (obs_only) return;
     float dist = sqrtf(err2);
     float bonus = (dist < T.pose_thd ? 1.f : 0.f) + (dist < 1.5f * T.pose_thd ? 1.f : 0.f);
     float pen = dist > T.far_th ? -1.f : 0.f;
@@ -1401,7 +1442,7 @@ __global__ void obs_kernel(DevModel M, DevBatch Bt, TaskDev T) {
 
 // reach task needs tip positions: per-env group kernel reusing the kinematics stage
 template <int G>
-__global__ void __launch_bounds__(64) reach_obs_kernel(DevModel M, DevBatch Bt, TaskDev T) {
+__global__ void __launch_bounds__(64) reach_obs_kernel(DevModel M, DevBatch Bt, TaskDev T, int obs_only) {
   extern __shared__ __align__(16) float smem[];
   const Lay& Y = M.lay;
   const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
@@ -1420,6 +1461,7 @@ __global__ void __launch_bounds__(64) reach_obs_kernel(DevModel M, DevBatch Bt, 
     float p[3];
     site_world(M, E, T.tip_site[i], p);
     for (int k = 0; k < 3; k++) {
+      p[k] += M.origin[k];  // kernels work relative to the lowered origin; observations are world coordinates
       float tg = Bt.target[(size_t)env * T.ntarget + 3 * i + k];
       float re = tg - p[k];
       err2 += re * re;
@@ -1436,7 +1478,7 @@ __global__ void __launch_bounds__(64) reach_obs_kernel(DevModel M, DevBatch Bt, 
   actn = sqrtf(grp_sum<G>(actn)) / (float)(nu > 0 ? nu : 1);
   if (valid) {
     GFOR(i, nv) { o[i] = E[Y.qpos + i]; o[nv + i] = Bt.qvel[(size_t)env * nv + i] * dt; }
-    if (sub == 0) {
+    if (sub == 0 && !obs_only) {
       float dist = sqrtf(err2);
       float near_th = T.near_th, far_th = Bt.time[env] > 2 * dt ? T.far_th : 1e30f;
       float bonus = (dist < 2 * near_th ? 1.f : 0.f) + (dist < near_th ? 1.f : 0.f);
@@ -1451,6 +1493,7 @@ __global__ void __launch_bounds__(64) reach_obs_kernel(DevModel M, DevBatch Bt, 
 // ================================================================================================
 // host side
 // ================================================================================================
+static int g_lanes = 16;  // lanes per env (16 / 32 / 64); MYO_LANES env var or myo_set_lanes()
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MYO_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
@@ -1471,10 +1514,12 @@ struct myo_batch {
   const myo_model* model = nullptr;
   DevBatch db{};
   TaskDev task{};
-  int ntarget_alloc = 0, obs_alloc = 0;
+  int ntarget_alloc = 0, obs_alloc = 0, env_offset = 0;
   std::vector<void*> dev_allocs;
   float *d_tlo = nullptr, *d_thi = nullptr, *d_init = nullptr, *d_jlo = nullptr, *d_jhi = nullptr, *d_action = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  uint64_t bench_step = 0;
+  long long* d_stamps = nullptr;
 };
 
 static const BlobRec* blob_find(const uint8_t* blob, const char* name) {
@@ -1596,6 +1641,11 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
   if ((rc = load_f(m, blob, "hip_jl", &d.jl, &jl))) { myo_model_free(m); return rc; }
   if ((rc = load_f(m, blob, "hip_c0", &tmp, &c0))) { myo_model_free(m); return rc; }
   d.c0[0] = c0[0]; d.c0[1] = c0[1]; d.c0[2] = c0[2];
+  {
+    std::vector<float> org;
+    if ((rc = load_f(m, blob, "hip_origin", &tmp, &org))) { myo_model_free(m); return rc; }
+    d.origin[0] = org[0]; d.origin[1] = org[1]; d.origin[2] = org[2];
+  }
   m->jnt_lo.resize(d.nv); m->jnt_hi.resize(d.nv);
   for (int i = 0; i < d.nv; i++) { m->jnt_lo[i] = jl[12 * i + 1]; m->jnt_hi[i] = jl[12 * i + 2]; }
   build_layout(d);
@@ -1645,10 +1695,12 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   BA(d.qpos, (size_t)B * nv) BA(d.qvel, (size_t)B * nv) BA(d.act, (size_t)B * nu) BA(d.ctrl, (size_t)B * nu) BA(d.warm, (size_t)B * nv)
   BA(d.time, B) BA(d.target, (size_t)B * b->ntarget_alloc) BA(d.obs, (size_t)B * b->obs_alloc) BA(d.reward, B) BA(d.done, B)
   BA(d.solved, B) BA(d.qacc, (size_t)B * nv) BA(d.tenlen, (size_t)B * nu) BA(d.actforce, (size_t)B * nu) BA(d.sitexpos, (size_t)B * 24)
-  BA(d.flags, B) BA(d.diag, (size_t)B * 8)
+  BA(d.flags, B) BA(d.diag, (size_t)B * 8) BA(d.elapsed, B) BA(d.episode, B)
   BA(b->d_tlo, b->ntarget_alloc) BA(b->d_thi, b->ntarget_alloc) BA(b->d_init, nv) BA(b->d_jlo, nv) BA(b->d_jhi, nv)
   BA(b->d_action, (size_t)B * nu)
+  BA(b->d_stamps, (size_t)B * 12 * 2)
 #undef BA
+  if (const char* e = getenv("MYO_LANES")) { int g = atoi(e); if (g == 16 || g == 32 || g == 64) g_lanes = g; }
   HIPCHK(hipMemcpy(b->d_jlo, m->jnt_lo.data(), nv * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(b->d_jhi, m->jnt_hi.data(), nv * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(b->d_init, m->qpos0.data(), nv * 4, hipMemcpyHostToDevice));
@@ -1719,6 +1771,7 @@ static int field_info(myo_batch* b, int f, void** p, size_t* pitch, size_t* widt
     case MYO_F_QACC: *p = d.qacc; *pitch = *width = nv; break;
     case MYO_F_TENLEN: *p = d.tenlen; *pitch = *width = nu; break;
     case MYO_F_ACTFORCE: *p = d.actforce; *pitch = *width = nu; break;
+    case MYO_F_ELAPSED: *p = d.elapsed; *pitch = *width = 1; break;
     case MYO_F_SITEXPOS: *p = d.sitexpos; *pitch = *width = b->task.ntip > 0 ? 3 * b->task.ntip : 1; break;
     default: return fail(MYO_E_ARG, "unknown field");
   }
@@ -1759,8 +1812,26 @@ int myo_reset(myo_batch* b, const uint8_t* mask_dev, uint64_t seed, void* stream
   const DevModel& dm = b->model->dm;
   HIPCHK(hipSetDevice(b->model->device));
   int B = b->db.B;
-  hipLaunchKernelGGL(reset_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->db, b->task, dm.nv, dm.nu, dm.qpos0, mask_dev, seed, 0);
+  hipLaunchKernelGGL(reset_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->db, b->task, dm.nv, dm.nu, dm.qpos0, mask_dev, seed,
+                     b->env_offset, 0);
   HIPCHK(hipGetLastError());
+  return MYO_OK;
+}
+
+int myo_autoreset(myo_batch* b, int max_episode_steps, uint64_t seed, void* stream) {
+  if (!b || max_episode_steps <= 0) return fail(MYO_E_ARG, "myo_autoreset: bad arguments");
+  const DevModel& dm = b->model->dm;
+  HIPCHK(hipSetDevice(b->model->device));
+  int B = b->db.B;
+  hipLaunchKernelGGL(reset_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->db, b->task, dm.nv, dm.nu, dm.qpos0,
+                     (const uint8_t*)nullptr, seed, b->env_offset, max_episode_steps);
+  HIPCHK(hipGetLastError());
+  return MYO_OK;
+}
+
+int myo_set_env_offset(myo_batch* b, int env_offset) {
+  if (!b) return fail(MYO_E_ARG, "null batch");
+  b->env_offset = env_offset;
   return MYO_OK;
 }
 
@@ -1778,16 +1849,21 @@ int myo_set_state(myo_batch* b, const float* qpos, const float* qvel, const floa
 
 static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, hipStream_t s) {
   const myo_model* m = b->model;
-  const int G = 16, EPW = 64 / G;
+  const int G = g_lanes, EPW = 64 / G;
   int grid = (b->db.B + EPW - 1) / EPW;
   size_t lds = (size_t)EPW * m->env_lds_bytes;
   static bool attr_set = false;
   if (!attr_set) {
     HIPCHK(hipFuncSetAttribute((const void*)step_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)step_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)step_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)reach_obs_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(step_kernel<16>, dim3(grid), dim3(64), lds, s, m->dm, b->db, action, actmap, nsub);
+  long long* st = b->d_stamps;
+  if (G == 16) hipLaunchKernelGGL(step_kernel<16>, dim3(grid), dim3(64), lds, s, m->dm, b->db, action, actmap, nsub, st);
+  else if (G == 32) hipLaunchKernelGGL(step_kernel<32>, dim3(grid), dim3(64), lds, s, m->dm, b->db, action, actmap, nsub, st);
+  else hipLaunchKernelGGL(step_kernel<64>, dim3(grid), dim3(64), lds, s, m->dm, b->db, action, actmap, nsub, st);
   HIPCHK(hipGetLastError());
   return MYO_OK;
 }
@@ -1798,14 +1874,14 @@ int myo_step(myo_batch* b, const float* action_dev, int actmap, int nsubsteps, v
   return launch_step(b, action_dev, actmap, nsubsteps, (hipStream_t)stream);
 }
 
-static int launch_obs(myo_batch* b, hipStream_t s) {
+static int launch_obs(myo_batch* b, hipStream_t s, int obs_only = 0) {
   const myo_model* m = b->model;
   int B = b->db.B;
   if (b->task.task == MYO_TASK_POSE) {
-    hipLaunchKernelGGL(obs_kernel, dim3((B + 63) / 64), dim3(64), 0, s, m->dm, b->db, b->task);
+    hipLaunchKernelGGL(obs_kernel, dim3((B + 63) / 64), dim3(64), 0, s, m->dm, b->db, b->task, obs_only);
   } else if (b->task.task == MYO_TASK_REACH) {
     const int EPW = 4;
-    hipLaunchKernelGGL(reach_obs_kernel<16>, dim3((B + EPW - 1) / EPW), dim3(64), (size_t)EPW * m->env_lds_bytes, s, m->dm, b->db, b->task);
+    hipLaunchKernelGGL(reach_obs_kernel<16>, dim3((B + EPW - 1) / EPW), dim3(64), (size_t)EPW * m->env_lds_bytes, s, m->dm, b->db, b->task, obs_only);
   } else {
     return fail(MYO_E_ARG, "myo_obs: no task configured");
   }
@@ -1817,6 +1893,12 @@ int myo_obs(myo_batch* b, void* stream) {
   if (!b) return fail(MYO_E_ARG, "myo_obs: null");
   HIPCHK(hipSetDevice(b->model->device));
   return launch_obs(b, (hipStream_t)stream);
+}
+
+int myo_obs_only(myo_batch* b, void* stream) {
+  if (!b) return fail(MYO_E_ARG, "myo_obs_only: null");
+  HIPCHK(hipSetDevice(b->model->device));
+  return launch_obs(b, (hipStream_t)stream, 1);
 }
 
 int myo_status(myo_batch* b, int32_t* host_flags) {
@@ -1837,22 +1919,41 @@ int myo_random_action(myo_batch* b, float* action_dev, uint64_t seed, uint64_t s
   return MYO_OK;
 }
 
+int myo_set_lanes(int lanes) {
+  if (lanes != 16 && lanes != 32 && lanes != 64) return fail(MYO_E_ARG, "lanes per env must be 16, 32 or 64");
+  g_lanes = lanes;
+  return MYO_OK;
+}
+
+/* diagnostic build only (MYO_STAMPS=1): per-workgroup clock64 totals of the 10 stages of the last myo_step */
+int myo_read_stamps(myo_batch* b, long long* host, int nwg) {
+  if (!b || !host) return fail(MYO_E_ARG, "myo_read_stamps: null");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(host, b->d_stamps, (size_t)nwg * 12 * sizeof(long long), hipMemcpyDeviceToHost));
+  return MYO_STAMPS ? MYO_OK : 1;
+}
+
 int myo_sync(void* stream) {
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   return MYO_OK;
 }
 
-int myo_bench_rollout(myo_batch* b, int steps, int nsubsteps, uint64_t seed, int with_obs, void* stream, float* ms_out) {
+int myo_bench_rollout(myo_batch* b, int steps, int nsubsteps, uint64_t seed, int mode, int max_episode_steps, void* stream, float* ms_out) {
   if (!b || steps <= 0 || !ms_out) return fail(MYO_E_ARG, "myo_bench_rollout: bad arguments");
   HIPCHK(hipSetDevice(b->model->device));
   hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (!(mode & MYO_BENCH_FRESH_ACTIONS)) { rc = myo_random_action(b, b->d_action, seed, b->bench_step, b->env_offset, stream); if (rc) return rc; }
   HIPCHK(hipEventRecord(b->ev0, s));
   for (int i = 0; i < steps; i++) {
-    int rc = myo_random_action(b, b->d_action, seed, (uint64_t)i, 0, stream);
-    if (rc) return rc;
+    if (mode & MYO_BENCH_FRESH_ACTIONS) { rc = myo_random_action(b, b->d_action, seed, b->bench_step++, b->env_offset, stream); if (rc) return rc; }
     rc = launch_step(b, b->d_action, MYO_ACTMAP_MUSCLE_SIGMOID, nsubsteps, s);
     if (rc) return rc;
-    if (with_obs && b->task.task != MYO_TASK_NONE) { rc = launch_obs(b, s); if (rc) return rc; }
+    if ((mode & MYO_BENCH_OBS) && b->task.task != MYO_TASK_NONE) { rc = launch_obs(b, s); if (rc) return rc; }
+    if ((mode & MYO_BENCH_AUTORESET) && max_episode_steps > 0) {
+      rc = myo_autoreset(b, max_episode_steps, seed, stream); if (rc) return rc;
+      if ((mode & MYO_BENCH_OBS) && b->task.task != MYO_TASK_NONE) { rc = launch_obs(b, s, 1); if (rc) return rc; }
+    }
   }
   HIPCHK(hipEventRecord(b->ev1, s));
   HIPCHK(hipEventSynchronize(b->ev1));

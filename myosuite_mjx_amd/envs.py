@@ -1,0 +1,236 @@
+"""Batched MyoSuite task envs on the HIP stepper, keeping the reference's gym-style API.
+
+Mirrors (paths relative to /root/reference/myosuite/):
+  * env ids, kwargs and episode lengths      envs/myo/myobase/__init__.py:258-297,300-413,523-571
+  * action map + frame_skip                  envs/myo/base_v0.py:23-59,83-119
+  * obs / reward / done / reset, pose task   envs/myo/myobase/pose_v0.py:98-138,141-255
+  * obs / reward / done / reset, reach task  envs/myo/myobase/reach_v0.py:88-159
+  * obs vector layout and float32 cast       envs/obs_vec_dict.py:86-98
+  * gym step contract (obs, rwd, terminated, truncated, info)   envs/env_base.py:335-390
+
+One env object steps `num_envs` environments in one kernel launch; tensors stay on the device
+(torch views of the library's buffers, zero copy).  Physics runs only in libmyo_hip.so.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import capi
+from . import model as _model
+
+# ASL pose table (envs/myo/myobase/__init__.py:326-376): target joint vectors of myoHandPose{k}Fixed-v0;
+# the per-joint min/max over the ten rows is the target range of myoHandPoseRandom-v0 (:396-399)
+ASL_QPOS = np.array([
+    [0, 0, 0, 0.5624, 0.28272, -0.75573, -1.309, 1.30045, -0.006982, 1.45492, 0.998897, 1.26466, 0, 1.40604, 0.227795, 1.07614, -0.020944, 1.46103, 0.06284, 0.83263, -0.14399, 1.571, 1.38248],
+    [0, 0, 0, 0.0248, 0.04536, -0.7854, -1.309, 0.366605, 0.010473, 0.269258, 0.111722, 1.48459, 0, 1.45318, 1.44532, 1.44532, -0.204204, 1.46103, 1.44532, 1.48459, -0.2618, 1.47674, 1.48459],
+    [0, 0, 0, 0.0248, 0.04536, -0.7854, -1.13447, 0.514973, 0.010473, 0.128305, 0.111722, 0.510575, 0, 0.37704, 0.117825, 1.44532, -0.204204, 1.46103, 1.44532, 1.48459, -0.2618, 1.47674, 1.48459],
+    [0, 0, 0, 0.3384, 0.25305, 0.01569, -0.0262045, 0.645885, 0.010473, 0.128305, 0.111722, 0.510575, 0, 0.37704, 0.117825, 1.571, -0.036652, 1.52387, 1.45318, 1.40604, -0.068068, 1.39033, 1.571],
+    [0, 0, 0, 0.6392, -0.147495, -0.7854, -1.309, 0.637158, 0.010473, 0.128305, 0.111722, 0.510575, 0, 0.37704, 0.117825, 0.306345, -0.010472, 0.400605, 0.133535, 0.21994, -0.068068, 0.274925, 0.01571],
+    [0, 0, 0, 0.3384, 0.25305, 0.01569, -0.0262045, 0.645885, 0.010473, 0.128305, 0.111722, 0.510575, 0, 0.37704, 0.117825, 0.306345, -0.010472, 0.400605, 0.133535, 0.21994, -0.068068, 0.274925, 0.01571],
+    [0, 0, 0, 0.6392, -0.147495, -0.7854, -1.309, 0.637158, 0.010473, 0.128305, 0.111722, 0.510575, 0, 0.37704, 0.117825, 0.306345, -0.010472, 0.400605, 0.133535, 1.1861, -0.2618, 1.35891, 1.48459],
+    [0, 0, 0, 0.524, 0.01569, -0.7854, -1.309, 0.645885, -0.006982, 0.128305, 0.111722, 0.510575, 0, 0.37704, 0.117825, 1.28036, -0.115192, 1.52387, 1.45318, 0.432025, -0.068068, 0.18852, 0.149245],
+    [0, 0, 0, 0.428, 0.22338, -0.7854, -1.309, 0.645885, -0.006982, 0.128305, 0.194636, 1.39033, 0, 1.08399, 0.573415, 0.667675, -0.020944, 0, 0.06284, 0.432025, -0.068068, 0.18852, 0.149245],
+    [0, 0, 0, 0.5624, 0.28272, -0.75573, -1.309, 1.30045, -0.006982, 1.45492, 0.998897, 0.39275, 0, 0.18852, 0.227795, 0.667675, -0.020944, 0, 0.06284, 0.432025, -0.068068, 0.18852, 0.149245],
+])
+# myoHandPoseFixed-v0 target (envs/myo/myobase/__init__.py:265-291)
+HAND_POSE_FIXED = np.array([0, 0, 0, -0.0904, 0.0824475, -0.681555, -0.514888, 0, -0.013964, -0.0458132, 0, 0.67553,
+                            -0.020944, 0.76979, 0.65982, 0, 0, 0, 0, 0.479155, -0.099484, 0.95831, 0])
+HAND_TIPS = ("THtip", "IFtip", "MFtip", "RFtip", "LFtip")
+# myoHandReach* target spans (envs/myo/myobase/__init__.py:523-571)
+_REACH_CENTRE = {"THtip": (-0.165, -0.537, 1.495), "IFtip": (-0.151, -0.547, 1.455), "MFtip": (-0.146, -0.547, 1.447),
+                 "RFtip": (-0.148, -0.543, 1.445), "LFtip": (-0.148, -0.528, 1.434)}
+_REACH_SPAN = {"THtip": ((-0.020, -0.040, -0.040), (0.040, 0.020, 0.040)),
+               "IFtip": ((-0.040, -0.020, -0.010), (0.040, 0.020, 0.010)),
+               "MFtip": ((-0.040, -0.020, -0.010), (0.040, 0.020, 0.010)),
+               "RFtip": ((-0.040, -0.020, -0.010), (0.040, 0.020, 0.010)),
+               "LFtip": ((-0.040, -0.020, -0.010), (0.040, 0.020, 0.010))}
+
+
+def _pose_spec(target_lo, target_hi, reset_type, target_type, pose_thd=0.7):
+    return dict(model="myohand_pose", task="pose", max_episode_steps=100, frame_skip=10, normalize_act=True,
+                target_lo=np.asarray(target_lo, float), target_hi=np.asarray(target_hi, float),
+                reset_type=reset_type, target_type=target_type, pose_thd=pose_thd,
+                weights=dict(pose=1.0, bonus=4.0, act_reg=1.0, penalty=50.0))
+
+
+def _reach_spec(random, far_th):
+    lo, hi = [], []
+    for tip in HAND_TIPS:
+        c = np.array(_REACH_CENTRE[tip])
+        a, b = (np.array(_REACH_SPAN[tip][0]), np.array(_REACH_SPAN[tip][1])) if random else (np.zeros(3), np.zeros(3))
+        lo.append(c + a)
+        hi.append(c + b)
+    return dict(model="myohand_pose", task="reach", max_episode_steps=100, frame_skip=10, normalize_act=True,
+                target_lo=np.concatenate(lo), target_hi=np.concatenate(hi), tips=HAND_TIPS, far_th=far_th,
+                reset_type="init", target_type="generate" if random else "fixed",
+                weights=dict(reach=1.0, bonus=4.0, penalty=50.0, act_reg=0.0))
+
+
+REGISTRY = {
+    "myoHandPoseFixed-v0": _pose_spec(HAND_POSE_FIXED, HAND_POSE_FIXED, "init", "fixed"),
+    "myoHandPoseRandom-v0": _pose_spec(ASL_QPOS.min(0), ASL_QPOS.max(0), "random", "generate"),
+    "myoHandReachFixed-v0": _reach_spec(False, 0.044),
+    "myoHandReachRandom-v0": _reach_spec(True, 0.034),
+}
+for _k in range(10):
+    REGISTRY[f"myoHandPose{_k}Fixed-v0"] = _pose_spec(ASL_QPOS[_k], ASL_QPOS[_k], "init", "fixed")
+# registered by the reference but not runnable on the HIP path yet (DESIGN.md "out of scope this round")
+UNSUPPORTED = {
+    "myoFingerPoseFixed-v0": "finger model needs tendon-limit rows and pulleys in the HIP kernel (oracle-only this round)",
+    "myoFingerPoseRandom-v0": "finger model needs tendon-limit rows and pulleys in the HIP kernel (oracle-only this round)",
+    "myoLegWalk-v0": "leg model needs free/slide joints, equality rows and plane contacts in the HIP kernel",
+}
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box (gym is not a dependency of the stepper)."""
+
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.low = np.full(shape, low, dtype)
+        self.high = np.full(shape, high, dtype)
+        self.shape = tuple(shape)
+        self.dtype = dtype
+
+    def sample(self, rng=None):
+        rng = rng or np.random.default_rng()
+        return rng.uniform(self.low, self.high).astype(self.dtype)
+
+
+class _DevArray:
+    """__cuda_array_interface__ holder so torch can view library-owned device memory without a copy."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+        self._owner = owner
+
+
+class BatchedMyoEnv:
+    """`num_envs` copies of one MyoSuite task, stepped together on one MI355X.
+
+    step(action[B, nu] in [-1, 1]) -> (obs[B, obs_dim] f32, reward[B], terminated[B] bool, truncated[B] bool, info)
+    following envs/env_base.py:335-365.  Finished episodes (done, or max_episode_steps like gym's TimeLimit)
+    are reset in place and the returned obs row is the first observation of the new episode.
+    """
+
+    def __init__(self, env_id, num_envs=1, device=0, seed=0, env_offset=0, autoreset=True, as_torch=True):
+        if env_id in UNSUPPORTED:
+            raise NotImplementedError(f"{env_id}: {UNSUPPORTED[env_id]}")
+        if env_id not in REGISTRY:
+            raise KeyError(f"unknown env id {env_id!r}; known: {sorted(REGISTRY)}")
+        self.id = env_id
+        self.spec = spec = REGISTRY[env_id]
+        self.num_envs = int(num_envs)
+        self.device = device
+        self.seed = int(seed)
+        self.autoreset = autoreset
+        self.as_torch = as_torch
+        self.mjmodel = _model.load_asset(spec["model"])
+        self.model = capi.HipModel(self.mjmodel.blob(), device)       # raises if there is no GPU / no library
+        self.batch = capi.HipBatch(self.model, self.num_envs)
+        self.batch.set_env_offset(env_offset)
+        m = self.mjmodel
+        self.frame_skip = spec["frame_skip"]
+        self.dt = m.timestep * self.frame_skip                        # env_base.py:616-617
+        self.max_episode_steps = spec["max_episode_steps"]
+        w = spec["weights"]
+        if spec["task"] == "pose":
+            self.batch.configure(task=capi.TASK_POSE, frame_skip=self.frame_skip,
+                                 reset_random=spec["reset_type"] == "random", target_generate=spec["target_type"] == "generate",
+                                 target_lo=spec["target_lo"], target_hi=spec["target_hi"], init_qpos=m.qpos0,
+                                 pose_thd=spec["pose_thd"], far_th=4 * np.pi / 2,
+                                 w_pose=w["pose"], w_bonus=w["bonus"], w_act_reg=w["act_reg"], w_penalty=w["penalty"])
+            self.obs_dim = 3 * m.nq + m.na
+        else:
+            tips = [m.name2id("site", t) for t in spec["tips"]]
+            n = len(tips)
+            self.batch.configure(task=capi.TASK_REACH, frame_skip=self.frame_skip, reset_random=0,
+                                 target_generate=spec["target_type"] == "generate", target_lo=spec["target_lo"],
+                                 target_hi=spec["target_hi"], init_qpos=m.qpos0, tip_sites=tips,
+                                 far_th=spec["far_th"] * n, near_th=0.0125 * n,
+                                 w_reach=w["reach"], w_bonus=w["bonus"], w_act_reg=w["act_reg"], w_penalty=w["penalty"])
+            self.obs_dim = 2 * m.nq + 6 * n + m.na
+        self.act_dim = m.nu
+        self.action_space = Box(-1.0, 1.0, (m.nu,))                    # env_base.py:101-113 (normalize_act)
+        self.observation_space = Box(-10.0, 10.0, (self.obs_dim,))     # env_base.py:172-176
+        self._episode_seed = self.seed
+        self._views = {}
+        self._action_buf = None
+        if as_torch:
+            import torch
+            self._torch = torch
+            self._action_buf = torch.empty((self.num_envs, m.nu), dtype=torch.float32, device=f"cuda:{device}")
+
+    # -- zero-copy views ---------------------------------------------------------------------------------
+    def view(self, field):
+        """torch view (as_torch) or numpy copy of a per-env field."""
+        if not self.as_torch:
+            return self.batch.read(field)
+        if field not in self._views:
+            ptr, pitch, width = self.batch.field_ptr(field)
+            ts = "<i4" if field in capi.INT_FIELDS else "<f4"
+            arr = _DevArray(ptr, (self.num_envs, width), ts, self.batch)
+            self._views[field] = self._torch.as_tensor(arr, device=f"cuda:{self.device}")
+        return self._views[field]
+
+    def _stream(self):
+        if self.as_torch:
+            return self._torch.cuda.current_stream(self.device).cuda_stream
+        return None
+
+    # -- gym API -------------------------------------------------------------------------------------------
+    def reset(self, seed=None):
+        if seed is not None:
+            self._episode_seed = int(seed)
+        s = self._stream()
+        self.batch.reset(None, self._episode_seed, s)
+        self.batch.obs(s)
+        return self.view(capi.F_OBS)
+
+    def step(self, action):
+        s = self._stream()
+        if self.as_torch:
+            a = self._torch.as_tensor(action, dtype=self._torch.float32, device=self._action_buf.device)
+            a = self._torch.clamp(a, -1.0, 1.0, out=self._action_buf)      # env_base.py:341 (clip to action space)
+            self.batch.step(a.data_ptr(), capi.ACTMAP_MUSCLE_SIGMOID, self.frame_skip, s)
+        else:
+            import ctypes
+            a = np.clip(np.ascontiguousarray(action, np.float32).reshape(self.num_envs, self.act_dim), -1, 1)
+            # host actions go through the CTRL field: apply the muscle sigmoid here (base_v0.py:87-91)
+            self.batch.write(capi.F_CTRL, 1.0 / (1.0 + np.exp(-5.0 * (a - 0.5))))
+            self.batch.step(None, capi.ACTMAP_NONE, self.frame_skip, s)
+        self.batch.obs(s)
+        if self.as_torch:
+            reward = self.view(capi.F_REWARD)[:, 0].clone()
+            done = self.view(capi.F_DONE)[:, 0] > 0
+            elapsed = self.view(capi.F_ELAPSED)[:, 0]
+            truncated = (elapsed >= self.max_episode_steps) & ~done
+            solved = self.view(capi.F_SOLVED)[:, 0] > 0
+        else:
+            reward = self.batch.read(capi.F_REWARD)[:, 0]
+            done = self.batch.read(capi.F_DONE)[:, 0] > 0
+            truncated = (self.batch.read(capi.F_ELAPSED)[:, 0] >= self.max_episode_steps) & ~done
+            solved = self.batch.read(capi.F_SOLVED)[:, 0] > 0
+        if self.autoreset:
+            self.batch.autoreset(self.max_episode_steps, self._episode_seed, s)
+            self.batch.obs_only(s)
+        info = {"solved": solved, "time": self.view(capi.F_TIME)}
+        return self.view(capi.F_OBS), reward, done, truncated, info
+
+    # -- state access (env_base.py:643-705 get_env_state / set_env_state) ----------------------------------
+    def get_env_state(self):
+        return {k: self.batch.read(f) for k, f in (("qpos", capi.F_QPOS), ("qvel", capi.F_QVEL), ("act", capi.F_ACT),
+                                                   ("time", capi.F_TIME), ("target", capi.F_TARGET))}
+
+    def set_env_state(self, state):
+        for k, f in (("qpos", capi.F_QPOS), ("qvel", capi.F_QVEL), ("act", capi.F_ACT), ("time", capi.F_TIME), ("target", capi.F_TARGET)):
+            if k in state:
+                self.batch.write(f, state[k])
+
+    def status(self):
+        """Per-env int32 flag bits since the last call (capi.FLAG_*); bad states were reset like mj_sim_scene.py:56-61."""
+        return self.batch.status()
+
+
+def make(env_id, num_envs=1, **kw):
+    """gym.make counterpart for the batched envs (envs/myo/myobase/__init__.py registers the same ids)."""
+    return BatchedMyoEnv(env_id, num_envs=num_envs, **kw)
