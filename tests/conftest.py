@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hand():
+    from myosuite_mjx_amd import model as M
+    return M.load_asset("myohand_pose")
+
+
+@pytest.fixture(scope="session")
+def oracle64(hand):
+    from oracle.oracle import Oracle
+    return Oracle(hand.blob())
+
+
+@pytest.fixture(scope="session")
+def oracle32(hand):
+    from oracle.oracle import Oracle
+    return Oracle(hand.blob(), f32=True)
+
+
+REFERENCE = "/root/reference/myosuite"
+needs_reference = pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree not present (GPU box)")

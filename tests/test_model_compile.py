@@ -1,0 +1,89 @@
+"""Model compiler + blob: sizes match SURVEY.md Appendix A; committed asset == fresh compile (container only)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REFERENCE, needs_reference
+from myosuite_mjx_amd import blob
+
+
+def test_blob_roundtrip():
+    a = {"x": np.arange(12, dtype=np.float64).reshape(3, 4), "i": np.array([1, -2, 3], np.int32), "e": np.zeros((0, 3))}
+    b = blob.unpack(blob.pack(a))
+    assert set(b) == set(a)
+    for k in a:
+        assert b[k].shape == a[k].shape and np.array_equal(b[k], a[k])
+
+
+def test_hand_sizes(hand):
+    # SURVEY.md Appendix A, column H (myohand_pose.xml)
+    assert (hand.nq, hand.nv, hand.nu, hand.na) == (23, 23, 39, 39)
+    assert hand.nbody == 39 and hand.ntendon == 44 and hand.nsite == 333
+    assert int(hand.sizes[11]) == 116                        # tree-sparse mass matrix non-zeros
+    assert int((hand.jnt_limited != 0).sum()) == 23
+    assert abs(hand.timestep - 0.002) < 1e-12
+    ct = hand.geom_type[(hand.geom_contype != 0) | (hand.geom_conaffinity != 0)]
+    assert (ct == 3).sum() == 22 and (ct == 4).sum() == 5    # 22 capsules + 5 ellipsoid pads (+ plane + pedestal)
+    hs = dict(zip("nl nlevel nv nu ngt nseg ndl maxnnz nwg ncg npair maxkc".split(), hand.hip_sizes))
+    assert hs["nl"] == 17 and hs["nlevel"] == 5 and hs["maxnnz"] <= 8 and hs["maxkc"] <= 8
+
+
+def test_hand_muscle_defaults(hand):
+    # <muscle> defaults (range .75-1.05, lmin .5, lmax 1.6, vmax 1.5, fpmax 1.3, fvmax 1.2, timeconst .01/.04)
+    g = hand.actuator_gainprm
+    assert np.allclose(g[:, [0, 1, 4, 5, 6, 7, 8]], [0.75, 1.05, 0.5, 1.6, 1.5, 1.3, 1.2])
+    assert np.allclose(hand.actuator_dynprm[:, :2], [0.01, 0.04])
+    i = hand.name2id("actuator", "ECRL")
+    assert g[i, 2] == 337.3 and np.allclose(hand.actuator_lengthrange[i], [0.313191, 0.341072])   # myohand_assets.xml:501
+
+
+def test_hand_inertia_bounds(hand):
+    # compiler boundmass=0.001, boundinertia=1e-4, balanceinertia (myohand_assets.xml:11)
+    mv = hand.body_weldid != 0
+    assert (hand.body_mass[mv] >= 0.001 - 1e-15).all() and (hand.body_inertia[mv] >= 1e-4 - 1e-15).all()
+    I = hand.body_inertia[mv]
+    assert (I[:, 0] + I[:, 1] >= I[:, 2] - 1e-12).all()
+
+
+@needs_reference
+def test_asset_matches_fresh_compile(hand):
+    from myosuite_mjx_amd import model as M
+    fresh = M.from_mjcf(os.path.join(REFERENCE, "envs/myo/assets/hand/myohand_pose.xml"))
+    assert set(fresh.arrays) == set(hand.arrays)
+    for k, v in fresh.arrays.items():
+        assert np.allclose(np.asarray(v, float), np.asarray(hand.arrays[k], float), rtol=0, atol=1e-12), k
+    assert fresh.names == hand.names
+
+
+@needs_reference
+def test_unsupported_feature_raises(tmp_path):
+    from myosuite_mjx_amd.mjcf import compile_mjcf
+    p = tmp_path / "m.xml"
+    p.write_text("<mujoco><worldbody><body><joint type='ball'/><geom size='0.1'/></body></worldbody></mujoco>")
+    with pytest.raises(NotImplementedError):
+        compile_mjcf(str(p))
+
+
+def test_sim_scene_style_inline_model(tmp_path):
+    """Same shape as the reference's physics/sim_scene_test.py:19-40 (tiny inline hinge chain): compiles and steps."""
+    from myosuite_mjx_amd import blob as B
+    from myosuite_mjx_amd.mjcf import compile_mjcf
+    from myosuite_mjx_amd.setconst import set_constants
+    from oracle.oracle import Oracle
+    xml = """<mujoco><compiler angle="radian"/><worldbody>
+      <body name="main" pos="0 0 1"><joint name="j0" type="hinge" axis="0 1 0" range="-1 1" limited="true"/>
+        <geom type="capsule" size="0.05 0.2" pos="0 0 -0.2"/>
+        <body pos="0 0 -0.4"><joint name="j1" type="hinge" axis="0 1 0"/><geom type="capsule" size="0.04 0.15" pos="0 0 -0.15"/>
+          <body pos="0 0 -0.3"><joint name="j2" type="slide" axis="0 0 1"/><geom type="ellipsoid" size="0.05 0.04 0.03"/></body>
+        </body></body></worldbody></mujoco>"""
+    p = tmp_path / "chain.xml"
+    p.write_text(xml)
+    cm = compile_mjcf(str(p))
+    set_constants(cm)
+    assert list(cm.sizes[:2]) == [3, 3]
+    o = Oracle(B.pack(cm.arrays))
+    o.set_state(qpos=[0.3, -0.2, 0.01])
+    for _ in range(10):
+        assert o.step(1) == 0
+    assert abs(o.time - 10 * 0.002) < 1e-12 and np.isfinite(o.field("qpos")).all()

@@ -1,0 +1,172 @@
+"""Oracle pinning and invariants (CPU).  Golden: the MuJoCo-computed muscle `lengthrange` values that the
+reference's own model file stores (simhive/myo_sim/hand/assets/myohand_assets.xml:501-539)."""
+import numpy as np
+import pytest
+
+# tendons whose stored lengthrange is consistent with the shipped geometry on BOTH ends (the rest were computed on
+# an earlier edit of the model): sphere, cylinder and inside-wrap ("torus") paths are all covered
+GOLDEN_TENDONS = ["ECRB", "ECU", "PQ", "EIP", "RI2", "RI3", "EDM", "FCR", "EDC5"]
+
+
+def _extremum(o, m, t, sign):
+    """Projected gradient descent (sign=+1: shortest, -1: longest) on tendon t from qpos0 inside the joint box:
+    the fixed point MuJoCo's damped length-range simulation converges to."""
+    lo, hi = m.jnt_range[:, 0], m.jnt_range[:, 1]
+    q = m.qpos0.copy()
+    step = 0.5
+
+    def ev(q):
+        o.set_state(qpos=q)
+        o.fwd_position()
+        return o.field("ten_length")[t], o.field("ten_J").reshape(m.ntendon, m.nv)[t].copy()
+    best, J = ev(q)
+    for _ in range(300):
+        g = sign * J
+        qn = np.clip(q - step * g / (np.linalg.norm(g) + 1e-12), lo, hi)
+        Ln, Jn = ev(qn)
+        if sign * Ln < sign * best - 1e-13:
+            q, best, J = qn, Ln, Jn
+        else:
+            step *= 0.5
+            if step < 1e-6:
+                break
+    return best
+
+
+@pytest.mark.parametrize("name", GOLDEN_TENDONS)
+def test_lengthrange_golden(hand, oracle64, name):
+    i = hand.name2id("actuator", name)
+    t = int(hand.actuator_trnid[i])
+    lo_ref, hi_ref = hand.actuator_lengthrange[i]
+    span = hi_ref - lo_ref
+    lo = _extremum(oracle64, hand, t, +1)
+    hi = _extremum(oracle64, hand, t, -1)
+    assert abs(lo - lo_ref) < 0.015 * span, (name, lo, lo_ref)
+    assert abs(hi - hi_ref) < 0.015 * span, (name, hi, hi_ref)
+
+
+def test_lengthrange_tight_subset(hand, oracle64):
+    """Four tendons agree with MuJoCo's numbers to <= 1e-3 of their range at both ends (PQ: 5 significant digits)."""
+    for name in ("ECRB", "ECU", "PQ", "RI2"):
+        i = hand.name2id("actuator", name)
+        t = int(hand.actuator_trnid[i])
+        lo_ref, hi_ref = hand.actuator_lengthrange[i]
+        span = hi_ref - lo_ref
+        assert abs(_extremum(oracle64, hand, t, +1) - lo_ref) < 1e-3 * span
+        assert abs(_extremum(oracle64, hand, t, -1) - hi_ref) < 1e-3 * span
+
+
+def test_numpy_twin_agrees(hand, oracle64):
+    """Independent numpy restatement (setconst.py) vs the C oracle: tendon lengths, Jacobians, mass matrix."""
+    from myosuite_mjx_amd import setconst as sc
+    rng = np.random.default_rng(0)
+    for _ in range(3):
+        q = rng.uniform(hand.jnt_range[:, 0], hand.jnt_range[:, 1])
+        oracle64.set_state(qpos=q, qvel=np.zeros(hand.nv))
+        oracle64.fwd_position()
+        L, J = sc.tendons(hand, q)
+        assert np.abs(oracle64.field("ten_length") - L).max() < 1e-13
+        assert np.abs(oracle64.field("ten_J").reshape(hand.ntendon, hand.nv) - J).max() < 1e-13
+        M = sc.mass_matrix(hand, q)
+        Mo = oracle64.full_m(hand.nv)
+        assert np.abs(M - Mo).max() < 1e-14 and np.linalg.eigvalsh(Mo).min() > 0
+
+
+def test_tendon_jacobian_finite_difference(hand, oracle64):
+    rng = np.random.default_rng(1)
+    q = rng.uniform(hand.jnt_range[:, 0], hand.jnt_range[:, 1])
+    oracle64.set_state(qpos=q)
+    oracle64.fwd_position()
+    J = oracle64.field("ten_J").reshape(hand.ntendon, hand.nv).copy()
+    eps = 1e-6
+    for i in range(hand.nv):
+        qp, qm = q.copy(), q.copy()
+        qp[i] += eps
+        qm[i] -= eps
+        oracle64.set_state(qpos=qp); oracle64.fwd_position(); Lp = oracle64.field("ten_length").copy()
+        oracle64.set_state(qpos=qm); oracle64.fwd_position(); Lm = oracle64.field("ten_length").copy()
+        assert np.abs((Lp - Lm) / (2 * eps) - J[:, i]).max() < 1e-7
+
+
+def test_energy_drift_is_first_order(hand):
+    """No damping, no muscle force, no constraints: the semi-implicit Euler energy drift halves with the timestep."""
+    from myosuite_mjx_amd import blob
+    from oracle.oracle import Oracle
+    A = {k: v.copy() for k, v in hand.arrays.items()}
+    A["dof_damping"][:] = 0
+    A["actuator_gainprm"][:, 2] = 0
+    A["actuator_biasprm"][:, 2] = 0
+    rng = np.random.default_rng(2)
+    mid = hand.jnt_range.mean(1)
+    q0 = mid + rng.uniform(-0.1, 0.1, hand.nq)
+    v0 = rng.normal(0, 1.0, hand.nv)
+    drift = []
+    for dt in (2e-4, 1e-4):
+        A["opt"][0] = dt
+        o = Oracle(blob.pack(A))
+        o.switches(1, 1, 1)
+        o.set_state(qpos=q0, qvel=v0)
+        o.forward()
+        ke, pe = o.energy()
+        o.step(int(round(0.02 / dt)))
+        o.forward()
+        ke2, pe2 = o.energy()
+        drift.append((ke2 + pe2 - ke - pe) / ke)
+    assert abs(drift[0]) < 5e-3 and 1.7 < drift[0] / drift[1] < 2.3
+
+
+def test_limit_constraint_pushes_back(hand, oracle64):
+    q = hand.qpos0.copy()
+    j = hand.name2id("joint", "mcp2_flexion")
+    q[j] = hand.jnt_range[j, 0] - 0.05                      # 0.05 rad below the lower limit
+    oracle64.switches(1, 0, 1)
+    oracle64.reset()
+    oracle64.set_state(qpos=q)
+    oracle64.forward()
+    assert oracle64.nefc >= 1 and oracle64.field("qfrc_constraint")[j] > 0
+    oracle64.switches(0, 0, 0)
+
+
+def test_contact_rows_and_normal_force(hand, oracle64):
+    """A closed-fist pose produces contacts; every pyramid edge force is non-negative, the solver converges."""
+    rng = np.random.default_rng(3)
+    oracle64.switches(0, 0, 0)
+    oracle64.reset()
+    for _ in range(60):
+        a = rng.uniform(0.0, 1.0, hand.nu)
+        oracle64.set_state(ctrl=a)
+        oracle64.step(10)
+    assert oracle64.ncon > 0 and oracle64.nefc >= 4 * 1
+    assert (oracle64.field("efc_force") >= -1e-9).all()
+    assert oracle64.solver_iter <= 20
+    for c in oracle64.contacts():
+        assert abs(np.linalg.norm(c[4:7]) - 1) < 1e-9 and c[0] < 0.001 + 1e-12     # unit normal, dist < margin
+
+
+def test_f32_oracle_gap_is_small(hand, oracle64, oracle32):
+    """The float build of the oracle bounds what float arithmetic can deliver: tendon lengths within 1e-5 m."""
+    rng = np.random.default_rng(4)
+    worst = 0.0
+    for _ in range(200):
+        q = rng.uniform(hand.jnt_range[:, 0], hand.jnt_range[:, 1]).astype(np.float32)
+        oracle64.set_state(qpos=q); oracle64.fwd_position()
+        oracle32.set_state(qpos=q); oracle32.fwd_position()
+        worst = max(worst, np.abs(oracle64.field("ten_length") - oracle32.field("ten_length")).max())
+    assert worst < 2e-5
+
+
+def test_oracle_deterministic_and_batch_driver(hand, oracle64):
+    rng = np.random.default_rng(5)
+    B = 6
+    qpos = rng.uniform(hand.jnt_range[:, 0], hand.jnt_range[:, 1], (B, hand.nq))
+    qvel = rng.normal(0, 0.3, (B, hand.nv)); act = rng.uniform(0, 1, (B, hand.nu)); ctrl = rng.uniform(0, 1, (B, hand.nu))
+    a = [qpos.copy(), qvel.copy(), act.copy(), np.zeros((B, hand.nv)), np.zeros(B)]
+    b = [x.copy() for x in a]
+    oracle64.step_batch(*a, ctrl, 5, 2)
+    oracle64.step_batch(*b, ctrl, 5, 1)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)                          # thread count does not change results
+    oracle64.reset()
+    oracle64.set_state(qpos=qpos[0], qvel=qvel[0], act=act[0], ctrl=ctrl[0])
+    oracle64.step(5)
+    assert np.array_equal(oracle64.field("qpos"), a[0][0])
