@@ -1366,6 +1366,800 @@ __global__ void __launch_bounds__(64) step_kernel(DevModel M, DevBatch Bt, const
 #endif
 }
 
+// ================================================================================================
+// WAVE-PER-ENV KERNEL (lanes_per_env = 64): one wavefront steps one environment.
+//  * per-dof quantities (qacc, M rows, gradient, search direction, limit rows ...) live in the registers of lane = dof;
+//    contact rows live in lane = contact; dense Cholesky / triangular solves / M*v run on registers with v_readlane
+//    broadcasts -- no barriers, no LDS round trips;
+//  * J^T f and J^T D J are scattered with LDS float atomics (one wave => deterministic order);
+//  * tendons run lane = segment (wrapping segments first, then straight ones) instead of lane = tendon;
+//  * the LDS slice is <= 10 KB so 16 envs (= 16 waves, 4 per SIMD) are resident per CU.
+// ================================================================================================
+#define NCONW 32
+struct LayW {
+  int qpos, qvel, act, ctrl, lpos, lmat, axis, anchor, xv, qfc, sq, X;
+  int tJ, tlen, tforce, seglen, dlval;            // region X, tendon phase
+  int cdof, cinert, crb, cvel, cacc, cfrc;        // region X, dynamics phase
+  int gpos, gax, cand, cdist, cpos, cnrm, cpair, cJ, cdofs;  // region X, collision + solver phase
+  int total;
+};
+struct DevModelW {
+  LayW lay;
+  const int *seg_order, *seg_tendon, *gt_dl;
+  const float* link_mat0;
+  int nwrapseg, ndl;
+};
+
+__device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ int rdlanei(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 64 lanes, result in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  v = dpp_add<0x140>(v);  // row_mirror  -> every lane of a 16-lane row holds the row sum
+  return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
+}
+#define WFOR(i, n) for (int i = lane; i < (n); i += 64)
+// dof id k (0..7) of contact c from the byte-packed table
+#define CDOF(E_, Y_, c_, k_) ((int)((((const unsigned int*)((E_) + (Y_).cdofs))[2 * (c_) + ((k_) >> 2)] >> (8 * ((k_) & 3))) & 255u))
+
+// in: r[k] = H[lane][k] (k <= lane). out: r[k] = L[lane][k], returns 1/L[lane][lane].  All indices are compile-time.
+template <int NVT> __device__ __forceinline__ float chol_rows(float (&r)[NVT], int lane) {
+  float invd = 1.0f;
+#pragma unroll
+  for (int j = 0; j < NVT; j++) {
+    float s = r[j];
+#pragma unroll
+    for (int k = 0; k < j; k++) s -= r[k] * rdlane(r[k], j);
+    float dj = sqrtf(fmaxf(rdlane(s, j), MINVALF));
+    float inv = 1.0f / dj;
+    r[j] = (lane == j) ? dj : s * inv;
+    if (lane == j) invd = inv;
+  }
+  return invd;
+}
+// x <- (L L^T)^-1 b ; L rows in registers, L^T columns read from the LDS copy T[j*(NVT+1) + lane]
+template <int NVT> __device__ __forceinline__ float chol_solve_rows(const float (&r)[NVT], float invd, float b, const float* T, int lane) {
+  float y = b;
+#pragma unroll
+  for (int j = 0; j < NVT; j++) {
+    float yj = rdlane(y, j) * rdlane(invd, j);
+    y = (lane == j) ? yj : (lane > j ? y - r[j] * yj : y);
+  }
+  float c[NVT];
+#pragma unroll
+  for (int j = 0; j < NVT; j++) c[j] = T[j * (NVT + 1) + (lane < NVT ? lane : 0)];
+#pragma unroll
+  for (int j = NVT - 1; j >= 0; j--) {
+    float xj = rdlane(y, j) * rdlane(invd, j);
+    y = (lane == j) ? xj : (lane < j ? y - c[j] * xj : y);
+  }
+  return y;
+}
+template <int NVT> __device__ __forceinline__ float symv_rows(const float (&Mrow)[NVT], float x) {
+  float s = 0;
+#pragma unroll
+  for (int j = 0; j < NVT; j++) s += Mrow[j] * rdlane(x, j);
+  return s;
+}
+
+__device__ __forceinline__ void site_world_w(const DevModel& M, const LayW& Y, const float* E, int s, float* out) {
+  int l = M.site_link[s];
+  const float* lp = M.site_lpos + 3 * s;
+  float a = lp[0], b = lp[1], c = lp[2];
+  if (l < 0) { out[0] = a; out[1] = b; out[2] = c; return; }
+  const float* R = E + Y.lmat + 9 * l;
+  const float* P = E + Y.lpos + 3 * l;
+  out[0] = P[0] + R[0] * a + R[1] * b + R[2] * c;
+  out[1] = P[1] + R[3] * a + R[4] * b + R[5] * c;
+  out[2] = P[2] + R[6] * a + R[7] * b + R[8] * c;
+}
+__device__ __forceinline__ void geom_world_pos(const DevModel& M, const LayW& Y, const float* E, int g, float* out) {
+  int l = M.cg_link[g];
+  const float* lp = M.cg_lpos + 3 * g;
+  float a = lp[0], b = lp[1], c = lp[2];
+  if (l < 0) { out[0] = a; out[1] = b; out[2] = c; return; }
+  const float* R = E + Y.lmat + 9 * l;
+  const float* P = E + Y.lpos + 3 * l;
+  out[0] = P[0] + R[0] * a + R[1] * b + R[2] * c;
+  out[1] = P[1] + R[3] * a + R[4] * b + R[5] * c;
+  out[2] = P[2] + R[6] * a + R[7] * b + R[8] * c;
+}
+__device__ __forceinline__ void geom_world_mat(const DevModel& M, const LayW& Y, const float* E, int g, float* R) {
+  int l = M.cg_link[g];
+  if (l < 0) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = M.cg_lmat[9 * g + k];
+  } else {
+    matmul3(R, E + Y.lmat + 9 * l, M.cg_lmat + 9 * g);
+  }
+}
+// moment-arm entries of one straight tendon piece into dlval[]
+__device__ __forceinline__ float straight_w(const DevModel& M, const LayW& Y, float* E, const float* pa, const float* pb, int adr, int n,
+                                            float invdiv, bool active) {
+  float dif[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+  float dist = norm3(dif);
+  float inv = dist > MINVALF ? 1.0f / dist : 0.f;
+  dif[0] *= inv; dif[1] *= inv; dif[2] *= inv;
+  for (int k = 0; k < n; k++) {
+    const int* e = M.dl + 3 * (adr + k);
+    int d = e[0];
+    const float* ax = E + Y.axis + 3 * d;
+    float col;
+    if (M.dof_type[d] == 3) {
+      const float* an = E + Y.anchor + 3 * d;
+      float r[3] = {pb[0] - an[0], pb[1] - an[1], pb[2] - an[2]}, c[3];
+      cross3(c, ax, r);
+      col = dot3(dif, c);
+    } else col = dot3(dif, ax);
+    E[Y.dlval + adr + k] = active ? (float)e[1] * col * invdiv : 0.f;
+  }
+  return active ? dist * invdiv : 0.f;
+}
+
+template <int NVT>
+__global__ void __launch_bounds__(64, 4) step_kernel_w(DevModel M, DevModelW W, DevBatch Bt, const float* __restrict__ action, int actmap, int nsub,
+                                                        long long* stamps) {
+  extern __shared__ __align__(16) float E[];
+  const LayW& Y = W.lay;
+  const int lane = threadIdx.x;
+  const int env = blockIdx.x;
+  const int nv = M.nv, nu = M.nu;
+#if MYO_STAMPS
+  long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long st_t0 = clock64();
+#endif
+  // ---- state: LDS copies of what other lanes gather; per-dof / per-actuator scalars stay in registers
+  float warm = 0.f, qacc = 0.f, actdot = 0.f;
+  if (lane < nv) {
+    E[Y.qpos + lane] = Bt.qpos[(size_t)env * nv + lane];
+    E[Y.qvel + lane] = Bt.qvel[(size_t)env * nv + lane];
+    warm = Bt.warm[(size_t)env * nv + lane];
+  }
+  if (lane < nu) {
+    E[Y.act + lane] = Bt.act[(size_t)env * nu + lane];
+    float c;
+    if (action) {
+      c = action[(size_t)env * nu + lane];
+      if (actmap == MYO_ACTMAP_MUSCLE_SIGMOID) c = 1.0f / (1.0f + expf(-5.0f * (c - 0.5f)));
+    } else c = Bt.ctrl[(size_t)env * nu + lane];
+    E[Y.ctrl + lane] = c;
+  }
+  float time = Bt.time[env];
+  int flags = 0, d_nefc = 0, d_ncon = 0, d_iter = 0;
+  bool alive = true;
+  const float h = M.timestep;
+  const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
+  const float damping = lane < nv ? M.dof_damping[lane] : 0.f;
+  SYNC();
+  for (int step = 0; step < nsub; step++) {
+    {  // mj_checkPos / mj_checkVel
+      bool bad = false;
+      if (lane < nv) { float a = E[Y.qpos + lane], b = E[Y.qvel + lane]; bad = !(a == a) || fabsf(a) > MAXVALF || !(b == b) || fabsf(b) > MAXVALF; }
+      if (__any(bad) && alive) { flags |= MYO_FLAG_BAD_STATE; alive = false; }
+    }
+    STAMP(0);
+    // ---------------------------------------------------------------- kinematics (lane = link, level by level)
+    for (int L = 0; L < M.nlevel; L++) {
+      int l = M.level_adr[L] + lane;
+      if (l < M.level_adr[L + 1]) {
+        float pos[3], R[9];
+        int par = M.link_parent[l];
+        const float* lp = M.link_pos + 3 * l;
+        if (par < 0) {
+          pos[0] = lp[0]; pos[1] = lp[1]; pos[2] = lp[2];
+#pragma unroll
+          for (int k = 0; k < 9; k++) R[k] = W.link_mat0[9 * l + k];
+        } else {
+          float v[3];
+          matvec(v, E + Y.lmat + 9 * par, lp);
+          pos[0] = E[Y.lpos + 3 * par] + v[0]; pos[1] = E[Y.lpos + 3 * par + 1] + v[1]; pos[2] = E[Y.lpos + 3 * par + 2] + v[2];
+          matmul3(R, E + Y.lmat + 9 * par, W.link_mat0 + 9 * l);
+        }
+        int da = M.link_dofadr[l], dn = M.link_dofnum[l];
+        for (int k = 0; k < dn; k++) {
+          int d = da + k;
+          const float* al = M.dof_axis + 3 * d;
+          float ax[3], an[3];
+          matvec(ax, R, al);
+          matvec(an, R, M.dof_pos + 3 * d);
+          an[0] += pos[0]; an[1] += pos[1]; an[2] += pos[2];
+          E[Y.axis + 3 * d] = ax[0]; E[Y.axis + 3 * d + 1] = ax[1]; E[Y.axis + 3 * d + 2] = ax[2];
+          E[Y.anchor + 3 * d] = an[0]; E[Y.anchor + 3 * d + 1] = an[1]; E[Y.anchor + 3 * d + 2] = an[2];
+          float ang = E[Y.qpos + d] - M.qpos0[d];
+          if (M.dof_type[d] == 3) {
+            float sn, cs;
+            sincosf(ang, &sn, &cs);
+            float oc = 1 - cs, x = al[0], y = al[1], z = al[2];
+            float Rj[9] = {cs + oc * x * x, oc * x * y - sn * z, oc * x * z + sn * y, oc * x * y + sn * z, cs + oc * y * y, oc * y * z - sn * x,
+                           oc * x * z - sn * y, oc * y * z + sn * x, cs + oc * z * z};
+            matmul3(R, R, Rj);
+            float v[3];
+            matvec(v, R, M.dof_pos + 3 * d);
+            pos[0] = an[0] - v[0]; pos[1] = an[1] - v[1]; pos[2] = an[2] - v[2];
+          } else {
+            pos[0] += ax[0] * ang; pos[1] += ax[1] * ang; pos[2] += ax[2] * ang;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) E[Y.lpos + 3 * l + k] = pos[k];
+#pragma unroll
+        for (int k = 0; k < 9; k++) E[Y.lmat + 9 * l + k] = R[k];
+      }
+      SYNC();
+    }
+    STAMP(1);
+    // ---------------------------------------------------------------- tendons: lane = segment
+    for (int base = 0; base < M.nseg; base += 64) {
+      int idx = base + lane;
+      if (idx < M.nseg) {
+        int si = W.seg_order[idx];
+        const int* S = M.seg + 12 * si;
+        float invdiv = 1.0f / M.seg_div[si];
+        float p0[3], p1[3];
+        site_world_w(M, Y, E, S[0], p0);
+        site_world_w(M, Y, E, S[1], p1);
+        float wlen = -1, wp[6];
+        if (S[2] >= 0) {
+          int g = S[2], gl = M.wg_link[g];
+          float gpos[3], gmat[9], side[3] = {0, 0, 0};
+          if (gl < 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) gpos[k] = M.wg_lpos[3 * g + k];
+#pragma unroll
+            for (int k = 0; k < 9; k++) gmat[k] = M.wg_lmat[9 * g + k];
+          } else {
+            float v[3];
+            matvec(v, E + Y.lmat + 9 * gl, M.wg_lpos + 3 * g);
+#pragma unroll
+            for (int k = 0; k < 3; k++) gpos[k] = E[Y.lpos + 3 * gl + k] + v[k];
+            matmul3(gmat, E + Y.lmat + 9 * gl, M.wg_lmat + 9 * g);
+          }
+          if (S[3] >= 0) site_world_w(M, Y, E, S[3], side);
+          wlen = wrap_geom(wp, p0, p1, gpos, gmat, M.wg_radius[g], S[10] != 0, side, S[3] >= 0);
+        }
+        bool wr = wlen >= 0;
+        float L = straight_w(M, Y, E, p0, p1, S[4], S[5], invdiv, !wr);
+        if (S[2] >= 0) {
+          L += straight_w(M, Y, E, p0, wp, S[6], S[7], invdiv, wr);
+          L += straight_w(M, Y, E, wp + 3, p1, S[8], S[9], invdiv, wr);
+          if (wr) L += wlen * invdiv;
+        }
+        E[Y.seglen + si] = L;
+      }
+    }
+    SYNC();
+    if (lane < M.ngt) {  // lane = tendon: gather its segments, then the muscle
+      int gt = lane;
+      float* Jrow = E + Y.tJ + gt * M.maxnnz;
+      for (int k = 0; k < M.maxnnz; k++) Jrow[k] = 0;
+      float L = 0;
+      for (int si = M.gt_seg_adr[gt]; si < M.gt_seg_adr[gt] + M.gt_seg_num[gt]; si++) L += E[Y.seglen + si];
+      int e0 = W.gt_dl[2 * gt], en = W.gt_dl[2 * gt + 1];
+      for (int e = e0; e < e0 + en; e++) Jrow[M.dl[3 * e + 2]] += E[Y.dlval + e];
+      E[Y.tlen + gt] = L;
+      if (gt < nu) {
+        const float* A = M.act + 16 * gt;
+        float vel = 0;
+        for (int k = 0; k < M.maxnnz; k++) {
+          int d = M.gt_dofs[gt * M.maxnnz + k];
+          if (d >= 0) vel += Jrow[k] * E[Y.qvel + d];
+        }
+        float f;
+        muscle(A, A[14] * L, A[14] * vel, E[Y.act + gt], E[Y.ctrl + gt], &f, &actdot);
+        E[Y.tforce + gt] = f * A[14];
+      }
+    }
+    SYNC();
+    float qfa = 0.f;
+    if (lane < nv) {
+      for (int k = M.col_adr[lane]; k < M.col_adr[lane + 1]; k++) {
+        int t = M.col[2 * k], slot = M.col[2 * k + 1];
+        qfa += E[Y.tJ + t * M.maxnnz + slot] * E[Y.tforce + t];
+      }
+    }
+    float tlen_out = lane < nu ? E[Y.tlen + lane] : 0.f, tforce_out = lane < nu ? E[Y.tforce + lane] : 0.f;
+    SYNC();  // region X changes owner: tendon scratch -> spatial dynamics
+    STAMP(2);
+    // ---------------------------------------------------------------- CRB + RNE (lane = link / dof)
+    if (lane < M.nl) {
+      int l = lane;
+      const float* R = E + Y.lmat + 9 * l;
+      const float* I = M.link_inertia + 6 * l;
+      float Il[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}, T[9], Iw[9], com[3];
+      matmul3(T, R, Il);
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Iw[3 * i + j] = T[3 * i] * R[3 * j] + T[3 * i + 1] * R[3 * j + 1] + T[3 * i + 2] * R[3 * j + 2];
+      matvec(com, R, M.link_com + 3 * l);
+      float mass = M.link_mass[l];
+      float dif[3] = {E[Y.lpos + 3 * l] + com[0] - M.c0[0], E[Y.lpos + 3 * l + 1] + com[1] - M.c0[1], E[Y.lpos + 3 * l + 2] + com[2] - M.c0[2]};
+      float ci[10];
+      ci[0] = Iw[0] + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
+      ci[1] = Iw[4] + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
+      ci[2] = Iw[8] + mass * (dif[0] * dif[0] + dif[1] * dif[1]);
+      ci[3] = Iw[1] - mass * dif[0] * dif[1];
+      ci[4] = Iw[2] - mass * dif[0] * dif[2];
+      ci[5] = Iw[5] - mass * dif[1] * dif[2];
+      ci[6] = mass * dif[0]; ci[7] = mass * dif[1]; ci[8] = mass * dif[2]; ci[9] = mass;
+#pragma unroll
+      for (int k = 0; k < 10; k++) { E[Y.cinert + 10 * l + k] = ci[k]; E[Y.crb + 10 * l + k] = ci[k]; }
+    }
+    if (lane < nv) {
+      int d = lane;
+      const float* ax = E + Y.axis + 3 * d;
+      float c[6];
+      if (M.dof_type[d] == 3) {
+        float off[3] = {M.c0[0] - E[Y.anchor + 3 * d], M.c0[1] - E[Y.anchor + 3 * d + 1], M.c0[2] - E[Y.anchor + 3 * d + 2]};
+        c[0] = ax[0]; c[1] = ax[1]; c[2] = ax[2];
+        cross3(c + 3, ax, off);
+      } else { c[0] = c[1] = c[2] = 0; c[3] = ax[0]; c[4] = ax[1]; c[5] = ax[2]; }
+#pragma unroll
+      for (int k = 0; k < 6; k++) E[Y.cdof + 6 * d + k] = c[k];
+    }
+    WFOR(i, NVT * (NVT + 1)) E[Y.sq + i] = 0;
+    SYNC();
+    for (int L = 0; L < M.nlevel; L++) {
+      int l = M.level_adr[L] + lane;
+      if (l < M.level_adr[L + 1]) {
+        int par = M.link_parent[l];
+        float cvel[6], cacc[6];
+        if (par < 0) {
+          cvel[0] = cvel[1] = cvel[2] = cvel[3] = cvel[4] = cvel[5] = 0;
+          cacc[0] = cacc[1] = cacc[2] = 0; cacc[3] = -M.grav[0]; cacc[4] = -M.grav[1]; cacc[5] = -M.grav[2];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 6; k++) { cvel[k] = E[Y.cvel + 6 * par + k]; cacc[k] = E[Y.cacc + 6 * par + k]; }
+        }
+        int da = M.link_dofadr[l], dn = M.link_dofnum[l];
+        for (int j = 0; j < dn; j++) {
+          int d = da + j;
+          float cd[6], cdd[6], qv = E[Y.qvel + d];
+#pragma unroll
+          for (int k = 0; k < 6; k++) cd[k] = E[Y.cdof + 6 * d + k];
+          cross_motion(cdd, cvel, cd);
+#pragma unroll
+          for (int k = 0; k < 6; k++) { cacc[k] += cdd[k] * qv; cvel[k] += cd[k] * qv; }
+        }
+        float ci[10], f[6], t[6], t1[6];
+#pragma unroll
+        for (int k = 0; k < 10; k++) ci[k] = E[Y.cinert + 10 * l + k];
+        mul_inert_vec(f, ci, cacc);
+        mul_inert_vec(t, ci, cvel);
+        cross_force(t1, cvel, t);
+#pragma unroll
+        for (int k = 0; k < 6; k++) { E[Y.cvel + 6 * l + k] = cvel[k]; E[Y.cacc + 6 * l + k] = cacc[k]; E[Y.cfrc + 6 * l + k] = f[k] + t1[k]; }
+      }
+      SYNC();
+    }
+    for (int L = M.nlevel - 2; L >= 0; L--) {
+      int l = M.level_adr[L] + lane;
+      if (l < M.level_adr[L + 1]) {
+        for (int ci = M.child_adr[l]; ci < M.child_adr[l + 1]; ci++) {
+          int c = M.child[ci];
+#pragma unroll
+          for (int k = 0; k < 6; k++) E[Y.cfrc + 6 * l + k] += E[Y.cfrc + 6 * c + k];
+#pragma unroll
+          for (int k = 0; k < 10; k++) E[Y.crb + 10 * l + k] += E[Y.crb + 10 * c + k];
+        }
+      }
+      SYNC();
+    }
+    float smooth = 0.f;
+    if (lane < nv) {
+      int d = lane, l = M.dof_link[d];
+      float cd[6], buf[6], crb[10];
+#pragma unroll
+      for (int k = 0; k < 6; k++) cd[k] = E[Y.cdof + 6 * d + k];
+#pragma unroll
+      for (int k = 0; k < 10; k++) crb[k] = E[Y.crb + 10 * l + k];
+      float bias = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) bias += cd[k] * E[Y.cfrc + 6 * l + k];
+      mul_inert_vec(buf, crb, cd);
+      int a = d;
+      while (a >= 0) {
+        float sdot = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) sdot += E[Y.cdof + 6 * a + k] * buf[k];
+        if (a == d) sdot += M.dof_armature[d];
+        E[Y.sq + d * (NVT + 1) + a] = sdot;   // full symmetric copy: (d,a) and (a,d)
+        E[Y.sq + a * (NVT + 1) + d] = sdot;
+        a = M.dof_parent[a];
+      }
+      smooth = -damping * E[Y.qvel + d] - bias + qfa;
+    }
+    SYNC();  // region X changes owner: dynamics scratch -> collision / contact rows
+    STAMP(3);
+    // ---------------------------------------------------------------- collision (geom frames computed on the fly)
+    int ncon = 0;
+    if (!M.disable_contact) {
+      int ncand = 0;
+      int* cand = (int*)(E + Y.cand);
+      if (lane < M.ncg) {   // world centre and long axis (3rd column) of every collision geom
+        float x[3], R[9];
+        geom_world_pos(M, Y, E, lane, x);
+        geom_world_mat(M, Y, E, lane, R);
+        E[Y.gpos + 3 * lane] = x[0]; E[Y.gpos + 3 * lane + 1] = x[1]; E[Y.gpos + 3 * lane + 2] = x[2];
+        E[Y.gax + 3 * lane] = R[2]; E[Y.gax + 3 * lane + 1] = R[5]; E[Y.gax + 3 * lane + 2] = R[8];
+      }
+      SYNC();
+      for (int base = 0; base < M.npair; base += 64) {
+        int p = base + lane;
+        bool hit = false;
+        if (p < M.npair) {
+          const int* P = M.pair_i + 6 * p;
+          if (!(M.disable_ellipsoid && !P[4])) {
+            int g1 = P[0], g2 = P[1];
+            const float *x1 = E + Y.gpos + 3 * g1, *x2 = E + Y.gpos + 3 * g2;
+            float dif[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
+            float bound = M.cg_rbound[g1] + M.cg_rbound[g2] + M.pair_f[12 * p];
+            hit = dot3(dif, dif) <= bound * bound;
+            if (hit && !P[4]) {
+              // conservative refinement before the expensive MPR: replace a capsule's bounding sphere by the distance
+              // from the other geom's centre to the capsule's SEGMENT (a bound on the true distance, never excludes a contact)
+              float b1 = M.cg_rbound[g1], b2 = M.cg_rbound[g2];
+              float c1[3] = {x1[0], x1[1], x1[2]}, c2[3] = {x2[0], x2[1], x2[2]};
+              if (M.cg_type[g1] == GEOM_CAPSULE) {
+                const float* a = E + Y.gax + 3 * g1;
+                float hh = M.cg_size[3 * g1 + 1], t = clipf(dot3(dif, a), -hh, hh);
+                c1[0] += t * a[0]; c1[1] += t * a[1]; c1[2] += t * a[2];
+                b1 = M.cg_size[3 * g1];
+              }
+              if (M.cg_type[g2] == GEOM_CAPSULE) {
+                const float* a = E + Y.gax + 3 * g2;
+                float nd[3] = {c1[0] - x2[0], c1[1] - x2[1], c1[2] - x2[2]};
+                float hh = M.cg_size[3 * g2 + 1], t = clipf(dot3(nd, a), -hh, hh);
+                c2[0] += t * a[0]; c2[1] += t * a[1]; c2[2] += t * a[2];
+                b2 = M.cg_size[3 * g2];
+              }
+              float d2[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
+              float bb = b1 + b2 + M.pair_f[12 * p];
+              hit = dot3(d2, d2) <= bb * bb;
+            }
+          }
+        }
+        unsigned long long bal = __ballot(hit);
+        int pos = ncand + __popcll(bal & ((1ull << lane) - 1ull));
+        if (hit && pos < NCAND) cand[pos] = p;
+        ncand += __popcll(bal);
+      }
+      if (ncand > NCAND) { flags |= MYO_FLAG_CAND_OVERFLOW; ncand = NCAND; }
+      SYNC();
+      for (int base = 0; base < ncand; base += 64) {
+        int ci = base + lane;
+        bool hit = false;
+        float dist = 0, cpos[3] = {0, 0, 0}, nrm[3] = {1, 0, 0};
+        int p = -1;
+        if (ci < ncand) {
+          p = cand[ci];
+          const int* P = M.pair_i + 6 * p;
+          int g1 = P[0], g2 = P[1];
+          float margin = M.pair_f[12 * p];
+          const float *x1 = E + Y.gpos + 3 * g1, *x2 = E + Y.gpos + 3 * g2;
+          const float *sz1 = M.cg_size + 3 * g1, *sz2 = M.cg_size + 3 * g2;
+          if (P[4]) {
+            const float *a1 = E + Y.gax + 3 * g1, *a2 = E + Y.gax + 3 * g2;
+            float dif[3] = {x1[0] - x2[0], x1[1] - x2[1], x1[2] - x2[2]};
+            float mb = -dot3(a1, a2), u = -dot3(a1, dif), v = dot3(a2, dif), det = 1 - mb * mb, xa, xb;
+            if (fabsf(det) >= MINVALF) {
+              xa = (u - mb * v) / det;
+              xb = (v - mb * u) / det;
+              if (xa > sz1[1]) { xa = sz1[1]; xb = v - mb * sz1[1]; }
+              else if (xa < -sz1[1]) { xa = -sz1[1]; xb = v + mb * sz1[1]; }
+              if (xb > sz2[1]) { xb = sz2[1]; xa = clipf(u - mb * sz2[1], -sz1[1], sz1[1]); }
+              else if (xb < -sz2[1]) { xb = -sz2[1]; xa = clipf(u + mb * sz2[1], -sz1[1], sz1[1]); }
+            } else {
+              xa = clipf(u, -sz1[1], sz1[1]);
+              xb = clipf(v - mb * xa, -sz2[1], sz2[1]);
+              xa = clipf(u - mb * xb, -sz1[1], sz1[1]);
+            }
+            float v1[3] = {x1[0] + a1[0] * xa, x1[1] + a1[1] * xa, x1[2] + a1[2] * xa};
+            float v2[3] = {x2[0] + a2[0] * xb, x2[1] + a2[1] * xb, x2[2] + a2[2] * xb};
+            float dd[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
+            float cd = norm3(dd);
+            if (cd <= margin + sz1[0] + sz2[0]) {
+              if (cd < MINVALF) { dd[0] = 1; dd[1] = 0; dd[2] = 0; } else { float inv = 1.0f / cd; dd[0] *= inv; dd[1] *= inv; dd[2] *= inv; }
+              dist = cd - sz1[0] - sz2[0];
+#pragma unroll
+              for (int k = 0; k < 3; k++) { cpos[k] = v1[k] + dd[k] * (sz1[0] + 0.5f * dist); nrm[k] = dd[k]; }
+              hit = true;
+            }
+          } else {
+            const float zero3[3] = {0.f, 0.f, 0.f};
+            float rel[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]}, R1[9], R2[9];
+            geom_world_mat(M, Y, E, g1, R1);
+            geom_world_mat(M, Y, E, g2, R2);
+            CObj o1 = {zero3, R1, sz1, M.cg_type[g1], 0.5f * margin}, o2 = {rel, R2, sz2, M.cg_type[g2], 0.5f * margin};
+            float depth, dir[3], pos[3];
+            if (mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos)) {
+              dist = margin - depth;
+              normalize3(dir);
+#pragma unroll
+              for (int k = 0; k < 3; k++) { cpos[k] = pos[k] + x1[k]; nrm[k] = dir[k]; }
+              hit = true;
+            }
+          }
+          if (hit && !(dist < margin - M.pair_f[12 * p + 1])) hit = false;
+        }
+        unsigned long long bal = __ballot(hit);
+        int pos = ncon + __popcll(bal & ((1ull << lane) - 1ull));
+        if (hit && pos < NCONW) {
+          E[Y.cdist + pos] = dist;
+#pragma unroll
+          for (int k = 0; k < 3; k++) { E[Y.cpos + 3 * pos + k] = cpos[k]; E[Y.cnrm + 3 * pos + k] = nrm[k]; }
+          ((int*)(E + Y.cpair))[pos] = p;
+        }
+        ncon += __popcll(bal);
+      }
+      if (ncon > NCONW) { flags |= MYO_FLAG_CONTACT_OVERFLOW; ncon = NCONW; }
+      SYNC();
+    }
+    STAMP(4);
+    // ---------------------------------------------------------------- constraint rows (registers: lane = dof / lane = contact)
+    float lsign = 0.f, laref = 0.f, lD = 0.f;
+    if (lane < nv && !M.disable_limit) {
+      const float* J = M.jl + 12 * lane;
+      if (J[0] != 0) {
+        float q = E[Y.qpos + lane], margin = J[3];
+        float dlo = q - J[1], dhi = J[2] - q, dist = 0;
+        if (dlo < margin && dlo <= dhi) { lsign = 1; dist = dlo; }
+        else if (dhi < margin) { lsign = -1; dist = dhi; }
+        if (lsign != 0) {
+          float imp = impedance(J + 6, dist, margin), K, B;
+          float R = fmaxf(MINVALF, (1 - imp) / imp * J[11]);
+          kbi(J[4], J[5], J[7], M.timestep, &K, &B);
+          laref = -B * (lsign * E[Y.qvel + lane]) - K * imp * (dist - margin);
+          lD = 1.0f / R;
+        }
+      }
+    }
+    float caref[4] = {0, 0, 0, 0}, cD = 0.f, cmu = 0.f;
+    int ckc = 0;
+    if (lane < ncon) {
+      int c = lane;
+      int p = ((const int*)(E + Y.cpair))[c];
+      const int* P = M.pair_i + 6 * p;
+      const float* F = M.pair_f + 12 * p;
+      float n[3] = {E[Y.cnrm + 3 * c], E[Y.cnrm + 3 * c + 1], E[Y.cnrm + 3 * c + 2]}, t1[3], t2[3];
+      float cp[3] = {E[Y.cpos + 3 * c], E[Y.cpos + 3 * c + 1], E[Y.cpos + 3 * c + 2]};
+      make_frame(n, t1, t2);
+      float vn = 0, vt1 = 0, vt2 = 0;
+      float* cJ = E + Y.cJ + c * 3 * KCMAX;
+      unsigned int dpk0 = 0, dpk1 = 0;
+      ckc = P[3];
+#pragma unroll
+      for (int k = 0; k < KCMAX; k++) {
+        float jn = 0, j1 = 0, j2 = 0;
+        int d = 0;
+        if (k < ckc) {
+          d = M.pair_dl[2 * (P[2] + k)];
+          float sg = (float)M.pair_dl[2 * (P[2] + k) + 1];
+          const float* ax = E + Y.axis + 3 * d;
+          float col[3];
+          if (M.dof_type[d] == 3) {
+            float r[3] = {cp[0] - E[Y.anchor + 3 * d], cp[1] - E[Y.anchor + 3 * d + 1], cp[2] - E[Y.anchor + 3 * d + 2]};
+            cross3(col, ax, r);
+          } else { col[0] = ax[0]; col[1] = ax[1]; col[2] = ax[2]; }
+          jn = sg * dot3(n, col); j1 = sg * dot3(t1, col); j2 = sg * dot3(t2, col);
+          float qv = E[Y.qvel + d];
+          vn += jn * qv; vt1 += j1 * qv; vt2 += j2 * qv;
+        }
+        cJ[k] = jn; cJ[KCMAX + k] = j1; cJ[2 * KCMAX + k] = j2;
+        if (k < 4) dpk0 |= (unsigned int)d << (8 * k); else dpk1 |= (unsigned int)d << (8 * (k - 4));   // padded entries: zero jacobian, dof 0
+      }
+      ((unsigned int*)(E + Y.cdofs))[2 * c] = dpk0;
+      ((unsigned int*)(E + Y.cdofs))[2 * c + 1] = dpk1;
+      float dist = E[Y.cdist + c], incl = F[0] - F[1];
+      cmu = F[2];
+      float imp = impedance(F + 6, dist, incl), K, B;
+      kbi(F[4], F[5], F[7], M.timestep, &K, &B);
+      float R0 = fmaxf(MINVALF, (1 - imp) / imp * F[3] * (1 + cmu * cmu));
+      cD = 1.0f / fmaxf(MINVALF, 2 * cmu * cmu * R0);
+      float pos = -K * imp * (dist - incl);
+      caref[0] = -B * (vn + cmu * vt1) + pos; caref[1] = -B * (vn - cmu * vt1) + pos;
+      caref[2] = -B * (vn + cmu * vt2) + pos; caref[3] = -B * (vn - cmu * vt2) + pos;
+    }
+    int nefc = __popcll(__ballot(lsign != 0.f)) + 4 * ncon;
+    SYNC();
+    float Mrow[NVT];   // row `lane` of the (full symmetric) mass matrix, kept in registers for the whole solver
+#pragma unroll
+    for (int k = 0; k < NVT; k++) Mrow[k] = (lane < nv) ? E[Y.sq + lane * (NVT + 1) + k] : 0.f;
+    SYNC();
+    STAMP(5);
+    // ---------------------------------------------------------------- solver: Newton iterations, then the Euler solve, sharing ONE
+    // instance of the unrolled register Cholesky.  phase 0 = Newton, 1 = unconstrained (nefc == 0), 2 = Euler (implicit damping)
+    float Ma = 0.f, grad = 0.f, qfc = 0.f, ljar = 0.f, ljv = 0.f, cost = 0.f, qaccE = 0.f;
+    float cjar[4] = {0, 0, 0, 0}, cjv[4] = {0, 0, 0, 0};
+    int phase = nefc > 0 ? 0 : 1, iters = 0;
+    if (phase == 0) {  // start from the warm start (MuJoCo also tries qacc_smooth; the minimiser is the same)
+      qacc = warm;
+      Ma = symv_rows<NVT>(Mrow, qacc);
+      ljar = lsign * qacc - laref;
+      if (lane < nv) E[Y.xv + lane] = qacc;
+      SYNC();
+      if (lane < ncon) {
+        const float* cJ = E + Y.cJ + lane * 3 * KCMAX;
+        float an = 0, a1 = 0, a2 = 0;
+#pragma unroll
+        for (int k = 0; k < KCMAX; k++) { float xv = E[Y.xv + CDOF(E, Y, lane, k)]; an += cJ[k] * xv; a1 += cJ[KCMAX + k] * xv; a2 += cJ[2 * KCMAX + k] * xv; }
+        cjar[0] = an + cmu * a1 - caref[0]; cjar[1] = an - cmu * a1 - caref[1]; cjar[2] = an + cmu * a2 - caref[2]; cjar[3] = an - cmu * a2 - caref[3];
+      }
+    }
+    bool first = true;
+    while (true) {
+      float r[NVT], rhs;
+      if (phase == 0) {
+        // forces of the active rows, J^T f (LDS atomics), cost, gradient, Hessian blocks (LDS atomics)
+        bool lact = lsign != 0.f && ljar < 0;
+        float w0 = cjar[0] < 0 ? cD : 0.f, w1 = cjar[1] < 0 ? cD : 0.f, w2 = cjar[2] < 0 ? cD : 0.f, w3 = cjar[3] < 0 ? cD : 0.f;
+        float f0 = -w0 * cjar[0], f1 = -w1 * cjar[1], f2 = -w2 * cjar[2], f3 = -w3 * cjar[3];
+        if (lane < nv) E[Y.qfc + lane] = lact ? -lsign * lD * ljar : 0.f;
+        WFOR(i, NVT * (NVT + 1)) E[Y.sq + i] = 0;
+        SYNC();
+        if (lane < ncon) {
+          const float* cJ = E + Y.cJ + lane * 3 * KCMAX;
+          float Fn = f0 + f1 + f2 + f3, Ft1 = cmu * (f0 - f1), Ft2 = cmu * (f2 - f3);
+          for (int k = 0; k < ckc; k++) atomicAdd(&E[Y.qfc + CDOF(E, Y, lane, k)], Fn * cJ[k] + Ft1 * cJ[KCMAX + k] + Ft2 * cJ[2 * KCMAX + k]);
+        }
+        if (lane < nv && lact) E[Y.sq + lane * (NVT + 1) + lane] = lD;
+        float Wn = w0 + w1 + w2 + w3, A1 = cmu * (w0 - w1), A2 = cmu * (w2 - w3), B1 = cmu * cmu * (w0 + w1), B2 = cmu * cmu * (w2 + w3);
+        SYNC();
+        for (int c = 0; c < ncon; c++) {   // one contact per step, lanes = entries of its kc x kc block
+          int kc = rdlanei(ckc, c);
+          float sW = rdlane(Wn, c), sA1 = rdlane(A1, c), sA2 = rdlane(A2, c), sB1 = rdlane(B1, c), sB2 = rdlane(B2, c);
+          if (sW == 0.f) continue;
+          if (lane < kc * kc) {
+            int a = lane / kc, b = lane - a * kc;
+            const float* cJ = E + Y.cJ + c * 3 * KCMAX;
+            int da = CDOF(E, Y, c, a), db = CDOF(E, Y, c, b);
+            if (da >= db) {
+              float na = cJ[a], nb = cJ[b], ta = cJ[KCMAX + a], tb = cJ[KCMAX + b], ua = cJ[2 * KCMAX + a], ub = cJ[2 * KCMAX + b];
+              atomicAdd(&E[Y.sq + da * (NVT + 1) + db], sW * na * nb + sA1 * (na * tb + ta * nb) + sA2 * (na * ub + ua * nb) + sB1 * ta * tb + sB2 * ua * ub);
+            }
+          }
+        }
+        SYNC();
+        qfc = lane < nv ? E[Y.qfc + lane] : 0.f;
+        float cst = lact ? 0.5f * lD * ljar * ljar : 0.f;
+        cst += 0.5f * (w0 * cjar[0] * cjar[0] + w1 * cjar[1] * cjar[1] + w2 * cjar[2] * cjar[2] + w3 * cjar[3] * cjar[3]);
+        cst += 0.5f * qacc * Ma - qacc * smooth;          // Gauss term up to a constant
+        float newcost = wave_sum(cst);
+        grad = Ma - smooth - qfc;
+        if (!first) {
+          float improvement = scale * (cost - newcost);
+          float gn = scale * sqrtf(wave_sum(grad * grad));
+          iters++;
+          if (improvement < fmaxf(M.tolerance, 1e-6f * scale * fabsf(newcost)) || gn < M.tolerance || iters >= M.iterations) phase = 2;
+        }
+        cost = newcost;
+        first = false;
+      }
+      if (phase == 0) {
+#pragma unroll
+        for (int k = 0; k < NVT; k++) r[k] = (lane < nv) ? E[Y.sq + lane * (NVT + 1) + k] + Mrow[k] : (k == lane ? 1.f : 0.f);
+        rhs = -grad;
+      } else if (phase == 1) {
+#pragma unroll
+        for (int k = 0; k < NVT; k++) r[k] = (lane < nv) ? Mrow[k] : (k == lane ? 1.f : 0.f);
+        rhs = smooth;
+      } else {
+#pragma unroll
+        for (int k = 0; k < NVT; k++) r[k] = (lane < nv) ? Mrow[k] + (k == lane ? h * damping : 0.f) : (k == lane ? 1.f : 0.f);
+        rhs = smooth + qfc;
+      }
+      SYNC();
+      float invd = chol_rows<NVT>(r, lane);
+      if (lane < NVT) {
+#pragma unroll
+        for (int k = 0; k < NVT; k++) E[Y.sq + lane * (NVT + 1) + k] = r[k];
+      }
+      SYNC();
+      float x = chol_solve_rows<NVT>(r, invd, rhs, E + Y.sq, lane);
+      if (phase == 1) { qacc = x; qfc = 0.f; phase = 2; continue; }
+      if (phase == 2) { qaccE = x; break; }
+      // ---- Newton: exact line search along x
+      float search = lane < nv ? x : 0.f;
+      float Mv = symv_rows<NVT>(Mrow, search);
+      ljv = lsign * search;
+      if (lane < nv) E[Y.xv + lane] = search;
+      SYNC();
+      if (lane < ncon) {
+        const float* cJ = E + Y.cJ + lane * 3 * KCMAX;
+        float an = 0, a1 = 0, a2 = 0;
+#pragma unroll
+        for (int k = 0; k < KCMAX; k++) { float xv = E[Y.xv + CDOF(E, Y, lane, k)]; an += cJ[k] * xv; a1 += cJ[KCMAX + k] * xv; a2 += cJ[2 * KCMAX + k] * xv; }
+        cjv[0] = an + cmu * a1; cjv[1] = an - cmu * a1; cjv[2] = an + cmu * a2; cjv[3] = an - cmu * a2;
+      }
+      float g1 = wave_sum(search * (Ma - smooth)), g2 = wave_sum(0.5f * search * Mv), sn = sqrtf(wave_sum(search * search));
+      float alpha = 0, lo = 0, hi = -1, dlo = 0, d2lo = 0, dhi = 0, d2hi = 0, d1init = 0;
+      bool ls_on = sn >= MINVALF;
+      for (int lsit = -1; lsit < M.ls_iterations && ls_on; lsit++) {
+        float a = (lsit < 0) ? 0.f : alpha;
+        float p1 = 0, p2 = 0;
+        if (lsign != 0.f) { float xx = ljar + a * ljv; if (xx < 0) { p1 += lD * xx * ljv; p2 += lD * ljv * ljv; } }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { float xx = cjar[k] + a * cjv[k]; if (xx < 0) { p1 += cD * xx * cjv[k]; p2 += cD * cjv[k] * cjv[k]; } }
+        float d1 = wave_sum(p1) + g1 + 2 * a * g2;
+        float d2 = wave_sum(p2) + 2 * g2;
+        if (lsit < 0) {
+          if (d1 >= 0 || d2 <= 0) { ls_on = false; alpha = 0; break; }
+          dlo = d1; d2lo = d2; d1init = fabsf(d1);
+          alpha = -d1 / d2;
+          continue;
+        }
+        float gtol = fmaxf(M.tolerance * M.ls_tolerance * sn / scale, 1e-6f * d1init);
+        if (fabsf(d1) < gtol) break;
+        if (d1 < 0) { lo = alpha; dlo = d1; d2lo = d2; } else { hi = alpha; dhi = d1; d2hi = d2; }
+        float cand = alpha - d1 / d2;
+        if (hi < 0) {
+          if (!(cand > lo)) break;
+          alpha = cand;
+        } else {
+          if (!(cand > lo && cand < hi)) {
+            float c2 = d1 < 0 ? hi - dhi / d2hi : lo - dlo / d2lo;
+            cand = (c2 > lo && c2 < hi) ? c2 : 0.5f * (lo + hi);
+          }
+          if (cand == alpha || hi - lo <= 1e-7f * hi) break;
+          alpha = cand;
+        }
+      }
+      if (!(alpha > 0)) { phase = 2; continue; }   // no descent left: keep qacc / qfc of this iterate
+      qacc += alpha * search; Ma += alpha * Mv; ljar += alpha * ljv;
+#pragma unroll
+      for (int k = 0; k < 4; k++) cjar[k] += alpha * cjv[k];
+    }
+    STAMP(7);
+    d_nefc = nefc; d_ncon = ncon; d_iter = max(d_iter, iters);
+    {  // mj_checkAcc
+      bool bad = lane < nv && (!(qacc == qacc) || fabsf(qacc) > MAXVALF);
+      if (__any(bad) && alive) { flags |= MYO_FLAG_BAD_QACC; alive = false; }
+    }
+    warm = qacc;
+    if (alive) {
+      if (lane < nu) E[Y.act + lane] += h * actdot;
+      if (lane < nv) { float v = E[Y.qvel + lane] + h * qaccE; E[Y.qvel + lane] = v; E[Y.qpos + lane] += h * v; }
+      time += h;
+    }
+    if (step == nsub - 1 && lane < nu) {   // diagnostics of the last substep
+      Bt.tenlen[(size_t)env * nu + lane] = tlen_out;
+      Bt.actforce[(size_t)env * nu + lane] = tforce_out;
+    }
+    SYNC();
+    STAMP(8);
+  }
+  if (!alive) {  // a bad env is reset like mj_resetData (mj_sim_scene.py:56-61)
+    if (lane < nv) { E[Y.qpos + lane] = M.qpos0[lane]; E[Y.qvel + lane] = 0; warm = 0; }
+    if (lane < nu) { E[Y.act + lane] = 0; E[Y.ctrl + lane] = 0; }
+    time = 0;
+  }
+  if (lane < nv) {
+    Bt.qpos[(size_t)env * nv + lane] = E[Y.qpos + lane];
+    Bt.qvel[(size_t)env * nv + lane] = E[Y.qvel + lane];
+    Bt.warm[(size_t)env * nv + lane] = warm;
+    Bt.qacc[(size_t)env * nv + lane] = qacc;
+  }
+  if (lane < nu) {
+    Bt.act[(size_t)env * nu + lane] = E[Y.act + lane];
+    Bt.ctrl[(size_t)env * nu + lane] = E[Y.ctrl + lane];
+  }
+  if (lane == 0) {
+    Bt.time[env] = time;
+    Bt.elapsed[env] += 1;
+    Bt.flags[env] |= flags;
+    Bt.diag[(size_t)env * 8 + 0] = d_nefc; Bt.diag[(size_t)env * 8 + 1] = d_ncon; Bt.diag[(size_t)env * 8 + 2] = d_iter;
+  }
+#if MYO_STAMPS
+  STAMP(9);
+  if (stamps && lane == 0) for (int k = 0; k < 12; k++) stamps[(size_t)blockIdx.x * 12 + k] = st_acc[k];
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // counter-based RNG (splitmix64 of (seed, stream, counter)) -> U[0,1)
 __device__ __host__ inline float u01(uint64_t seed, uint64_t a, uint64_t b) {
@@ -1493,7 +2287,7 @@ __global__ void __launch_bounds__(64) reach_obs_kernel(DevModel M, DevBatch Bt, 
 // ================================================================================================
 // host side
 // ================================================================================================
-static int g_lanes = 16;  // lanes per env (16 / 32 / 64); MYO_LANES env var or myo_set_lanes()
+static int g_lanes = 64;  // lanes per env (16 / 32 / 64); MYO_LANES env var or myo_set_lanes(); 64 = wave-per-env kernel
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(MYO_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
@@ -1503,6 +2297,9 @@ struct BlobRec { char name[32]; uint32_t dtype, ndim, shape[4]; uint64_t nbytes,
 struct myo_model {
   int device = 0;
   DevModel dm{};
+  DevModelW dw{};
+  int env_lds_bytes_w = 0;
+  bool wave_ok = false;
   myo_dims dims{};
   std::vector<void*> dev_allocs;
   std::vector<float> qpos0, jnt_lo, jnt_hi;
@@ -1560,6 +2357,29 @@ static int load_i(myo_model* m, const uint8_t* blob, const char* name, const int
   memcpy(v.data(), blob + r->offset, n * 4);
   if (keep) *keep = v;
   return upload<int>(m, v, out);
+}
+
+static void build_layout_w(const DevModel& d, DevModelW& w, int nvt) {
+  LayW& Y = w.lay;
+  int o = 0;
+  auto take = [&](int n) { int r = o; o += n; return r; };
+  int nv = d.nv, nu = d.nu, nl = d.nl;
+  Y.qpos = take(nv); Y.qvel = take(nv); Y.act = take(nu); Y.ctrl = take(nu);
+  Y.lpos = take(3 * nl); Y.lmat = take(9 * nl); Y.axis = take(3 * nv); Y.anchor = take(3 * nv);
+  Y.xv = take(nvt); Y.qfc = take(nvt); Y.sq = take(nvt * (nvt + 1));
+  Y.X = o;
+  Y.tJ = take(d.ngt * d.maxnnz); Y.tlen = take(d.ngt); Y.tforce = take(nu); Y.seglen = take(d.nseg); Y.dlval = take(w.ndl);
+  int endT = o;
+  o = Y.X;
+  Y.cdof = take(6 * nv); Y.cinert = take(10 * nl); Y.crb = take(10 * nl); Y.cvel = take(6 * nl); Y.cacc = take(6 * nl); Y.cfrc = take(6 * nl);
+  int endD = o;
+  o = Y.X;
+  Y.gpos = take(3 * d.ncg); Y.gax = take(3 * d.ncg);
+  Y.cand = take(NCAND); Y.cdist = take(NCONW); Y.cpos = take(3 * NCONW); Y.cnrm = take(3 * NCONW); Y.cpair = take(NCONW);
+  Y.cJ = take(NCONW * 3 * KCMAX); Y.cdofs = take(NCONW * 2);   // 8 dof ids per contact, one byte each
+  if (o < endT) o = endT;
+  if (o < endD) o = endD;
+  Y.total = o;
 }
 
 static void build_layout(DevModel& d) {
@@ -1650,7 +2470,20 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
   for (int i = 0; i < d.nv; i++) { m->jnt_lo[i] = jl[12 * i + 1]; m->jnt_hi[i] = jl[12 * i + 2]; }
   build_layout(d);
   m->env_lds_bytes = d.lay.total * 4;
-  m->dims = myo_dims{S[0], S[1], S[2], S[3], S[4], S[8], S[7], d.nl, 0, m->env_lds_bytes, 16, NCON, d.timestep};
+  {  // wave-per-env kernel tables (one env per wavefront, nv <= 24)
+    DevModelW& w = m->dw;
+    std::vector<int> nws;
+    const int* tmpi;
+    if ((rc = load_i(m, blob, "hip_seg_order", &w.seg_order)) || (rc = load_i(m, blob, "hip_seg_tendon", &w.seg_tendon)) ||
+        (rc = load_i(m, blob, "hip_gt_dl", &w.gt_dl)) || (rc = load_f(m, blob, "hip_link_mat0", &w.link_mat0)) ||
+        (rc = load_i(m, blob, "hip_nwrapseg", &tmpi, &nws))) { myo_model_free(m); return rc; }
+    w.nwrapseg = nws[0];
+    w.ndl = H[6];
+    m->wave_ok = d.nv <= 24 && d.nu <= 64 && d.ngt <= 64 && d.nl <= 64 && d.ncg <= 64;
+    build_layout_w(d, w, 24);
+    m->env_lds_bytes_w = w.lay.total * 4;
+  }
+  m->dims = myo_dims{S[0], S[1], S[2], S[3], S[4], S[8], S[7], d.nl, 0, m->env_lds_bytes, 64, NCON, d.timestep};
   if (4 * m->env_lds_bytes > 160 * 1024) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "model working set exceeds 160 KB of LDS per workgroup"); }
   *out = m;
   return MYO_OK;
@@ -1849,7 +2682,7 @@ int myo_set_state(myo_batch* b, const float* qpos, const float* qvel, const floa
 
 static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, hipStream_t s) {
   const myo_model* m = b->model;
-  const int G = g_lanes, EPW = 64 / G;
+  const int G = (g_lanes == 64 && !m->wave_ok) ? 16 : g_lanes, EPW = 64 / G;   // models the wave kernel cannot take fall back to 16 lanes
   int grid = (b->db.B + EPW - 1) / EPW;
   size_t lds = (size_t)EPW * m->env_lds_bytes;
   static bool attr_set = false;
@@ -1861,6 +2694,13 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     attr_set = true;
   }
   long long* st = b->d_stamps;
+  if (G == 64 && m->wave_ok) {
+    static bool attr_w = false;
+    if (!attr_w) { HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr_w = true; }
+    hipLaunchKernelGGL(step_kernel_w<24>, dim3(b->db.B), dim3(64), (size_t)m->env_lds_bytes_w, s, m->dm, m->dw, b->db, action, actmap, nsub, st);
+    HIPCHK(hipGetLastError());
+    return MYO_OK;
+  }
   if (G == 16) hipLaunchKernelGGL(step_kernel<16>, dim3(grid), dim3(64), lds, s, m->dm, b->db, action, actmap, nsub, st);
   else if (G == 32) hipLaunchKernelGGL(step_kernel<32>, dim3(grid), dim3(64), lds, s, m->dm, b->db, action, actmap, nsub, st);
   else hipLaunchKernelGGL(step_kernel<64>, dim3(grid), dim3(64), lds, s, m->dm, b->db, action, actmap, nsub, st);

@@ -235,6 +235,21 @@ def lower(cm):
             seg_div.append(div)
         gt_seg_num.append(len(segs) - gt_seg_adr[-1])
         gt_dofs.append(row)
+    # per-tendon contiguous range of moment-arm entries, and a segment order with the wrapping segments first
+    # (the wave-per-env kernel runs lane = segment: one full round of wraps, then straight segments only)
+    gt_dl_adr, gt_dl_num = [], []
+    for i in range(len(gt_tendon)):
+        sa, sn = gt_seg_adr[i], gt_seg_num[i]
+        es = [x for sg in segs[sa:sa + sn] for x in ((sg[4], sg[5]), (sg[6], sg[7]), (sg[8], sg[9])) if x[1] > 0]
+        lo_e = min([a for a, n in es], default=0)
+        hi_e = max([a + n for a, n in es], default=0)
+        gt_dl_adr.append(lo_e)
+        gt_dl_num.append(hi_e - lo_e)
+    seg_tendon = []
+    for i in range(len(gt_tendon)):
+        seg_tendon += [i] * gt_seg_num[i]
+    seg_order = [k for k in range(len(segs)) if segs[k][2] >= 0] + [k for k in range(len(segs)) if segs[k][2] < 0]
+    nwrapseg = sum(1 for sg in segs if sg[2] >= 0)
     maxnnz = max([len(r) for r in gt_dofs] + [1])
     ngt = len(gt_tendon)
     gt_dof_tab = np.full((ngt, maxnnz), -1, np.int32)
@@ -379,6 +394,11 @@ def lower(cm):
     A["hip_gt_seg_adr"] = np.array(gt_seg_adr, np.int32)
     A["hip_gt_seg_num"] = np.array(gt_seg_num, np.int32)
     A["hip_gt_dofs"] = gt_dof_tab
+    A["hip_gt_dl"] = np.stack([np.array(gt_dl_adr, np.int32), np.array(gt_dl_num, np.int32)], 1).reshape(-1, 2)
+    A["hip_seg_order"] = np.array(seg_order, np.int32)
+    A["hip_seg_tendon"] = np.array(seg_tendon, np.int32)
+    A["hip_nwrapseg"] = np.array([nwrapseg], np.int32)
+    A["hip_link_mat0"] = np.stack([quat2mat(q).ravel() for q in link_quat]) if nl else np.zeros((0, 9))
     A["hip_seg"] = np.array(segs, np.int32).reshape(-1, SEG_INTS)
     A["hip_seg_div"] = np.array(seg_div)
     A["hip_dl"] = np.array(dls, np.int32).reshape(-1, 3)

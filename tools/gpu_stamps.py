@@ -10,7 +10,7 @@ B = int(os.environ.get("B", 4096))
 NAMES = ["load/check", "kinematics", "tendon+muscle", "dynamics(CRB/RNE)", "collision", "constraint rows", "chol+solve(qacc_smooth)", "newton", "euler", "store"]
 env = BatchedMyoEnv("myoHandPoseRandom-v0", num_envs=B, as_torch=False)
 mode = capi.BENCH_OBS | capi.BENCH_FRESH_ACTIONS | capi.BENCH_AUTORESET
-for lanes in (16, 32, 64):
+for lanes in (16, 64):
     capi.set_lanes(lanes)
     env.reset(seed=1)
     env.batch.bench_rollout(30, 10, 0, mode, 100, None)
