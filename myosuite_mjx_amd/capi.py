@@ -41,7 +41,8 @@ def build_library(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= os.path.getmtime(SRC_PATH):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH, SRC_PATH]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
+           "-shared", "-fPIC", "-o", LIB_PATH, SRC_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -423,7 +423,7 @@ __device__ __forceinline__ void make_frame(const float* n, float* t1, float* t2)
 
 // ------------------------------------------------------------------------------------------------
 // convex collision for ellipsoid pads: margin-inflated MPR (float twin of the oracle's mpr_penetration)
-struct CObj { const float *pos, *mat, *size; int type; float margin; };
+struct CObj { float pos[3], mat[9], size[3]; int type; float margin; };  // by value: keeps everything in registers
 __device__ void support_world(const CObj& o, const float* dir, float* out) {
   float dl[3], pl[3];
   matTvec(dl, o.mat, dir);
@@ -962,7 +962,12 @@ template <int G> __device__ int stage_collision(const DevModel& M, float* E, int
         // MPR in coordinates relative to geom1's centre (float resolution ~1e-9 m), converged tolerance
         const float zero3[3] = {0.f, 0.f, 0.f};
         float rel[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
-        CObj o1 = {zero3, R1, sz1, M.cg_type[g1], 0.5f * margin}, o2 = {rel, R2, sz2, M.cg_type[g2], 0.5f * margin};
+        CObj o1, o2;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { o1.pos[k] = zero3[k]; o2.pos[k] = rel[k]; o1.size[k] = sz1[k]; o2.size[k] = sz2[k]; }
+#pragma unroll
+        for (int k = 0; k < 9; k++) { o1.mat[k] = R1[k]; o2.mat[k] = R2[k]; }
+        o1.type = M.cg_type[g1]; o2.type = M.cg_type[g2]; o1.margin = o2.margin = 0.5f * margin;
         float depth, dir[3], pos[3];
         if (mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos)) {
           dist = margin - depth;
@@ -1502,9 +1507,13 @@ __device__ __forceinline__ float straight_w(const DevModel& M, const LayW& Y, fl
 }
 
 template <int NVT>
-__global__ void __launch_bounds__(64, 4) step_kernel_w(DevModel M, DevModelW W, DevBatch Bt, const float* __restrict__ action, int actmap, int nsub,
-                                                        long long* stamps) {
+__global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restrict__ Mp, const DevModelW* __restrict__ Wp, DevBatch Bt,
+                                                        const float* __restrict__ action, int actmap, int nsub, long long* stamps) {
   extern __shared__ __align__(16) float E[];
+  // the model structs stay in (scalar-cached) global memory: fields are s_load-ed where they are used instead of
+  // pinning ~150 SGPRs for the whole kernel
+  const DevModel& M = *Mp;
+  const DevModelW& W = *Wp;
   const LayW& Y = W.lay;
   const int lane = threadIdx.x;
   const int env = blockIdx.x;
@@ -1872,10 +1881,12 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(DevModel M, DevModelW W, 
             }
           } else {
             const float zero3[3] = {0.f, 0.f, 0.f};
-            float rel[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]}, R1[9], R2[9];
-            geom_world_mat(M, Y, E, g1, R1);
-            geom_world_mat(M, Y, E, g2, R2);
-            CObj o1 = {zero3, R1, sz1, M.cg_type[g1], 0.5f * margin}, o2 = {rel, R2, sz2, M.cg_type[g2], 0.5f * margin};
+            CObj o1, o2;
+            geom_world_mat(M, Y, E, g1, o1.mat);
+            geom_world_mat(M, Y, E, g2, o2.mat);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { o1.pos[k] = zero3[k]; o2.pos[k] = x2[k] - x1[k]; o1.size[k] = sz1[k]; o2.size[k] = sz2[k]; }
+            o1.type = M.cg_type[g1]; o2.type = M.cg_type[g2]; o1.margin = o2.margin = 0.5f * margin;
             float depth, dir[3], pos[3];
             if (mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos)) {
               dist = margin - depth;
@@ -2298,6 +2309,8 @@ struct myo_model {
   int device = 0;
   DevModel dm{};
   DevModelW dw{};
+  DevModel* d_dm = nullptr;     // device copies of the model structs for the wave kernel
+  DevModelW* d_dw = nullptr;
   int env_lds_bytes_w = 0;
   bool wave_ok = false;
   myo_dims dims{};
@@ -2482,6 +2495,11 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
     m->wave_ok = d.nv <= 24 && d.nu <= 64 && d.ngt <= 64 && d.nl <= 64 && d.ncg <= 64;
     build_layout_w(d, w, 24);
     m->env_lds_bytes_w = w.lay.total * 4;
+    void* p1 = nullptr; void* p2 = nullptr;
+    if (hipMalloc(&p1, sizeof(DevModel)) != hipSuccess || hipMalloc(&p2, sizeof(DevModelW)) != hipSuccess) { myo_model_free(m); return fail(MYO_E_NOMEM, "hipMalloc model structs"); }
+    m->dev_allocs.push_back(p1); m->dev_allocs.push_back(p2);
+    m->d_dm = (DevModel*)p1; m->d_dw = (DevModelW*)p2;
+    if (hipMemcpy(p1, &d, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(p2, &w, sizeof(DevModelW), hipMemcpyHostToDevice) != hipSuccess) { myo_model_free(m); return fail(MYO_E_HIP, "upload model structs"); }
   }
   m->dims = myo_dims{S[0], S[1], S[2], S[3], S[4], S[8], S[7], d.nl, 0, m->env_lds_bytes, 64, NCON, d.timestep};
   if (4 * m->env_lds_bytes > 160 * 1024) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "model working set exceeds 160 KB of LDS per workgroup"); }
@@ -2504,6 +2522,7 @@ int myo_model_dims(const myo_model* m, myo_dims* out) {
 int myo_model_set_switch(myo_model* m, int dc, int dl, int de) {
   if (!m) return fail(MYO_E_ARG, "null model");
   m->dm.disable_contact = dc; m->dm.disable_limit = dl; m->dm.disable_ellipsoid = de;
+  if (m->d_dm) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipMemcpy(m->d_dm, &m->dm, sizeof(DevModel), hipMemcpyHostToDevice)); }
   return MYO_OK;
 }
 
@@ -2697,7 +2716,8 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
   if (G == 64 && m->wave_ok) {
     static bool attr_w = false;
     if (!attr_w) { HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr_w = true; }
-    hipLaunchKernelGGL(step_kernel_w<24>, dim3(b->db.B), dim3(64), (size_t)m->env_lds_bytes_w, s, m->dm, m->dw, b->db, action, actmap, nsub, st);
+    hipLaunchKernelGGL(step_kernel_w<24>, dim3(b->db.B), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm, (const DevModelW*)m->d_dw, b->db, action,
+                       actmap, nsub, st);
     HIPCHK(hipGetLastError());
     return MYO_OK;
   }
