@@ -443,12 +443,12 @@ __device__ void support_world(const CObj& o, const float* dir, float* out) {
   float sc = n > MINVALF ? o.margin / n : 0.f;
   out[0] += o.pos[0] + dir[0] * sc; out[1] += o.pos[1] + dir[1] * sc; out[2] += o.pos[2] + dir[2] * sc;
 }
-struct Sup { float v[3], v1[3], v2[3]; };
+struct Sup { float v[3], v1[3]; };  // Minkowski point and its witness on obj1 (the witness on obj2 is v1 - v)
 __device__ void mink_support(const CObj& a, const CObj& b, const float* dir, Sup& s) {
-  float nd[3] = {-dir[0], -dir[1], -dir[2]};
+  float nd[3] = {-dir[0], -dir[1], -dir[2]}, w2[3];
   support_world(a, dir, s.v1);
-  support_world(b, nd, s.v2);
-  s.v[0] = s.v1[0] - s.v2[0]; s.v[1] = s.v1[1] - s.v2[1]; s.v[2] = s.v1[2] - s.v2[2];
+  support_world(b, nd, w2);
+  s.v[0] = s.v1[0] - w2[0]; s.v[1] = s.v1[1] - w2[1]; s.v[2] = s.v1[2] - w2[2];
 }
 __device__ __forceinline__ void portal_dir(const Sup* p, float* dir) {
   float a[3] = {p[2].v[0] - p[1].v[0], p[2].v[1] - p[1].v[1], p[2].v[2] - p[1].v[2]};
@@ -466,7 +466,7 @@ __device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int m
   Sup p[4];
   float dir[3], va[3], vb[3];
 #pragma unroll
-  for (int k = 0; k < 3; k++) { p[0].v1[k] = o1.pos[k]; p[0].v2[k] = o2.pos[k]; p[0].v[k] = o1.pos[k] - o2.pos[k]; }
+  for (int k = 0; k < 3; k++) { p[0].v1[k] = o1.pos[k]; p[0].v[k] = o1.pos[k] - o2.pos[k]; }
   if (norm3(p[0].v) < MINVALF) p[0].v[0] += 1e-5f;
   dir[0] = -p[0].v[0]; dir[1] = -p[0].v[1]; dir[2] = -p[0].v[2];
   normalize3(dir);
@@ -476,7 +476,7 @@ __device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int m
   if (norm3(dir) < 1e-12f) {
     *depth = norm3(p[1].v);
 #pragma unroll
-    for (int k = 0; k < 3; k++) { dirout[k] = p[1].v[k]; posout[k] = 0.5f * (p[1].v1[k] + p[1].v2[k]); }
+    for (int k = 0; k < 3; k++) { dirout[k] = p[1].v[k]; posout[k] = p[1].v1[k] - 0.5f * p[1].v[k]; }
     normalize3(dirout);
     return true;
   }
@@ -545,8 +545,8 @@ __device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int m
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     dirout[k] = dir[k];
-    posout[k] = 0.5f * inv * (bw[0] * (p[0].v1[k] + p[0].v2[k]) + bw[1] * (p[1].v1[k] + p[1].v2[k]) +
-                              bw[2] * (p[2].v1[k] + p[2].v2[k]) + bw[3] * (p[3].v1[k] + p[3].v2[k]));
+    posout[k] = inv * (bw[0] * (p[0].v1[k] - 0.5f * p[0].v[k]) + bw[1] * (p[1].v1[k] - 0.5f * p[1].v[k]) +
+                       bw[2] * (p[2].v1[k] - 0.5f * p[2].v[k]) + bw[3] * (p[3].v1[k] - 0.5f * p[3].v[k]));
   }
   return true;
 }
@@ -1386,6 +1386,7 @@ struct LayW {
   int tJ, tlen, tforce, seglen, dlval;            // region X, tendon phase
   int cdof, cinert, crb, cvel, cacc, cfrc;        // region X, dynamics phase
   int gpos, gax, cand, cdist, cpos, cnrm, cpair, cJ, cdofs;  // region X, collision + solver phase
+  int Mp;                                                     // packed mass matrix, aliases gpos/gax/cand once the contact rows exist
   int total;
 };
 struct DevModelW {
@@ -1435,20 +1436,27 @@ template <int NVT> __device__ __forceinline__ float chol_solve_rows(const float 
     float yj = rdlane(y, j) * rdlane(invd, j);
     y = (lane == j) ? yj : (lane > j ? y - r[j] * yj : y);
   }
-  float c[NVT];
-#pragma unroll
-  for (int j = 0; j < NVT; j++) c[j] = T[j * (NVT + 1) + (lane < NVT ? lane : 0)];
+  const float* Tc = T + (lane < NVT ? lane : 0);
 #pragma unroll
   for (int j = NVT - 1; j >= 0; j--) {
     float xj = rdlane(y, j) * rdlane(invd, j);
-    y = (lane == j) ? xj : (lane < j ? y - c[j] * xj : y);
+    float cj = Tc[j * (NVT + 1)];
+    y = (lane == j) ? xj : (lane < j ? y - cj * xj : y);
   }
   return y;
 }
-template <int NVT> __device__ __forceinline__ float symv_rows(const float (&Mrow)[NVT], float x) {
+// y_lane = sum_k M[lane][k] x_k with M packed lower-triangular in LDS (rows beyond nv read as zero)
+template <int NVT> __device__ __forceinline__ float symv_lds(const float* Mp, float x, int lane, int nv) {
   float s = 0;
+  const int d = lane < nv ? lane : 0;
+  const int based = (d * (d + 1)) / 2;
 #pragma unroll
-  for (int j = 0; j < NVT; j++) s += Mrow[j] * rdlane(x, j);
+  for (int k = 0; k < NVT; k++) {
+    int kk = k < nv ? k : 0;
+    int adr = (kk <= d) ? based + kk : (kk * (kk + 1)) / 2 + d;
+    float mv = (k < nv && lane < nv) ? Mp[adr] : 0.f;
+    s += mv * rdlane(x, k);
+  }
   return s;
 }
 
@@ -1515,7 +1523,7 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
   const DevModel& M = *Mp;
   const DevModelW& W = *Wp;
   const LayW& Y = W.lay;
-  const int lane = threadIdx.x;
+  const int lane_id = threadIdx.x;
   const int env = blockIdx.x;
   const int nv = M.nv, nu = M.nu;
 #if MYO_STAMPS
@@ -1524,28 +1532,33 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
 #endif
   // ---- state: LDS copies of what other lanes gather; per-dof / per-actuator scalars stay in registers
   float warm = 0.f, qacc = 0.f, actdot = 0.f;
-  if (lane < nv) {
-    E[Y.qpos + lane] = Bt.qpos[(size_t)env * nv + lane];
-    E[Y.qvel + lane] = Bt.qvel[(size_t)env * nv + lane];
-    warm = Bt.warm[(size_t)env * nv + lane];
+  if (lane_id < nv) {
+    E[Y.qpos + lane_id] = Bt.qpos[(size_t)env * nv + lane_id];
+    E[Y.qvel + lane_id] = Bt.qvel[(size_t)env * nv + lane_id];
+    warm = Bt.warm[(size_t)env * nv + lane_id];
   }
-  if (lane < nu) {
-    E[Y.act + lane] = Bt.act[(size_t)env * nu + lane];
+  if (lane_id < nu) {
+    E[Y.act + lane_id] = Bt.act[(size_t)env * nu + lane_id];
     float c;
     if (action) {
-      c = action[(size_t)env * nu + lane];
+      c = action[(size_t)env * nu + lane_id];
       if (actmap == MYO_ACTMAP_MUSCLE_SIGMOID) c = 1.0f / (1.0f + expf(-5.0f * (c - 0.5f)));
-    } else c = Bt.ctrl[(size_t)env * nu + lane];
-    E[Y.ctrl + lane] = c;
+    } else c = Bt.ctrl[(size_t)env * nu + lane_id];
+    E[Y.ctrl + lane_id] = c;
   }
   float time = Bt.time[env];
   int flags = 0, d_nefc = 0, d_ncon = 0, d_iter = 0;
   bool alive = true;
   const float h = M.timestep;
   const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
-  const float damping = lane < nv ? M.dof_damping[lane] : 0.f;
+  const float damping = lane_id < nv ? M.dof_damping[lane_id] : 0.f;
   SYNC();
   for (int step = 0; step < nsub; step++) {
+    // compiler-only barrier: keeps the (substep-invariant) model-table loads inside the loop body instead of hoisting
+    // ~60 values per lane out of it and spilling them to scratch
+    asm volatile("" ::: "memory");
+    int lane;   // opaque per-iteration copy of the lane id: address arithmetic derived from it cannot be hoisted (and spilled)
+    asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane_id));
     {  // mj_checkPos / mj_checkVel
       bool bad = false;
       if (lane < nv) { float a = E[Y.qpos + lane], b = E[Y.qvel + lane]; bad = !(a == a) || fabsf(a) > MAXVALF || !(b == b) || fabsf(b) > MAXVALF; }
@@ -1978,9 +1991,14 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
     }
     int nefc = __popcll(__ballot(lsign != 0.f)) + 4 * ncon;
     SYNC();
-    float Mrow[NVT];   // row `lane` of the (full symmetric) mass matrix, kept in registers for the whole solver
+    // the mass matrix moves from the square buffer (about to be reused for the Hessian) to a packed copy that
+    // aliases the now dead broad-phase scratch
+    if (lane < nv) {
+      const int based = (lane * (lane + 1)) / 2;
 #pragma unroll
-    for (int k = 0; k < NVT; k++) Mrow[k] = (lane < nv) ? E[Y.sq + lane * (NVT + 1) + k] : 0.f;
+      for (int k = 0; k < NVT; k++) if (k <= lane) E[Y.Mp + based + k] = E[Y.sq + lane * (NVT + 1) + k];
+    }
+    const float* Mp = E + Y.Mp;
     SYNC();
     STAMP(5);
     // ---------------------------------------------------------------- solver: Newton iterations, then the Euler solve, sharing ONE
@@ -1990,7 +2008,7 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
     int phase = nefc > 0 ? 0 : 1, iters = 0;
     if (phase == 0) {  // start from the warm start (MuJoCo also tries qacc_smooth; the minimiser is the same)
       qacc = warm;
-      Ma = symv_rows<NVT>(Mrow, qacc);
+      Ma = symv_lds<NVT>(Mp, qacc, lane, nv);
       ljar = lsign * qacc - laref;
       if (lane < nv) E[Y.xv + lane] = qacc;
       SYNC();
@@ -2003,7 +2021,10 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
       }
     }
     bool first = true;
+    const int lane_s = lane;
     while (true) {
+      int lane;   // opaque copy again: keeps the 24 per-lane symv addresses from being hoisted out of the loop and spilled
+      asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane_s));
       float r[NVT], rhs;
       if (phase == 0) {
         // forces of the active rows, J^T f (LDS atomics), cost, gradient, Hessian blocks (LDS atomics)
@@ -2051,18 +2072,17 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
         cost = newcost;
         first = false;
       }
-      if (phase == 0) {
+      {
+        const int dd = lane < nv ? lane : 0;
+        const int based = (dd * (dd + 1)) / 2;
+        const float diag_add = phase == 2 ? h * damping : 0.f;
 #pragma unroll
-        for (int k = 0; k < NVT; k++) r[k] = (lane < nv) ? E[Y.sq + lane * (NVT + 1) + k] + Mrow[k] : (k == lane ? 1.f : 0.f);
-        rhs = -grad;
-      } else if (phase == 1) {
-#pragma unroll
-        for (int k = 0; k < NVT; k++) r[k] = (lane < nv) ? Mrow[k] : (k == lane ? 1.f : 0.f);
-        rhs = smooth;
-      } else {
-#pragma unroll
-        for (int k = 0; k < NVT; k++) r[k] = (lane < nv) ? Mrow[k] + (k == lane ? h * damping : 0.f) : (k == lane ? 1.f : 0.f);
-        rhs = smooth + qfc;
+        for (int k = 0; k < NVT; k++) {
+          float mv = (lane < nv && k <= lane) ? Mp[based + (k <= dd ? k : 0)] : 0.f;                 // lower row of M
+          float hv = (phase == 0 && lane < nv) ? E[Y.sq + lane * (NVT + 1) + k] : 0.f;              // J^T D J (active rows)
+          r[k] = (lane < nv) ? mv + hv + (k == lane ? diag_add : 0.f) : (k == lane ? 1.f : 0.f);
+        }
+        rhs = phase == 0 ? -grad : (phase == 1 ? smooth : smooth + qfc);
       }
       SYNC();
       float invd = chol_rows<NVT>(r, lane);
@@ -2076,7 +2096,7 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
       if (phase == 2) { qaccE = x; break; }
       // ---- Newton: exact line search along x
       float search = lane < nv ? x : 0.f;
-      float Mv = symv_rows<NVT>(Mrow, search);
+      float Mv = symv_lds<NVT>(Mp, search, lane, nv);
       ljv = lsign * search;
       if (lane < nv) E[Y.xv + lane] = search;
       SYNC();
@@ -2145,21 +2165,21 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
     STAMP(8);
   }
   if (!alive) {  // a bad env is reset like mj_resetData (mj_sim_scene.py:56-61)
-    if (lane < nv) { E[Y.qpos + lane] = M.qpos0[lane]; E[Y.qvel + lane] = 0; warm = 0; }
-    if (lane < nu) { E[Y.act + lane] = 0; E[Y.ctrl + lane] = 0; }
+    if (lane_id < nv) { E[Y.qpos + lane_id] = M.qpos0[lane_id]; E[Y.qvel + lane_id] = 0; warm = 0; }
+    if (lane_id < nu) { E[Y.act + lane_id] = 0; E[Y.ctrl + lane_id] = 0; }
     time = 0;
   }
-  if (lane < nv) {
-    Bt.qpos[(size_t)env * nv + lane] = E[Y.qpos + lane];
-    Bt.qvel[(size_t)env * nv + lane] = E[Y.qvel + lane];
-    Bt.warm[(size_t)env * nv + lane] = warm;
-    Bt.qacc[(size_t)env * nv + lane] = qacc;
+  if (lane_id < nv) {
+    Bt.qpos[(size_t)env * nv + lane_id] = E[Y.qpos + lane_id];
+    Bt.qvel[(size_t)env * nv + lane_id] = E[Y.qvel + lane_id];
+    Bt.warm[(size_t)env * nv + lane_id] = warm;
+    Bt.qacc[(size_t)env * nv + lane_id] = qacc;
   }
-  if (lane < nu) {
-    Bt.act[(size_t)env * nu + lane] = E[Y.act + lane];
-    Bt.ctrl[(size_t)env * nu + lane] = E[Y.ctrl + lane];
+  if (lane_id < nu) {
+    Bt.act[(size_t)env * nu + lane_id] = E[Y.act + lane_id];
+    Bt.ctrl[(size_t)env * nu + lane_id] = E[Y.ctrl + lane_id];
   }
-  if (lane == 0) {
+  if (lane_id == 0) {
     Bt.time[env] = time;
     Bt.elapsed[env] += 1;
     Bt.flags[env] |= flags;
@@ -2167,7 +2187,7 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
   }
 #if MYO_STAMPS
   STAMP(9);
-  if (stamps && lane == 0) for (int k = 0; k < 12; k++) stamps[(size_t)blockIdx.x * 12 + k] = st_acc[k];
+  if (stamps && lane_id == 0) for (int k = 0; k < 12; k++) stamps[(size_t)blockIdx.x * 12 + k] = st_acc[k];
 #endif
 }
 
@@ -2387,8 +2407,10 @@ static void build_layout_w(const DevModel& d, DevModelW& w, int nvt) {
   Y.cdof = take(6 * nv); Y.cinert = take(10 * nl); Y.crb = take(10 * nl); Y.cvel = take(6 * nl); Y.cacc = take(6 * nl); Y.cfrc = take(6 * nl);
   int endD = o;
   o = Y.X;
+  Y.Mp = o;
   Y.gpos = take(3 * d.ncg); Y.gax = take(3 * d.ncg);
-  Y.cand = take(NCAND); Y.cdist = take(NCONW); Y.cpos = take(3 * NCONW); Y.cnrm = take(3 * NCONW); Y.cpair = take(NCONW);
+  Y.cand = take(NCAND);
+  if (o - Y.Mp < (nvt * (nvt + 1)) / 2) o = Y.Mp + (nvt * (nvt + 1)) / 2; Y.cdist = take(NCONW); Y.cpos = take(3 * NCONW); Y.cnrm = take(3 * NCONW); Y.cpair = take(NCONW);
   Y.cJ = take(NCONW * 3 * KCMAX); Y.cdofs = take(NCONW * 2);   // 8 dof ids per contact, one byte each
   if (o < endT) o = endT;
   if (o < endD) o = endD;
