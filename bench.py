@@ -118,6 +118,16 @@ def main():
     k_steps = max(10, min(args.steps, 100))
     k_ms = env.batch.bench_rollout(k_steps, env.frame_skip, 0, 0, 0, stream) / k_steps
     flags = env.status()
+    # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process; the value is
+    # the committed rocprofv3 measurement of the same kernel / batch (profiles/, separate FETCH_SIZE / WRITE_SIZE passes)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_d_pmc_step_kernel_wave.json")) as f:
+            t = json.load(f)["traffic"]
+        if B == B_PER_GPU:
+            traffic = t["hbm_bytes_per_launch_raw"]
+    except Exception:
+        pass
     if rank == 0:
         value = world * B * args.steps / el
         achieved = B_ALG * B / (k_ms * 1e-3) / 1e9
@@ -128,10 +138,10 @@ def main():
             "config": {"workload": f"{ENV_ID}, {B} envs per GPU, frame_skip=10 (dt=0.002), U(-1,1) device-generated actions, "
                                    "obs+reward+TimeLimit(100)/done auto-reset inside the timed region"
                                    + (", RCCL obs all-gather per step" if world > 1 else ""),
-                       "global_batch": world * B, "parallelism": f"env-shard x{world}", "lanes_per_env": 16,
+                       "global_batch": world * B, "parallelism": f"env-shard x{world}", "lanes_per_env": 64,
                        "substeps_per_s": value * env.frame_skip},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "step_kernel<16>", "kernel_ms": k_ms, "alg_bytes_per_launch": B_ALG * B,
+                         "traffic": traffic, "kernel": "step_kernel_w<24>", "kernel_ms": k_ms, "alg_bytes_per_launch": B_ALG * B,
                          "note": "path is FP32-VALU/latency bound, not HBM bound (SURVEY.md 8d); fp32 view alongside",
                          "fp32": {"achieved_tflops_est": F_ALG_EST * B / (k_ms * 1e-3) / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
                                   "frac_est": F_ALG_EST * B / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "flop_per_env_step": "SURVEY 8d estimate"}},

@@ -1684,7 +1684,10 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
         qfa += E[Y.tJ + t * M.maxnnz + slot] * E[Y.tforce + t];
       }
     }
-    float tlen_out = lane < nu ? E[Y.tlen + lane] : 0.f, tforce_out = lane < nu ? E[Y.tforce + lane] : 0.f;
+    if (step == nsub - 1 && lane < nu) {   // diagnostics of the last substep
+      Bt.tenlen[(size_t)env * nu + lane] = E[Y.tlen + lane];
+      Bt.actforce[(size_t)env * nu + lane] = E[Y.tforce + lane];
+    }
     SYNC();  // region X changes owner: tendon scratch -> spatial dynamics
     STAMP(2);
     // ---------------------------------------------------------------- CRB + RNE (lane = link / dof)
@@ -1894,18 +1897,34 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
             }
           } else {
             const float zero3[3] = {0.f, 0.f, 0.f};
+            // MPR in geom1's own frame: obj1 needs no rotation / translation at all (identity frame), obj2 carries the
+            // relative pose R1^T R2, R1^T (x2 - x1); normal and position are rotated back afterwards
+            float R1[9];
+            geom_world_mat(M, Y, E, g1, R1);
             CObj o1, o2;
-            geom_world_mat(M, Y, E, g1, o1.mat);
-            geom_world_mat(M, Y, E, g2, o2.mat);
+            {
+              float R2[9], rel[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
+              geom_world_mat(M, Y, E, g2, R2);
 #pragma unroll
-            for (int k = 0; k < 3; k++) { o1.pos[k] = zero3[k]; o2.pos[k] = x2[k] - x1[k]; o1.size[k] = sz1[k]; o2.size[k] = sz2[k]; }
+              for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) o2.mat[3 * i + j] = R1[i] * R2[j] + R1[3 + i] * R2[3 + j] + R1[6 + i] * R2[6 + j];
+              matTvec(o2.pos, R1, rel);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) o1.mat[k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { o1.pos[k] = 0.f; o1.size[k] = sz1[k]; o2.size[k] = sz2[k]; }
             o1.type = M.cg_type[g1]; o2.type = M.cg_type[g2]; o1.margin = o2.margin = 0.5f * margin;
             float depth, dir[3], pos[3];
             if (mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos)) {
               dist = margin - depth;
               normalize3(dir);
+              float dw[3], pw[3];
+              matvec(dw, R1, dir);
+              matvec(pw, R1, pos);
 #pragma unroll
-              for (int k = 0; k < 3; k++) { cpos[k] = pos[k] + x1[k]; nrm[k] = dir[k]; }
+              for (int k = 0; k < 3; k++) { cpos[k] = pw[k] + x1[k]; nrm[k] = dw[k]; }
               hit = true;
             }
           }
@@ -2156,10 +2175,6 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
       if (lane < nu) E[Y.act + lane] += h * actdot;
       if (lane < nv) { float v = E[Y.qvel + lane] + h * qaccE; E[Y.qvel + lane] = v; E[Y.qpos + lane] += h * v; }
       time += h;
-    }
-    if (step == nsub - 1 && lane < nu) {   // diagnostics of the last substep
-      Bt.tenlen[(size_t)env * nu + lane] = tlen_out;
-      Bt.actforce[(size_t)env * nu + lane] = tforce_out;
     }
     SYNC();
     STAMP(8);
