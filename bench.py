@@ -89,14 +89,16 @@ def main():
     gathered = torch.empty((world * B, env.obs_dim), dtype=torch.float32, device=obs.device) if world > 1 else None
 
     def run(nsteps):
-        """nsteps batched env steps; returns HIP-event milliseconds of the step work on this rank."""
+        """nsteps batched env steps; returns (HIP-event ms of all step work, HIP-event ms inside the step kernel) on this rank."""
         if world == 1:
-            return env.batch.bench_rollout(nsteps, env.frame_skip, 0, mode, env.max_episode_steps, stream)
-        ms = 0.0
+            ms = env.batch.bench_rollout(nsteps, env.frame_skip, 0, mode, env.max_episode_steps, stream)
+            return ms, env.batch.last_kernel_ms()
+        ms = kms = 0.0
         for _ in range(nsteps):
             ms += env.batch.bench_rollout(1, env.frame_skip, 0, mode, env.max_episode_steps, stream)
+            kms += env.batch.last_kernel_ms()
             dist.all_gather_into_tensor(gathered, obs)     # cross-GPU observation gather (RCCL over xGMI)
-        return ms
+        return ms, kms
 
     run(args.warmup)
     torch.cuda.synchronize()
@@ -104,7 +106,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev_ms = run(args.steps)
+    ev_ms, kernel_ms_total = run(args.steps)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -114,9 +116,9 @@ def main():
         t = torch.tensor([el], device=obs.device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
-    # dominant kernel alone (fused step kernel, fixed actions): HIP events on the launch stream
-    k_steps = max(10, min(args.steps, 100))
-    k_ms = env.batch.bench_rollout(k_steps, env.frame_skip, 0, 0, 0, stream) / k_steps
+    # dominant kernel: average launch duration from HIP event pairs recorded around every step-kernel launch of the
+    # timed region, on the stream it is launched on
+    k_ms = kernel_ms_total / args.steps
     flags = env.status()
     # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process; the value is
     # the committed rocprofv3 measurement of the same kernel / batch (profiles/, separate FETCH_SIZE / WRITE_SIZE passes)

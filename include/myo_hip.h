@@ -125,6 +125,8 @@ int myo_status(myo_batch*, int32_t* host_flags);
 /* fill action[B][nu] with U(-1,1) from a counter-based generator (seed, step, global env id) */
 int myo_random_action(myo_batch*, float* action_dev, uint64_t seed, uint64_t step, int env_offset, void* stream);
 int myo_sync(void* stream);
+/* cost-sorted workgroup -> env placement for the wave-per-env kernel (default on; speed only, results unchanged) */
+int myo_set_balance(myo_batch*, int on);
 /* lanes cooperating on one env (16, 32 or 64; default 16 or $MYO_LANES) -- a tuning knob, results are identical up to float round-off */
 int myo_set_lanes(int lanes);
 /* diagnostic build (-DMYO_STAMPS=1) only: per-workgroup clock64 totals per kernel stage; returns 1 in the normal build */
@@ -134,6 +136,8 @@ int myo_read_stamps(myo_batch*, long long* host, int nwg);
  * stream; returns elapsed milliseconds in *ms_out.  mode bits select what runs inside the timed region. */
 enum { MYO_BENCH_OBS = 1, MYO_BENCH_FRESH_ACTIONS = 2, MYO_BENCH_AUTORESET = 4 };
 int myo_bench_rollout(myo_batch*, int steps, int nsubsteps, uint64_t seed, int mode, int max_episode_steps, void* stream, float* ms_out);
+/* HIP-event milliseconds spent inside the step-kernel launches of the last myo_bench_rollout (events recorded on its stream) */
+int myo_bench_last_kernel_ms(myo_batch*, float* ms_out);
 
 #ifdef __cplusplus
 }

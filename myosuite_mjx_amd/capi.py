@@ -79,10 +79,12 @@ def lib():
         L.myo_random_action.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
         L.myo_sync.argtypes = [C.c_void_p]
         L.myo_bench_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+        L.myo_bench_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.myo_obs_only.argtypes = [C.c_void_p, C.c_void_p]
         L.myo_autoreset.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
         L.myo_set_env_offset.argtypes = [C.c_void_p, C.c_int]
         L.myo_set_lanes.argtypes = [C.c_int]
+        L.myo_set_balance.argtypes = [C.c_void_p, C.c_int]
         L.myo_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
@@ -188,11 +190,19 @@ class HipBatch:
     def random_action(self, action_ptr, seed, step, env_offset=0, stream=None):
         _chk(lib().myo_random_action(self.h, action_ptr, seed, step, env_offset, stream))
 
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        _chk(lib().myo_bench_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
     def obs_only(self, stream=None):
         _chk(lib().myo_obs_only(self.h, stream))
 
     def autoreset(self, max_episode_steps, seed=0, stream=None):
         _chk(lib().myo_autoreset(self.h, max_episode_steps, seed, stream))
+
+    def set_balance(self, on):
+        _chk(lib().myo_set_balance(self.h, int(on)))
 
     def set_env_offset(self, off):
         _chk(lib().myo_set_env_offset(self.h, off))

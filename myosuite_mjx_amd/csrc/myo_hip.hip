@@ -1516,7 +1516,8 @@ __device__ __forceinline__ float straight_w(const DevModel& M, const LayW& Y, fl
 
 template <int NVT>
 __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restrict__ Mp, const DevModelW* __restrict__ Wp, DevBatch Bt,
-                                                        const float* __restrict__ action, int actmap, int nsub, long long* stamps) {
+                                                        const float* __restrict__ action, int actmap, int nsub, long long* stamps,
+                                                        const int* __restrict__ order) {
   extern __shared__ __align__(16) float E[];
   // the model structs stay in (scalar-cached) global memory: fields are s_load-ed where they are used instead of
   // pinning ~150 SGPRs for the whole kernel
@@ -1524,7 +1525,9 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
   const DevModelW& W = *Wp;
   const LayW& Y = W.lay;
   const int lane_id = threadIdx.x;
-  const int env = blockIdx.x;
+  // workgroup -> env map: a speed-only placement hint (envs sorted by last step's cost, see balance_kernel); results of an
+  // env never depend on which workgroup steps it
+  const int env = order ? order[blockIdx.x] : blockIdx.x;
   const int nv = M.nv, nu = M.nu;
 #if MYO_STAMPS
   long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1547,7 +1550,7 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
     E[Y.ctrl + lane_id] = c;
   }
   float time = Bt.time[env];
-  int flags = 0, d_nefc = 0, d_ncon = 0, d_iter = 0;
+  int flags = 0, d_nefc = 0, d_ncon = 0, d_iter = 0, d_cost = 0;
   bool alive = true;
   const float h = M.timestep;
   const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
@@ -2166,6 +2169,7 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
     }
     STAMP(7);
     d_nefc = nefc; d_ncon = ncon; d_iter = max(d_iter, iters);
+    d_cost += 40 + 3 * ncon + (iters + 1) * (24 + ncon);   // crude work estimate for the placement hint
     {  // mj_checkAcc
       bool bad = lane < nv && (!(qacc == qacc) || fabsf(qacc) > MAXVALF);
       if (__any(bad) && alive) { flags |= MYO_FLAG_BAD_QACC; alive = false; }
@@ -2199,9 +2203,12 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
     Bt.elapsed[env] += 1;
     Bt.flags[env] |= flags;
     Bt.diag[(size_t)env * 8 + 0] = d_nefc; Bt.diag[(size_t)env * 8 + 1] = d_ncon; Bt.diag[(size_t)env * 8 + 2] = d_iter;
+    Bt.diag[(size_t)env * 8 + 3] = d_cost;
   }
 #if MYO_STAMPS
   STAMP(9);
+  st_acc[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: wave/simd/cu/sh/se ids (placement census)
+  st_acc[11] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
   if (stamps && lane_id == 0) for (int k = 0; k < 12; k++) stamps[(size_t)blockIdx.x * 12 + k] = st_acc[k];
 #endif
 }
@@ -2214,6 +2221,36 @@ __device__ __host__ inline float u01(uint64_t seed, uint64_t a, uint64_t b) {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z = z ^ (z >> 31);
   return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// Placement hint for the wave-per-env kernel.  All B envs are co-resident (4 waves per SIMD), so a launch ends when the
+// slowest SIMD ends; envs differ ~2x in work (contacts, Newton iterations) and that work is strongly correlated from one
+// env step to the next.  Sort envs by last step's cost (counting sort, one workgroup) and deal them out so that the waves
+// that land on one SIMD come from different cost quartiles (snake order over `nslot` = B/4 slots).  Dispatch order is not
+// a contract: this only ever changes speed.
+__global__ void __launch_bounds__(1024) balance_kernel(const int* __restrict__ diag, int B, int* __restrict__ order, int nslot) {
+  __shared__ int hist[256], start[256];
+  __shared__ int cmax_s;
+  const int t = threadIdx.x;
+  if (t < 256) hist[t] = 0;
+  if (t == 0) cmax_s = 1;
+  __syncthreads();
+  int cm = 1;
+  for (int e = t; e < B; e += 1024) cm = max(cm, diag[(size_t)e * 8 + 3]);
+  atomicMax(&cmax_s, cm);
+  __syncthreads();
+  const int cmax = cmax_s;
+  for (int e = t; e < B; e += 1024) atomicAdd(&hist[255 - min(255, (int)(255LL * diag[(size_t)e * 8 + 3] / cmax))], 1);   // bucket 0 = heaviest
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int k = 0; k < 256; k++) { start[k] = acc; acc += hist[k]; } }
+  __syncthreads();
+  for (int e = t; e < B; e += 1024) {
+    int b = 255 - min(255, (int)(255LL * diag[(size_t)e * 8 + 3] / cmax));
+    int r = atomicAdd(&start[b], 1);                       // rank by descending cost (ties in arbitrary order)
+    int q = r / nslot, i = r - q * nslot;
+    int wg = q * nslot + ((q & 1) ? nslot - 1 - i : i);    // snake: slot i gets ranks i, 2*nslot-1-i, 2*nslot+i, ...
+    order[wg < B ? wg : r] = e;
+  }
 }
 
 __global__ void random_action_kernel(float* action, int B, int nu, uint64_t seed, uint64_t step, int env_offset) {
@@ -2365,6 +2402,10 @@ struct myo_batch {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint64_t bench_step = 0;
   long long* d_stamps = nullptr;
+  int* d_order = nullptr;
+  int balance = 1;
+  std::vector<hipEvent_t> kev;   // per-launch event pairs around the step kernel (bench only)
+  float last_kernel_ms = 0.f;
 };
 
 static const BlobRec* blob_find(const uint8_t* blob, const char* name) {
@@ -2588,6 +2629,7 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   BA(b->d_tlo, b->ntarget_alloc) BA(b->d_thi, b->ntarget_alloc) BA(b->d_init, nv) BA(b->d_jlo, nv) BA(b->d_jhi, nv)
   BA(b->d_action, (size_t)B * nu)
   BA(b->d_stamps, (size_t)B * 12 * 2)
+  BA(b->d_order, B)
 #undef BA
   if (const char* e = getenv("MYO_LANES")) { int g = atoi(e); if (g == 16 || g == 32 || g == 64) g_lanes = g; }
   HIPCHK(hipMemcpy(b->d_jlo, m->jnt_lo.data(), nv * 4, hipMemcpyHostToDevice));
@@ -2607,6 +2649,7 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
 
 void myo_batch_free(myo_batch* b) {
   if (!b) return;
+  for (hipEvent_t e : b->kev) (void)hipEventDestroy(e);
   for (void* p : b->dev_allocs) (void)hipFree(p);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
@@ -2753,8 +2796,14 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
   if (G == 64 && m->wave_ok) {
     static bool attr_w = false;
     if (!attr_w) { HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr_w = true; }
-    hipLaunchKernelGGL(step_kernel_w<24>, dim3(b->db.B), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm, (const DevModelW*)m->d_dw, b->db, action,
-                       actmap, nsub, st);
+    const int* order = nullptr;
+    int Bn = b->db.B;
+    if (b->balance && Bn >= 1024 && Bn % 4 == 0) {
+      hipLaunchKernelGGL(balance_kernel, dim3(1), dim3(1024), 0, s, (const int*)b->db.diag, Bn, b->d_order, Bn / 4);
+      order = b->d_order;
+    }
+    hipLaunchKernelGGL(step_kernel_w<24>, dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm, (const DevModelW*)m->d_dw, b->db, action,
+                       actmap, nsub, st, order);
     HIPCHK(hipGetLastError());
     return MYO_OK;
   }
@@ -2816,6 +2865,12 @@ int myo_random_action(myo_batch* b, float* action_dev, uint64_t seed, uint64_t s
   return MYO_OK;
 }
 
+int myo_set_balance(myo_batch* b, int on) {
+  if (!b) return fail(MYO_E_ARG, "null batch");
+  b->balance = on;
+  return MYO_OK;
+}
+
 int myo_set_lanes(int lanes) {
   if (lanes != 16 && lanes != 32 && lanes != 64) return fail(MYO_E_ARG, "lanes per env must be 16, 32 or 64");
   g_lanes = lanes;
@@ -2841,11 +2896,14 @@ int myo_bench_rollout(myo_batch* b, int steps, int nsubsteps, uint64_t seed, int
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (!(mode & MYO_BENCH_FRESH_ACTIONS)) { rc = myo_random_action(b, b->d_action, seed, b->bench_step, b->env_offset, stream); if (rc) return rc; }
+  while ((int)b->kev.size() < 2 * steps) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); b->kev.push_back(e); }
   HIPCHK(hipEventRecord(b->ev0, s));
   for (int i = 0; i < steps; i++) {
     if (mode & MYO_BENCH_FRESH_ACTIONS) { rc = myo_random_action(b, b->d_action, seed, b->bench_step++, b->env_offset, stream); if (rc) return rc; }
+    HIPCHK(hipEventRecord(b->kev[2 * i], s));       // brackets the dominant kernel (+ its tiny placement kernel) on its own stream
     rc = launch_step(b, b->d_action, MYO_ACTMAP_MUSCLE_SIGMOID, nsubsteps, s);
     if (rc) return rc;
+    HIPCHK(hipEventRecord(b->kev[2 * i + 1], s));
     if ((mode & MYO_BENCH_OBS) && b->task.task != MYO_TASK_NONE) { rc = launch_obs(b, s); if (rc) return rc; }
     if ((mode & MYO_BENCH_AUTORESET) && max_episode_steps > 0) {
       rc = myo_autoreset(b, max_episode_steps, seed, stream); if (rc) return rc;
@@ -2855,6 +2913,16 @@ int myo_bench_rollout(myo_batch* b, int steps, int nsubsteps, uint64_t seed, int
   HIPCHK(hipEventRecord(b->ev1, s));
   HIPCHK(hipEventSynchronize(b->ev1));
   HIPCHK(hipEventElapsedTime(ms_out, b->ev0, b->ev1));
+  float tot = 0.f;
+  for (int i = 0; i < steps; i++) { float t; HIPCHK(hipEventElapsedTime(&t, b->kev[2 * i], b->kev[2 * i + 1])); tot += t; }
+  b->last_kernel_ms = tot;
+  return MYO_OK;
+}
+
+/* total HIP-event milliseconds spent in the step kernel launches of the last myo_bench_rollout call */
+int myo_bench_last_kernel_ms(myo_batch* b, float* ms_out) {
+  if (!b || !ms_out) return fail(MYO_E_ARG, "null");
+  *ms_out = b->last_kernel_ms;
   return MYO_OK;
 }
 

@@ -10,14 +10,15 @@ B = int(os.environ.get("B", 4096))
 NAMES = ["load/check", "kinematics", "tendon+muscle", "dynamics(CRB/RNE)", "collision", "constraint rows", "chol+solve(qacc_smooth)", "newton", "euler", "store"]
 env = BatchedMyoEnv("myoHandPoseRandom-v0", num_envs=B, as_torch=False)
 mode = capi.BENCH_OBS | capi.BENCH_FRESH_ACTIONS | capi.BENCH_AUTORESET
-for lanes in (16, 64):
+for lanes, bal in ((64, 0), (64, 1)):
     capi.set_lanes(lanes)
+    env.batch.set_balance(bal)
     env.reset(seed=1)
     env.batch.bench_rollout(30, 10, 0, mode, 100, None)
     ms = env.batch.bench_rollout(10, 10, 0, 0, 0, None) / 10
     nwg = B // (64 // lanes)
     st, ok = capi.read_stamps(env.batch, nwg)
     tot = st.sum(1)
-    print(f"== lanes/env {lanes}: step kernel {ms:.3f} ms per env-step ({B/ms*1e3:,.0f} env-steps/s); per-WG total cycles mean {tot.mean():,.0f} max {tot.max():,.0f} (10 substeps)")
+    print(f"== lanes/env {lanes} balance {bal}: step kernel {ms:.3f} ms per env-step ({B/ms*1e3:,.0f} env-steps/s); per-WG total cycles mean {tot.mean():,.0f} max {tot.max():,.0f} (10 substeps)")
     for k, n in enumerate(NAMES):
         print(f"   {n:26s} {st[:,k].mean()/10:12,.0f} cycles/substep  {100*st[:,k].mean()/tot.mean():5.1f}%")
