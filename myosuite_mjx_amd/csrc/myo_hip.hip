@@ -36,6 +36,7 @@
 #define GEOM_SPHERE 2
 #define GEOM_CAPSULE 3
 #define GEOM_ELLIPSOID 4
+#define GEOM_CYLINDER 5
 
 // ------------------------------------------------------------------------------------------------
 // device-side model: sizes + device pointers + LDS layout; passed by value as a kernel argument
@@ -432,6 +433,10 @@ __device__ void support_world(const CObj& o, const float* dir, float* out) {
     float n = norm3(s);
     float inv = n > MINVALF ? 1.0f / n : 0.f;
     pl[0] = o.size[0] * s[0] * inv; pl[1] = o.size[1] * s[1] * inv; pl[2] = o.size[2] * s[2] * inv;
+  } else if (o.type == GEOM_CYLINDER) {
+    float n = sqrtf(dl[0] * dl[0] + dl[1] * dl[1]);
+    float inv = n > MINVALF ? o.size[0] / n : 0.f;
+    pl[0] = dl[0] * inv; pl[1] = dl[1] * inv; pl[2] = dl[2] >= 0 ? o.size[1] : -o.size[1];
   } else {  // sphere / capsule
     float n = norm3(dl);
     float inv = n > MINVALF ? o.size[0] / n : 0.f;
@@ -1387,13 +1392,15 @@ struct LayW {
   int cdof, cinert, crb, cvel, cacc, cfrc;        // region X, dynamics phase
   int gpos, gax, cand, cdist, cpos, cnrm, cpair, cJ, cdofs;  // region X, collision + solver phase
   int Mp;                                                     // packed mass matrix, aliases gpos/gax/cand once the contact rows exist
+  int tJp;                                                    // persistent sparse tendon rows (only for models with tendon limits)
   int total;
 };
 struct DevModelW {
   LayW lay;
   const int *seg_order, *seg_tendon, *gt_dl;
   const float* link_mat0;
-  int nwrapseg, ndl;
+  int nwrapseg, ndl, has_tl;
+  const float* tl;
 };
 
 __device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
@@ -1619,6 +1626,7 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
     }
     STAMP(1);
     // ---------------------------------------------------------------- tendons: lane = segment
+    float tlen_r = 0.f, tvel_r = 0.f;
     for (int base = 0; base < M.nseg; base += 64) {
       int idx = base + lane;
       if (idx < M.nseg) {
@@ -1667,13 +1675,16 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
       int e0 = W.gt_dl[2 * gt], en = W.gt_dl[2 * gt + 1];
       for (int e = e0; e < e0 + en; e++) Jrow[M.dl[3 * e + 2]] += E[Y.dlval + e];
       E[Y.tlen + gt] = L;
+      tlen_r = L;
+      float vel = 0;
+      for (int k = 0; k < M.maxnnz; k++) {
+        int d = M.gt_dofs[gt * M.maxnnz + k];
+        if (d >= 0) vel += Jrow[k] * E[Y.qvel + d];
+        if (W.has_tl) E[Y.tJp + gt * M.maxnnz + k] = Jrow[k];
+      }
+      tvel_r = vel;
       if (gt < nu) {
         const float* A = M.act + 16 * gt;
-        float vel = 0;
-        for (int k = 0; k < M.maxnnz; k++) {
-          int d = M.gt_dofs[gt * M.maxnnz + k];
-          if (d >= 0) vel += Jrow[k] * E[Y.qvel + d];
-        }
         float f;
         muscle(A, A[14] * L, A[14] * vel, E[Y.act + gt], E[Y.ctrl + gt], &f, &actdot);
         E[Y.tforce + gt] = f * A[14];
@@ -2012,6 +2023,58 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
       caref[2] = -B * (vn + cmu * vt2) + pos; caref[3] = -B * (vn - cmu * vt2) + pos;
     }
     int nefc = __popcll(__ballot(lsign != 0.f)) + 4 * ncon;
+    const int ncon_real = ncon;
+    if (W.has_tl) {
+      // an active tendon limit becomes a frictionless pseudo-contact: jacobian = +-(sparse tendon row), mu = 0 and D/4 on each
+      // of the four identical "pyramid" rows, which together act exactly like the single MuJoCo limit row
+      bool tact = false;
+      float t_aref = 0.f, t_D = 0.f, t_sign = 0.f;
+      if (lane < M.ngt && !M.disable_limit) {
+        const float* T = W.tl + 12 * lane;
+        if (T[0] != 0) {
+          float margin = T[3], dlo = tlen_r - T[1], dhi = T[2] - tlen_r, dist = 0;
+          if (dlo < margin && dlo <= dhi) { t_sign = 1; dist = dlo; }
+          else if (dhi < margin) { t_sign = -1; dist = dhi; }
+          if (t_sign != 0) {
+            float imp = impedance(T + 6, dist, margin), K, B;
+            float R = fmaxf(MINVALF, (1 - imp) / imp * T[11]);
+            kbi(T[4], T[5], T[7], M.timestep, &K, &B);
+            t_aref = -B * (t_sign * tvel_r) - K * imp * (dist - margin);
+            t_D = 1.0f / R;
+            tact = true;
+          }
+        }
+      }
+      unsigned long long bal = __ballot(tact);
+      int slot = ncon + __popcll(bal & ((1ull << lane) - 1ull));
+      if (tact && slot < NCONW) {
+        float* cJ = E + Y.cJ + slot * 3 * KCMAX;
+        unsigned int dpk0 = 0, dpk1 = 0;
+        int kc = 0;
+#pragma unroll
+        for (int k = 0; k < KCMAX; k++) {
+          int d = k < M.maxnnz ? M.gt_dofs[lane * M.maxnnz + k] : -1;
+          float jv = d >= 0 ? t_sign * E[Y.tJp + lane * M.maxnnz + k] : 0.f;
+          if (d >= 0) kc = k + 1; else d = 0;
+          cJ[k] = jv; cJ[KCMAX + k] = 0.f; cJ[2 * KCMAX + k] = 0.f;
+          if (k < 4) dpk0 |= (unsigned int)d << (8 * k); else dpk1 |= (unsigned int)d << (8 * (k - 4));
+        }
+        ((unsigned int*)(E + Y.cdofs))[2 * slot] = dpk0;
+        ((unsigned int*)(E + Y.cdofs))[2 * slot + 1] = dpk1;
+        E[Y.cdist + slot] = t_aref; E[Y.cpos + 3 * slot] = t_D; E[Y.cpos + 3 * slot + 1] = (float)kc;
+      }
+      int ntl = __popcll(bal);
+      int nt = min(ncon + ntl, NCONW);
+      if (ncon + ntl > NCONW) flags |= MYO_FLAG_CONTACT_OVERFLOW;
+      SYNC();
+      if (lane >= ncon && lane < nt) {
+        float a = E[Y.cdist + lane];
+        caref[0] = caref[1] = caref[2] = caref[3] = a;
+        cD = 0.25f * E[Y.cpos + 3 * lane]; cmu = 0.f; ckc = (int)E[Y.cpos + 3 * lane + 1];
+      }
+      nefc += nt - ncon;
+      ncon = nt;
+    }
     SYNC();
     // the mass matrix moves from the square buffer (about to be reused for the Hessian) to a packed copy that
     // aliases the now dead broad-phase scratch
@@ -2168,7 +2231,7 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
       for (int k = 0; k < 4; k++) cjar[k] += alpha * cjv[k];
     }
     STAMP(7);
-    d_nefc = nefc; d_ncon = ncon; d_iter = max(d_iter, iters);
+    d_nefc = nefc; d_ncon = ncon_real; d_iter = max(d_iter, iters);
     d_cost += 40 + 3 * ncon + (iters + 1) * (24 + ncon);   // crude work estimate for the placement hint
     {  // mj_checkAcc
       bool bad = lane < nv && (!(qacc == qacc) || fabsf(qacc) > MAXVALF);
@@ -2385,6 +2448,7 @@ struct myo_model {
   DevModelW* d_dw = nullptr;
   int env_lds_bytes_w = 0;
   bool wave_ok = false;
+  int has_tl = 0;
   myo_dims dims{};
   std::vector<void*> dev_allocs;
   std::vector<float> qpos0, jnt_lo, jnt_hi;
@@ -2456,6 +2520,7 @@ static void build_layout_w(const DevModel& d, DevModelW& w, int nvt) {
   Y.qpos = take(nv); Y.qvel = take(nv); Y.act = take(nu); Y.ctrl = take(nu);
   Y.lpos = take(3 * nl); Y.lmat = take(9 * nl); Y.axis = take(3 * nv); Y.anchor = take(3 * nv);
   Y.xv = take(nvt); Y.qfc = take(nvt); Y.sq = take(nvt * (nvt + 1));
+  Y.tJp = w.has_tl ? take(d.ngt * d.maxnnz) : 0;
   Y.X = o;
   Y.tJ = take(d.ngt * d.maxnnz); Y.tlen = take(d.ngt); Y.tforce = take(nu); Y.seglen = take(d.nseg); Y.dlval = take(w.ndl);
   int endT = o;
@@ -2570,6 +2635,13 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
         (rc = load_i(m, blob, "hip_nwrapseg", &tmpi, &nws))) { myo_model_free(m); return rc; }
     w.nwrapseg = nws[0];
     w.ndl = H[6];
+    {
+      std::vector<float> tlv;
+      if ((rc = load_f(m, blob, "hip_tl", &w.tl, &tlv))) { myo_model_free(m); return rc; }
+      w.has_tl = 0;
+      for (int t = 0; t < d.ngt; t++) if (tlv[12 * t] != 0) w.has_tl = 1;
+      m->has_tl = w.has_tl;
+    }
     m->wave_ok = d.nv <= 24 && d.nu <= 64 && d.ngt <= 64 && d.nl <= 64 && d.ncg <= 64;
     build_layout_w(d, w, 24);
     m->env_lds_bytes_w = w.lay.total * 4;
@@ -2793,6 +2865,7 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     attr_set = true;
   }
   long long* st = b->d_stamps;
+  if (m->has_tl && !(G == 64 && m->wave_ok)) return fail(MYO_E_UNSUPPORTED, "tendon limits are only implemented in the wave-per-env kernel (lanes = 64)");
   if (G == 64 && m->wave_ok) {
     static bool attr_w = false;
     if (!attr_w) { HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr_w = true; }

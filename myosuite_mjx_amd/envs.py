@@ -46,8 +46,8 @@ _REACH_SPAN = {"THtip": ((-0.020, -0.040, -0.040), (0.040, 0.020, 0.040)),
                "LFtip": ((-0.040, -0.020, -0.010), (0.040, 0.020, 0.010))}
 
 
-def _pose_spec(target_lo, target_hi, reset_type, target_type, pose_thd=0.7):
-    return dict(model="myohand_pose", task="pose", max_episode_steps=100, frame_skip=10, normalize_act=True,
+def _pose_spec(target_lo, target_hi, reset_type, target_type, pose_thd=0.7, model="myohand_pose"):
+    return dict(model=model, task="pose", max_episode_steps=100, frame_skip=10, normalize_act=True,
                 target_lo=np.asarray(target_lo, float), target_hi=np.asarray(target_hi, float),
                 reset_type=reset_type, target_type=target_type, pose_thd=pose_thd,
                 weights=dict(pose=1.0, bonus=4.0, act_reg=1.0, penalty=50.0))
@@ -72,12 +72,14 @@ REGISTRY = {
     "myoHandReachFixed-v0": _reach_spec(False, 0.044),
     "myoHandReachRandom-v0": _reach_spec(True, 0.034),
 }
+# myoFingerPose*-v0 (envs/myo/myobase/__init__.py:222-253): joints IFadb, IFmcp, IFpip, IFdip; defaults reset "init",
+# target "generate", pose_thd 0.35 (pose_v0.py:46-57)
+REGISTRY["myoFingerPoseFixed-v0"] = _pose_spec([0, 0, 0.75, 0.75], [0, 0, 0.75, 0.75], "init", "generate", 0.35, "myofinger_v0")
+REGISTRY["myoFingerPoseRandom-v0"] = _pose_spec([-0.2, -0.4, 0.1, 0.1], [0.2, 1.0, 1.0, 1.0], "init", "generate", 0.35, "myofinger_v0")
 for _k in range(10):
     REGISTRY[f"myoHandPose{_k}Fixed-v0"] = _pose_spec(ASL_QPOS[_k], ASL_QPOS[_k], "init", "fixed")
 # registered by the reference but not runnable on the HIP path yet (DESIGN.md "out of scope this round")
 UNSUPPORTED = {
-    "myoFingerPoseFixed-v0": "finger model needs tendon-limit rows and pulleys in the HIP kernel (oracle-only this round)",
-    "myoFingerPoseRandom-v0": "finger model needs tendon-limit rows and pulleys in the HIP kernel (oracle-only this round)",
     "myoLegWalk-v0": "leg model needs free/slide joints, equality rows and plane contacts in the HIP kernel",
 }
 

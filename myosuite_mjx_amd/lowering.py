@@ -281,11 +281,32 @@ def lower(cm):
         act[i] = [gp[0], gp[1], force, gp[4], gp[5], gp[6], gp[7], gp[8], lr[0], lr[1],
                   m.actuator_dynprm[i, 0], m.actuator_dynprm[i, 1], cr[0], cr[1], m.actuator_gear[i], 0.0]
     # ---- collision geoms + pair table
-    moving_links = nl > 0
+    # reach bound: every point of link l stays within reach[l] + |p - anchor_l| of the (static) anchor of its root link,
+    # where anchor_l is the link's first joint position; distances between consecutive anchors are pose invariant
+    def first_anchor(l):
+        return dof_pos[link_dofadr[l]]
+
+    def link_extra(l):   # several joints with different anchors on one link, and slide travel
+        a0 = first_anchor(l)
+        ex = 0.0
+        for d in range(link_dofadr[l], link_dofadr[l] + link_dofnum[l]):
+            ex += 2 * np.linalg.norm(dof_pos[d] - a0)
+            if dof_type[d] == JNT_SLIDE:
+                j = m.dof_jntid[d]
+                ex += max(abs(m.jnt_range[j, 0]), abs(m.jnt_range[j, 1])) if m.jnt_limited[j] else 1e9
+        return ex
+
+    link_mat0 = [quat2mat(q) for q in link_quat]
     reach = np.zeros(nl)
+    root_anchor = {}
     for l in range(nl):
-        jp = sum(np.linalg.norm(dof_pos[d]) for d in range(link_dofadr[l], link_dofadr[l] + link_dofnum[l]))
-        reach[l] = (reach[link_parent[l]] + np.linalg.norm(link_pos[l]) if link_parent[l] >= 0 else 0.0) + 2 * jp
+        par = link_parent[l]
+        if par < 0:
+            reach[l] = link_extra(l)
+            root_anchor[l] = link_pos[l] + link_mat0[l] @ first_anchor(l)
+        else:
+            a_in_parent = link_pos[l] + link_mat0[l] @ first_anchor(l)
+            reach[l] = reach[par] + np.linalg.norm(a_in_parent - first_anchor(par)) + link_extra(l)
     cg_ids = {}
     pairs_i, pairs_f, pair_dl = [], [], []
 
@@ -299,7 +320,7 @@ def lower(cm):
         root = l
         while link_parent[root] >= 0:
             root = link_parent[root]
-        return link_pos[root], reach[l] + np.linalg.norm(geom_lpos[g]) + m.geom_rbound[g]
+        return root_anchor[root], reach[l] + np.linalg.norm(geom_lpos[g] - first_anchor(l)) + m.geom_rbound[g]
 
     pruned = 0
     for g1, g2 in m.pair_geom:
@@ -317,7 +338,7 @@ def lower(cm):
                 pruned += 1
                 continue
             raise NotImplementedError(f"HIP path: cannot prune static geom {stat} against moving geom {mov}")
-        ok = (GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_SPHERE)
+        ok = (GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_SPHERE, GEOM_CYLINDER)
         if t1 not in ok or t2 not in ok:
             raise NotImplementedError(f"HIP path: geom pair types {t1},{t2}")
         lst = dof_list(geom_link[g1], geom_link[g2])

@@ -935,9 +935,77 @@ static void collision(const Model* m, Data* d) { /* mj_collision over the compil
                (t2 == GEOM_CAPSULE || t2 == GEOM_ELLIPSOID || t2 == GEOM_CYLINDER || t2 == GEOM_SPHERE)) {
       if (m->disable_ellipsoid) continue;
       hit = convex_pair(m, d, &c, margin, g1, g2);
-    } else if (t1 == GEOM_PLANE) {
-      if (m->disable_ellipsoid) continue;
-      hit = convex_pair(m, d, &c, margin, g1, g2);
+    } else if (t1 == GEOM_PLANE && (t2 == GEOM_SPHERE || t2 == GEOM_ELLIPSOID || t2 == GEOM_CYLINDER)) {
+      /* mjc_PlaneSphere / mjc_PlaneConvex (ellipsoid: deepest support point) / mjc_PlaneCylinder [3P] */
+      const real* R = d->geom_xmat + 9 * g1;
+      real nrm[3] = {R[2], R[5], R[8]};
+      const real* R2 = d->geom_xmat + 9 * g2;
+      const real* sz = m->geom_size + 3 * g2;
+      real cdist[4], cpt[12];
+      int nc = 0;
+      real vec0[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
+      real dist0 = dot3(vec0, nrm);
+      if (t2 == GEOM_SPHERE) {
+        real dist = dist0 - sz[0];
+        if (dist <= margin) { cdist[0] = dist; for (int k = 0; k < 3; k++) cpt[k] = x2[k] - nrm[k] * (sz[0] + (real)0.5 * dist); nc = 1; }
+      } else if (t2 == GEOM_ELLIPSOID) {
+        real nl[3], sp[3], pw[3];
+        matT_vec3(nl, R2, nrm);                           /* plane normal in the ellipsoid frame */
+        real sv[3] = {sz[0] * nl[0], sz[1] * nl[1], sz[2] * nl[2]};
+        real nn = norm3(sv);
+        for (int k = 0; k < 3; k++) sp[k] = nn > MINVAL ? -sz[k] * sv[k] / nn : 0;   /* support point along -normal */
+        mat_vec3(pw, R2, sp);
+        real dist = dist0 + dot3(pw, nrm);
+        if (dist <= margin) { cdist[0] = dist; for (int k = 0; k < 3; k++) cpt[k] = x2[k] + pw[k] - nrm[k] * (real)0.5 * dist; nc = 1; }
+      } else {
+        real axis[3] = {R2[2], R2[5], R2[8]};
+        real prjaxis = dot3(nrm, axis);
+        if (prjaxis > 0) { for (int k = 0; k < 3; k++) axis[k] = -axis[k]; prjaxis = -prjaxis; }
+        real vec[3];
+        for (int k = 0; k < 3; k++) vec[k] = axis[k] * prjaxis - nrm[k];
+        real len_sqr = dot3(vec, vec);
+        if (len_sqr >= MINVAL) { real sc = sz[0] / sqrt(len_sqr); for (int k = 0; k < 3; k++) vec[k] *= sc; }
+        else { vec[0] = R2[0] * sz[0]; vec[1] = R2[3] * sz[0]; vec[2] = R2[6] * sz[0]; }
+        real prjvec = dot3(vec, nrm);
+        for (int k = 0; k < 3; k++) axis[k] *= sz[1];
+        prjaxis *= sz[1];
+        if (dist0 + prjaxis + prjvec <= margin) {
+          cdist[0] = dist0 + prjaxis + prjvec;
+          for (int k = 0; k < 3; k++) cpt[k] = x2[k] + vec[k] + axis[k] - nrm[k] * cdist[0] * (real)0.5;
+          nc = 1;
+          if (dist0 - prjaxis + prjvec <= margin) {
+            cdist[nc] = dist0 - prjaxis + prjvec;
+            for (int k = 0; k < 3; k++) cpt[3 * nc + k] = x2[k] + vec[k] - axis[k] - nrm[k] * cdist[nc] * (real)0.5;
+            nc++;
+          }
+          real prjvec1 = -prjvec * (real)0.5;
+          if (dist0 + prjaxis + prjvec1 <= margin) {
+            real vec1[3];
+            cross3(vec1, vec, axis);
+            normalize3(vec1);
+            for (int k = 0; k < 3; k++) vec1[k] *= sz[0] * (real)0.8660254037844386;
+            for (int sgn = 1; sgn >= -1; sgn -= 2) {
+              cdist[nc] = dist0 + prjaxis + prjvec1;
+              for (int k = 0; k < 3; k++) cpt[3 * nc + k] = x2[k] + sgn * vec1[k] + axis[k] - vec[k] * (real)0.5 - nrm[k] * cdist[nc] * (real)0.5;
+              nc++;
+            }
+          }
+        }
+      }
+      for (int q = 0; q < nc; q++) {
+        if (d->ncon >= NCON_MAX) { d->ncon_dropped++; continue; }
+        Contact* cc = &d->con[d->ncon];
+        memset(cc, 0, sizeof *cc);
+        cc->dist = cdist[q];
+        memcpy(cc->pos, cpt + 3 * q, 3 * sizeof(real));
+        memcpy(cc->frame, nrm, sizeof nrm);
+        make_frame(cc->frame);
+        contact_params(m, cc, g1, g2);
+        cc->includemargin = margin - gap;
+        cc->geom1 = g1; cc->geom2 = g2;
+        d->ncon++;
+      }
+      continue;
     } else {
       continue;
     }

@@ -18,6 +18,12 @@ def hand():
 
 
 @pytest.fixture(scope="session")
+def finger():
+    from myosuite_mjx_amd import model as M
+    return M.load_asset("myofinger_v0")
+
+
+@pytest.fixture(scope="session")
 def oracle64(hand):
     from oracle.oracle import Oracle
     return Oracle(hand.blob())

@@ -66,7 +66,9 @@ def test_registry_matches_reference_specs():
     assert np.allclose(f["target_lo"], HAND_POSE_FIXED) and f["reset_type"] == "init"
     rr = REGISTRY["myoHandReachRandom-v0"]
     assert rr["far_th"] == 0.034 and np.allclose(rr["target_lo"][:3], [-0.185, -0.577, 1.455]) and np.allclose(rr["target_hi"][:3], [-0.125, -0.517, 1.535])
-    assert "myoLegWalk-v0" in UNSUPPORTED and "myoFingerPoseFixed-v0" in UNSUPPORTED
+    assert "myoLegWalk-v0" in UNSUPPORTED
+    ff = REGISTRY["myoFingerPoseFixed-v0"]                       # envs/myo/myobase/__init__.py:222-236
+    assert ff["model"] == "myofinger_v0" and ff["pose_thd"] == 0.35 and ff["target_lo"].tolist() == [0, 0, 0.75, 0.75]
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/myosuite"), reason="reference tree not present")

@@ -139,3 +139,73 @@ def test_bad_state_is_reset_not_propagated(hand, hipmodel):
     assert np.allclose(q[1], hand.qpos0) and np.allclose(q[6], hand.qpos0) and np.isfinite(q).all()
     keep = [0, 2, 3, 4, 5, 7]
     assert np.array_equal(q[keep], ref.read(capi.F_QPOS)[keep])
+
+
+# ------------------------------------------------------------------------------------------------ MyoFinger (BASELINE config 0)
+def _finger_pair(finger, blob_bytes, qpos, qvel, act, ctrl, nsub):
+    from myosuite_mjx_amd import capi
+    from oracle.oracle import Oracle
+    hm = capi.HipModel(blob_bytes, 0)
+    o = Oracle(blob_bytes)
+    N = qpos.shape[0]
+    b = capi.HipBatch(hm, N)
+    for f, a in ((capi.F_QPOS, qpos), (capi.F_QVEL, qvel), (capi.F_ACT, act), (capi.F_CTRL, ctrl)):
+        b.write(f, a)
+    b.step(None, capi.ACTMAP_NONE, nsub)
+    gq, gv, ga, dg, fl = b.read(capi.F_QPOS), b.read(capi.F_QVEL), b.read(capi.F_ACT), b.read(capi.F_DIAG), b.status()
+    rq, rv, ra, ne = np.zeros_like(gq, dtype=float), np.zeros_like(gv, dtype=float), np.zeros_like(ga, dtype=float), np.zeros(N, int)
+    for e in range(N):
+        o.reset()
+        o.set_state(qpos=qpos[e], qvel=qvel[e], act=act[e], ctrl=ctrl[e])
+        o.step(nsub)
+        rq[e], rv[e], ra[e], ne[e] = o.field("qpos"), o.field("qvel"), o.field("act"), o.nefc
+    return (gq, gv, ga, dg, fl), (rq, rv, ra, ne)
+
+
+def _finger_states(finger, N, seed, beyond=0.0):
+    rng = np.random.default_rng(seed)
+    lo, hi = finger.jnt_range[:, 0], finger.jnt_range[:, 1]
+    f32 = np.float32
+    return (rng.uniform(lo - beyond, hi + beyond, (N, 4)).astype(f32), rng.normal(0, 1.0, (N, 4)).astype(f32),
+            rng.uniform(0, 1, (N, 5)).astype(f32), rng.uniform(0, 1, (N, 5)).astype(f32))
+
+
+@pytest.mark.parametrize("nsub", [1, 10])
+def test_finger_parity(finger, nsub):
+    """pulleys, sphere / cylinder wraps without side sites, compiler-derived muscle force, joint limits, convex pairs."""
+    g, r = _finger_pair(finger, finger.blob(), *_finger_states(finger, 128, 20, beyond=0.1), nsub)
+    assert (g[4] == 0).all() and r[3].max() >= 1
+    # finger muscles are ~5 kN (scale 10000 / acc0) on 0.05-0.18 kg links: stiffer than the hand, hence 1e-4 / 2e-2 at 10 substeps
+    assert np.abs(g[0] - r[0]).max() < (5e-6 if nsub == 1 else 1e-4)
+    assert np.abs(g[1] - r[1]).max() < (2e-3 if nsub == 1 else 2e-2)
+    assert np.abs(g[2] - r[2]).max() < 1e-6
+
+
+def test_finger_tendon_limits_active(finger):
+    """The shipped ranges (0..0.33 m) never bind; tighten them so the tendon-limit rows (lower and upper) are exercised."""
+    from myosuite_mjx_amd import blob
+    A = {k: v.copy() for k, v in finger.arrays.items()}
+    L0 = A["tendon_length0"]
+    gt = A["hip_gt_tendon"]
+    A["tendon_range"][:, 0] = L0 - 0.004
+    A["tendon_range"][:, 1] = L0 + 0.004
+    A["hip_tl"][:, 1] = A["tendon_range"][gt, 0]
+    A["hip_tl"][:, 2] = A["tendon_range"][gt, 1]
+    g, r = _finger_pair(finger, blob.pack(A), *_finger_states(finger, 128, 21), 10)
+    assert (g[4] == 0).all()
+    assert (g[3][:, 0] == r[3]).mean() > 0.9 and r[3].max() >= 3          # same constraint count, tendon rows present
+    assert np.abs(g[0] - r[0]).max() < 1e-4 and np.abs(g[1] - r[1]).max() < 2e-2
+
+
+def test_finger_env_config0():
+    """BASELINE config 0 shape: myoFingerPoseFixed-v0, batch 1, 100-step episode with a = 0.01*U[0,1) (tests/test_envs.py:61-64)."""
+    import torch
+    import myosuite_mjx_amd as myo
+    env = myo.make("myoFingerPoseFixed-v0", num_envs=1, seed=1234)
+    obs = env.reset(seed=1234)
+    assert obs.shape == (1, 17)                                            # qpos 4, qvel 4, pose_err 4, act 5 (Appendix C)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for k in range(100):
+        obs, rwd, term, trunc, info = env.step(0.01 * torch.rand((1, 5), device="cuda", generator=g))
+        assert torch.isfinite(obs).all() and not term.any()
+    assert trunc.all() and (env.status() == 0).all()

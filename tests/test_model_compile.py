@@ -56,6 +56,25 @@ def test_asset_matches_fresh_compile(hand):
     assert fresh.names == hand.names
 
 
+def test_finger_sizes(finger):
+    # SURVEY.md Appendix A, column F (myofinger_v0.xml): degrees -> radians, pulleys, tendon limits, compiler-derived force
+    assert (finger.nq, finger.nv, finger.nu, finger.ntendon, finger.nsite) == (4, 4, 5, 5, 20)
+    assert np.allclose(np.degrees(finger.jnt_range), [[-25, 25], [-25, 60], [0, 60], [0, 60]])
+    assert (finger.tendon_limited == 1).all() and np.allclose(finger.tendon_range, [[0, 0.33]] * 5)
+    assert (finger.wrap_type == 2).sum() == 2                     # two pulleys (finger_v0.xml:80,85)
+    assert np.allclose(finger.jnt_solimp[:, :3], [0.95, 0.95, 0.1]) and np.allclose(finger.dof_damping, 0.5)
+    assert (finger.actuator_gainprm[:, 2] == -1).all() and (finger.actuator_acc0 > 0).all()   # force = scale / acc0
+    assert int(finger.hip_sizes[15]) == 7                         # the 7 plane pairs are provably out of reach
+
+
+@needs_reference
+def test_finger_asset_matches_fresh_compile(finger):
+    from myosuite_mjx_amd import model as M
+    fresh = M.from_mjcf(os.path.join(REFERENCE, "simhive/myo_sim/finger/myofinger_v0.xml"))
+    for k, v in fresh.arrays.items():
+        assert np.allclose(np.asarray(v, float), np.asarray(finger.arrays[k], float), rtol=0, atol=1e-12), k
+
+
 @needs_reference
 def test_unsupported_feature_raises(tmp_path):
     from myosuite_mjx_amd.mjcf import compile_mjcf
