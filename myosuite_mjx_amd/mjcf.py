@@ -410,7 +410,9 @@ class _Compiler:
                      pos=_floats(e.attrib.get("pos", "0 0 0"), 3), quat=self._orientation(e.attrib),
                      inertial=None, jnts=[], geoms=[], childclass=childclass)
         self.bodies.append(b)
-        for ch in e:
+        # MuJoCo numbers joints / dofs body by body: a body's own elements come before anything of its child bodies, wherever
+        # they appear in the text (myolegs.xml puts <freejoint> after the included child chains)
+        for ch in [c for c in e if c.tag != "body"] + [c for c in e if c.tag == "body"]:
             t = ch.tag
             if t == "inertial":
                 a = ch.attrib
@@ -421,7 +423,7 @@ class _Compiler:
                 elif "diaginertia" in a:
                     ine["diag"] = _floats(a["diaginertia"], 3)
                 else:
-                    raise ValueError("inertial needs fullinertia or diaginertia")
+                    ine["diag"] = np.zeros(3)      # mass only: a point mass (myotorsorigid_chain.xml head body)
                 b["inertial"] = ine
             elif t == "joint" or t == "freejoint":
                 at = self._attrs(ch, "joint", childclass) if t == "joint" else dict(ch.attrib, type="free")
@@ -827,6 +829,9 @@ class _Compiler:
         for i in keep:
             if self.geoms[i]["type"] == GEOM_MESH:
                 raise NotImplementedError("colliding mesh geoms")
+        # explicit pairs may name geoms that neither collide dynamically nor wrap: keep them too
+        pair_names = {pr[k] for pr in self.pairs for k in ("geom1", "geom2")}
+        keep = sorted(set(keep) | {i for i, g in enumerate(self.geoms) if g["name"] and g["name"] in pair_names})
         geoms = [self.geoms[i] for i in keep]
         names["geom"] = [g["name"] for g in geoms]
         ng = len(geoms)
@@ -922,9 +927,22 @@ class _Compiler:
                 if (min(b1, b2), max(b1, b2)) in excl:
                     continue
                 pairs.append((g1, g2))
-        if self.pairs:
-            raise NotImplementedError("explicit <contact><pair> (leg model) not yet supported")
+        # heightfield geoms: kept as geoms, but their pairs are dropped (myoLegWalk-v0 parks the terrain below the floor plane,
+        # envs/myo/myobase/walk_v0.py:257-261); recorded so that callers can see it
+        nhf = sum(1 for (a, b) in pairs if geoms[a]["type"] == GEOM_HFIELD or geoms[b]["type"] == GEOM_HFIELD)
+        pairs = [(a, b) for (a, b) in pairs if geoms[a]["type"] != GEOM_HFIELD and geoms[b]["type"] != GEOM_HFIELD]
+        A["dropped_hfield_pairs"] = np.array([nhf], np.int32)
+        # explicit <contact><pair>: bypass the contype / parent filters; condim etc. from the pair element
+        pair_condim = [-1] * len(pairs)          # -1: derive from the geoms (dynamic pair)
+        for pr in self.pairs:
+            g1, g2 = names["geom"].index(pr["geom1"]), names["geom"].index(pr["geom2"])
+            for k in pr:
+                if k not in ("geom1", "geom2", "condim", "name"):
+                    raise NotImplementedError(f"<pair {k}=...>")
+            pairs.append((g1, g2))
+            pair_condim.append(int(pr.get("condim", 3)))
         A["pair_geom"] = np.array(pairs, np.int32).reshape(-1, 2)
+        A["pair_condim"] = np.array(pair_condim, np.int32)
         # keyframes
         kq = []
         for k in self.keys:
@@ -933,6 +951,7 @@ class _Compiler:
                 q = _floats(k["qpos"], nq)
             kq.append(q)
         A["key_qpos"] = np.stack(kq) if kq else np.zeros((0, nq))
+        A["key_qvel"] = np.stack([_floats(k["qvel"], nv) if "qvel" in k else np.zeros(nv) for k in self.keys]) if kq else np.zeros((0, nv))
         # options
         o = self.opt
         if o["cone"] != "pyramidal" or o["solver"] != "Newton" or o["integrator"] != "Euler":
@@ -942,8 +961,25 @@ class _Compiler:
                              0.0])  # last slot: stat.meaninertia, filled by setconst
         A["sizes"] = np.array([nq, nv, nu, nu, nb, njnt, ng, len(self.sites), nt, len(wtype), len(pairs), nM,
                                len(self.equalities)], np.int32)
-        if self.equalities:
-            raise NotImplementedError("equality constraints (leg model) not yet supported")
+        # equality constraints: joint couplings q1 - q1_0 = poly(q2 - q2_0)
+        eq_j1, eq_j2, eq_data, eq_solref, eq_solimp = [], [], [], [], []
+        for tag, at in self.equalities:
+            if tag != "joint":
+                raise NotImplementedError(f"equality <{tag}>")
+            if at.get("active", "true") != "true":
+                continue
+            eq_j1.append(names["joint"].index(at["joint1"]))
+            eq_j2.append(names["joint"].index(at["joint2"]) if "joint2" in at else -1)
+            eq_data.append(_pad(_floats(at.get("polycoef", "0 1 0 0 0")), [0, 1, 0, 0, 0]))
+            eq_solref.append(_floats(at.get("solref", "0.02 1"), 2))
+            eq_solimp.append(_solimp(at.get("solimp")))
+        ne = len(eq_j1)
+        A["eq_obj1id"] = np.array(eq_j1, np.int32)
+        A["eq_obj2id"] = np.array(eq_j2, np.int32)
+        A["eq_data"] = np.stack(eq_data) if ne else np.zeros((0, 5))
+        A["eq_solref"] = np.stack(eq_solref) if ne else np.zeros((0, 2))
+        A["eq_solimp"] = np.stack(eq_solimp) if ne else np.zeros((0, 5))
+        A["sizes"][12] = ne
         cm = CompiledModel(arrays=A, names=names, source=self.path)
         return cm
 

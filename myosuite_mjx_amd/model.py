@@ -83,11 +83,14 @@ def from_mjcf(path) -> Model:
     from .lowering import lower
     cm = compile_mjcf(path)
     set_constants(cm)
-    lower(cm)
+    try:
+        lower(cm)
+    except NotImplementedError as e:     # model is oracle-only for now: myo_model_load will refuse it (no hip_* tables)
+        cm.arrays["hip_unsupported"] = np.frombuffer(str(e).encode()[:200].ljust(4, b" "), dtype=np.uint8).astype(np.int32)
     return Model(cm.arrays, cm.names, path)
 
 
-_ASSETS = {"myohand_pose": "myohand_pose", "myofinger_v0": "myofinger_v0"}
+_ASSETS = {"myohand_pose": "myohand_pose", "myofinger_v0": "myofinger_v0", "myolegs": "myolegs"}
 
 
 def load_asset(name) -> Model:

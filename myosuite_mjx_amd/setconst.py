@@ -55,7 +55,7 @@ def forward_kinematics(m, qpos):
     return xpos, xquat, xanchor, xaxis
 
 
-def jac_point(m, xanchor, xaxis, body, point):
+def jac_point(m, xanchor, xaxis, body, point, xquat=None):
     """3 x nv translational and rotational Jacobians of a world point fixed to `body`."""
     nv = len(m.dof_bodyid)
     jp, jr = np.zeros((3, nv)), np.zeros((3, nv))
@@ -71,8 +71,11 @@ def jac_point(m, xanchor, xaxis, body, point):
                 jp[:, d] = xaxis[j]
             elif t == JNT_FREE:
                 jp[:, d:d + 3] = np.eye(3)
-                # rotational dofs of a free joint are expressed in the body frame
-                raise NotImplementedError("free joint jacobian (leg model) in setconst")
+                # rotational dofs of a free joint are expressed in the body frame (MuJoCo convention)
+                R = quat2mat(xquat[b])
+                for k in range(3):
+                    jr[:, d + 3 + k] = R[:, k]
+                    jp[:, d + 3 + k] = np.cross(R[:, k], point - xanchor[j])
         b = m.body_parentid[b]
     return jp, jr
 
@@ -89,7 +92,7 @@ def mass_matrix(m, qpos):
         c = xpos[b] + R @ m.body_ipos[b]
         Ri = R @ quat2mat(m.body_iquat[b])
         I = Ri @ np.diag(m.body_inertia[b]) @ Ri.T
-        jp, jr = jac_point(m, xanchor, xaxis, b, c)
+        jp, jr = jac_point(m, xanchor, xaxis, b, c, xquat)
         M += m.body_mass[b] * jp.T @ jp + jr.T @ I @ jr
     return M
 
@@ -287,8 +290,8 @@ def tendons(m, qpos, want_jac=True):
                 L[t] += dist / div
                 if want_jac and ba != bb and dist > mjMINVAL:
                     dif /= dist
-                    ja, _ = jac_point(m, xanchor, xaxis, ba, pa)
-                    jb, _ = jac_point(m, xanchor, xaxis, bb, pb)
+                    ja, _ = jac_point(m, xanchor, xaxis, ba, pa, xquat)
+                    jb, _ = jac_point(m, xanchor, xaxis, bb, pb, xquat)
                     J[t] += (dif @ (jb - ja)) / div
     return L, J
 
@@ -300,7 +303,13 @@ def set_constants(m, lengthrange_grid=5):
     M = mass_matrix(m, m.qpos0)
     Minv = np.linalg.inv(M)
     A["opt"][9] = float(np.mean(np.diag(M)))
-    A["dof_invweight0"] = np.diag(Minv).copy()
+    diw = np.diag(Minv).copy()
+    for j in range(len(m.jnt_type)):          # free joints: average over the 3 translational and the 3 rotational dofs
+        if m.jnt_type[j] == JNT_FREE:
+            d = m.jnt_dofadr[j]
+            diw[d:d + 3] = diw[d:d + 3].mean()
+            diw[d + 3:d + 6] = diw[d + 3:d + 6].mean()
+    A["dof_invweight0"] = diw
     xpos, xquat, xanchor, xaxis = forward_kinematics(m, m.qpos0)
     nb = len(m.body_parentid)
     biw = np.zeros((nb, 2))
@@ -308,7 +317,7 @@ def set_constants(m, lengthrange_grid=5):
         if m.body_weldid[b] == 0:
             continue
         c = xpos[b] + quat2mat(xquat[b]) @ m.body_ipos[b]
-        jp, jr = jac_point(m, xanchor, xaxis, b, c)
+        jp, jr = jac_point(m, xanchor, xaxis, b, c, xquat)
         biw[b, 0] = np.trace(jp @ Minv @ jp.T) / 3.0
         biw[b, 1] = np.trace(jr @ Minv @ jr.T) / 3.0
     A["body_invweight0"] = biw

@@ -69,7 +69,9 @@ typedef struct {
   int *actuator_trnid, *actuator_trntype, *actuator_ctrllimited, *actuator_forcelimited;
   real *actuator_gear, *actuator_dynprm, *actuator_gainprm, *actuator_biasprm, *actuator_ctrlrange,
       *actuator_forcerange, *actuator_lengthrange, *actuator_acc0;
-  int *pair_geom;
+  int *pair_geom, *pair_condim;
+  int neq, *eq_obj1id, *eq_obj2id;
+  real *eq_data, *eq_solref, *eq_solimp;
   int disable_contact, disable_limit, disable_ellipsoid; /* test switches */
   void* storage[256];
   int nstorage;
@@ -174,7 +176,9 @@ Model* myoo_load(const void* blobv, size_t nbytes) {
   LI(actuator_trnid); LI(actuator_trntype); LI(actuator_ctrllimited); LI(actuator_forcelimited);
   LF(actuator_gear); LF(actuator_dynprm); LF(actuator_gainprm); LF(actuator_biasprm); LF(actuator_ctrlrange);
   LF(actuator_forcerange); LF(actuator_lengthrange); LF(actuator_acc0);
-  LI(pair_geom);
+  LI(pair_geom); LI(pair_condim);
+  m->neq = sz[12];
+  LI(eq_obj1id); LI(eq_obj2id); LF(eq_data); LF(eq_solref); LF(eq_solimp);
 #undef LF
 #undef LI
   /* derived: subtree mass, last dof on the chain of each body */
@@ -272,7 +276,7 @@ Data* myoo_make_data(const Model* m) {
   AL(qfrc_bias, nv); AL(qfrc_passive, nv);
   AL(actuator_force, m->nu); AL(act_dot, m->na); AL(qfrc_actuator, nv); AL(qfrc_smooth, nv); AL(qacc_smooth, nv);
   AL(qfrc_constraint, nv); AL(qacc, nv);
-  d->nefc_max = 2 * m->njnt + 2 * m->ntendon + 6 * NCON_MAX;
+  d->nefc_max = m->neq + 2 * m->njnt + 2 * m->ntendon + 6 * NCON_MAX;
   int ne = d->nefc_max;
   d->efc_type = (int*)calloc(ne, sizeof(int)); d->efc_id = (int*)calloc(ne, sizeof(int));
   d->efc_state = (int*)calloc(ne, sizeof(int));
@@ -1013,6 +1017,7 @@ static void collision(const Model* m, Data* d) { /* mj_collision over the compil
     if (d->ncon >= NCON_MAX) { d->ncon_dropped++; continue; }
     make_frame(c.frame);
     contact_params(m, &c, g1, g2);
+    if (m->pair_condim[p] > 0) c.dim = m->pair_condim[p];   /* explicit <contact><pair condim=...> */
     c.includemargin = margin - gap;
     c.geom1 = g1; c.geom2 = g2;
     d->con[d->ncon++] = c;
@@ -1231,6 +1236,27 @@ static int add_row(Data* d, int nv, int type, int id, real pos, real margin, rea
 static void make_constraint(const Model* m, Data* d) { /* mj_makeConstraint: limits then contacts [3P] */
   int nv = m->nv;
   d->nefc = 0;
+  /* equality: joint couplings q1 - q1_0 = poly(q2 - q2_0) (mj_instantiateEquality, mjEQ_JOINT) [3P] */
+  for (int e = 0; e < m->neq; e++) {
+    int j1 = m->eq_obj1id[e], j2 = m->eq_obj2id[e];
+    const real* a = m->eq_data + 5 * e;
+    int q1 = m->jnt_qposadr[j1], d1 = m->jnt_dofadr[j1];
+    real pos = d->qpos[q1] - m->qpos0[q1], deriv = 0, diag = m->dof_invweight0[d1];
+    if (j2 >= 0) {
+      int q2 = m->jnt_qposadr[j2];
+      real x = d->qpos[q2] - m->qpos0[q2];
+      pos -= a[0] + x * (a[1] + x * (a[2] + x * (a[3] + x * a[4])));
+      deriv = a[1] + x * (2 * a[2] + x * (3 * a[3] + x * 4 * a[4]));
+      diag += m->dof_invweight0[m->jnt_dofadr[j2]];
+    } else {
+      pos -= a[0];
+    }
+    int r = add_row(d, nv, CT_EQUALITY, e, pos, 0, diag);
+    if (r >= 0) {
+      d->efc_J[(size_t)r * nv + d1] = 1;
+      if (j2 >= 0) d->efc_J[(size_t)r * nv + m->jnt_dofadr[j2]] = -deriv;
+    }
+  }
   if (!m->disable_limit) {
     for (int j = 0; j < m->njnt; j++) {
       if (!m->jnt_limited[j]) continue;
@@ -1290,6 +1316,7 @@ static void make_constraint(const Model* m, Data* d) { /* mj_makeConstraint: lim
 static void get_solparams(const Model* m, const Data* d, int i, const real** solref, const real** solimp) {
   int id = d->efc_id[i];
   switch (d->efc_type[i]) {
+    case CT_EQUALITY: *solref = m->eq_solref + 2 * id; *solimp = m->eq_solimp + 5 * id; break;
     case CT_LIMIT_JOINT: *solref = m->jnt_solref + 2 * id; *solimp = m->jnt_solimp + 5 * id; break;
     case CT_LIMIT_TENDON: *solref = m->tendon_solref + 2 * id; *solimp = m->tendon_solimp + 5 * id; break;
     default: *solref = d->con[id].solref; *solimp = d->con[id].solimp; break;

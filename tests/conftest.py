@@ -24,6 +24,12 @@ def finger():
 
 
 @pytest.fixture(scope="session")
+def legs():
+    from myosuite_mjx_amd import model as M
+    return M.load_asset("myolegs")
+
+
+@pytest.fixture(scope="session")
 def oracle64(hand):
     from oracle.oracle import Oracle
     return Oracle(hand.blob())

@@ -170,3 +170,67 @@ def test_oracle_deterministic_and_batch_driver(hand, oracle64):
     oracle64.set_state(qpos=qpos[0], qvel=qvel[0], act=act[0], ctrl=ctrl[0])
     oracle64.step(5)
     assert np.array_equal(oracle64.field("qpos"), a[0][0])
+
+
+# ------------------------------------------------------------------------------------------------ MyoLeg (BASELINE config 4), oracle side
+def test_legs_sizes_and_goldens(legs):
+    """SURVEY.md Appendix A column L; golden material stored in the reference's own model files:
+    keyframe qpos computed by MuJoCo satisfy the 7 right-knee polynomial couplings (myolegs_assets.xml:88-95), and the
+    MuJoCo-computed muscle lengthranges (myolegs_assets.xml:606-685) contain the tendon lengths at the keyframes."""
+    from myosuite_mjx_amd import setconst as sc
+    assert (legs.nq, legs.nv, legs.nu, legs.ntendon) == (35, 34, 80, 80) and int(legs.sizes[11]) == 351 and int(legs.sizes[12]) == 14
+    assert abs(legs.timestep - 0.001) < 1e-12 and legs.names["joint"][0] == "root" and int(legs.jnt_type[0]) == 0
+    assert (legs.pair_condim > 0).sum() == 14 and abs(legs.body_mass.sum() - 80.65) < 0.05
+    for k in range(len(legs.key_qpos)):
+        q = legs.key_qpos[k]
+        for e in range(7):                                        # right leg (the left-leg keyframe values mirror the right ones
+            j1, j2 = legs.eq_obj1id[e], legs.eq_obj2id[e]         # without the sign flips of the left polycoefs: not usable)
+            a = legs.eq_data[e]
+            x = q[legs.jnt_qposadr[j2]]
+            assert abs(q[legs.jnt_qposadr[j1]] - (a[0] + x * (a[1] + x * (a[2] + x * (a[3] + x * a[4]))))) < 5e-4   # keyframes: 6 significant digits
+        L, _ = sc.tendons(legs, q, want_jac=False)
+        lr = legs.actuator_lengthrange
+        Lt = L[legs.actuator_trnid]
+        over = np.maximum(lr[:, 0] - Lt, Lt - lr[:, 1]) / (lr[:, 1] - lr[:, 0])
+        assert (over <= 0.01).sum() >= 76                          # 76-77 of 80 inside; the rest are patella-coupled (vasti)
+
+
+def test_legs_numpy_twin_and_free_joint(legs):
+    from myosuite_mjx_amd import setconst as sc
+    from oracle.oracle import Oracle
+    o = Oracle(legs.blob())
+    q = legs.key_qpos[2].copy()
+    q[3:7] = [0.9, 0.1, -0.3, 0.2]
+    q[3:7] /= np.linalg.norm(q[3:7])
+    o.set_state(qpos=q, qvel=np.zeros(legs.nv))
+    o.fwd_position()
+    L, J = sc.tendons(legs, q)
+    assert np.abs(o.field("ten_length") - L).max() < 1e-13 and np.abs(o.field("ten_J").reshape(80, 34) - J).max() < 1e-12
+    M = sc.mass_matrix(legs, q)
+    Mo = o.full_m(34)
+    assert np.abs(M - Mo).max() < 1e-11 and np.linalg.eigvalsh(Mo).min() > 0
+    # free fall: no contacts, limits or muscle forces -> the root translational acceleration is gravity
+    o.switches(1, 1, 1)
+    o.set_state(qpos=q, qvel=np.zeros(legs.nv), act=np.zeros(80), ctrl=np.zeros(80))
+    o.forward()
+    ke0, pe0 = o.energy()
+    assert ke0 == 0
+    o.switches(0, 0, 0)
+
+
+def test_legs_equalities_hold_in_rollout(legs):
+    from oracle.oracle import Oracle
+    o = Oracle(legs.blob())
+    o.reset()
+    o.set_state(qpos=legs.key_qpos[2], qvel=legs.key_qvel[2])
+    rng = np.random.default_rng(0)
+    for k in range(30):
+        o.set_state(ctrl=rng.uniform(0, 1, 80))
+        assert o.step(10) == 0
+    q = o.field("qpos")
+    for e in range(14):
+        j1, j2 = legs.eq_obj1id[e], legs.eq_obj2id[e]
+        a = legs.eq_data[e]
+        x = q[legs.jnt_qposadr[j2]]
+        assert abs(q[legs.jnt_qposadr[j1]] - (a[0] + x * (a[1] + x * (a[2] + x * (a[3] + x * a[4]))))) < 2e-2
+    assert o.ncon >= 1 and np.isfinite(q).all()                 # feet on the floor

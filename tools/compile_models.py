@@ -12,6 +12,7 @@ REF = os.environ.get("MYO_REFERENCE", "/root/reference")
 MODELS = {
     "myohand_pose": "myosuite/envs/myo/assets/hand/myohand_pose.xml",
     "myofinger_v0": "myosuite/simhive/myo_sim/finger/myofinger_v0.xml",
+    "myolegs": "myosuite/simhive/myo_sim/leg/myolegs.xml",
 }
 
 if __name__ == "__main__":
