@@ -1401,6 +1401,9 @@ struct DevModelW {
   const float* link_mat0;
   int nwrapseg, ndl, has_tl;
   const float* tl;
+  int nq, has_free, neq;          // free-floating root (nq = nv + 1), joint-coupling equalities
+  const int *link_free, *dof_qposadr, *eq_i;
+  const float* eq_f;
 };
 
 __device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
@@ -1417,8 +1420,8 @@ __device__ __forceinline__ float wave_sum(float v) {
   return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
 }
 #define WFOR(i, n) for (int i = lane; i < (n); i += 64)
-// dof id k (0..7) of contact c from the byte-packed table
-#define CDOF(E_, Y_, c_, k_) ((int)((((const unsigned int*)((E_) + (Y_).cdofs))[2 * (c_) + ((k_) >> 2)] >> (8 * ((k_) & 3))) & 255u))
+// dof id k (0..KC-1) of contact c from the byte-packed table (CDW = ints per contact, a constexpr of the kernel)
+#define CDOF(E_, Y_, c_, k_) ((int)((((const unsigned int*)((E_) + (Y_).cdofs))[CDW * (c_) + ((k_) >> 2)] >> (8 * ((k_) & 3))) & 255u))
 
 // in: r[k] = H[lane][k] (k <= lane). out: r[k] = L[lane][k], returns 1/L[lane][lane].  All indices are compile-time.
 template <int NVT> __device__ __forceinline__ float chol_rows(float (&r)[NVT], int lane) {
@@ -1521,8 +1524,8 @@ __device__ __forceinline__ float straight_w(const DevModel& M, const LayW& Y, fl
   return active ? dist * invdiv : 0.f;
 }
 
-template <int NVT>
-__global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restrict__ Mp, const DevModelW* __restrict__ Wp, DevBatch Bt,
+template <int NVT, int KC, int NC, int NTR, int WPE>
+__global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restrict__ Mp, const DevModelW* __restrict__ Wp, DevBatch Bt,
                                                         const float* __restrict__ action, int actmap, int nsub, long long* stamps,
                                                         const int* __restrict__ order) {
   extern __shared__ __align__(16) float E[];
@@ -1535,26 +1538,34 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
   // workgroup -> env map: a speed-only placement hint (envs sorted by last step's cost, see balance_kernel); results of an
   // env never depend on which workgroup steps it
   const int env = order ? order[blockIdx.x] : blockIdx.x;
-  const int nv = M.nv, nu = M.nu;
+  const int nv = M.nv, nu = M.nu, nq = W.nq;
+  constexpr int CDW = (KC + 3) / 4;   // ints per contact holding its KC byte-packed dof ids
+  // the small instantiation (hand / finger class) is compiled without the free-joint, equality, plane-contact and condim-1 code;
+  // myo_model_load routes any model that needs one of those to the large instantiation
+  constexpr bool FULL = NVT > 24;
+  const bool has_free = FULL && W.has_free;
+  const int neq = FULL ? W.neq : 0;
 #if MYO_STAMPS
   long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long st_t0 = clock64();
 #endif
   // ---- state: LDS copies of what other lanes gather; per-dof / per-actuator scalars stay in registers
-  float warm = 0.f, qacc = 0.f, actdot = 0.f;
+  float warm = 0.f, qacc = 0.f, actdot[NTR];
+#pragma unroll
+  for (int r = 0; r < NTR; r++) actdot[r] = 0.f;
+  if (lane_id < nq) E[Y.qpos + lane_id] = Bt.qpos[(size_t)env * nq + lane_id];
   if (lane_id < nv) {
-    E[Y.qpos + lane_id] = Bt.qpos[(size_t)env * nv + lane_id];
     E[Y.qvel + lane_id] = Bt.qvel[(size_t)env * nv + lane_id];
     warm = Bt.warm[(size_t)env * nv + lane_id];
   }
-  if (lane_id < nu) {
-    E[Y.act + lane_id] = Bt.act[(size_t)env * nu + lane_id];
+  for (int i = lane_id; i < nu; i += 64) {
+    E[Y.act + i] = Bt.act[(size_t)env * nu + i];
     float c;
     if (action) {
-      c = action[(size_t)env * nu + lane_id];
+      c = action[(size_t)env * nu + i];
       if (actmap == MYO_ACTMAP_MUSCLE_SIGMOID) c = 1.0f / (1.0f + expf(-5.0f * (c - 0.5f)));
-    } else c = Bt.ctrl[(size_t)env * nu + lane_id];
-    E[Y.ctrl + lane_id] = c;
+    } else c = Bt.ctrl[(size_t)env * nu + i];
+    E[Y.ctrl + i] = c;
   }
   float time = Bt.time[env];
   int flags = 0, d_nefc = 0, d_ncon = 0, d_iter = 0, d_cost = 0;
@@ -1571,7 +1582,8 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
     asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane_id));
     {  // mj_checkPos / mj_checkVel
       bool bad = false;
-      if (lane < nv) { float a = E[Y.qpos + lane], b = E[Y.qvel + lane]; bad = !(a == a) || fabsf(a) > MAXVALF || !(b == b) || fabsf(b) > MAXVALF; }
+      if (lane < nq) { float a = E[Y.qpos + lane]; bad = !(a == a) || fabsf(a) > MAXVALF; }
+      if (lane < nv) { float b = E[Y.qvel + lane]; bad = bad || !(b == b) || fabsf(b) > MAXVALF; }
       if (__any(bad) && alive) { flags |= MYO_FLAG_BAD_STATE; alive = false; }
     }
     STAMP(0);
@@ -1593,6 +1605,24 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
           matmul3(R, E + Y.lmat + 9 * par, W.link_mat0 + 9 * l);
         }
         int da = M.link_dofadr[l], dn = M.link_dofnum[l];
+        if (has_free && W.link_free[l]) {
+          // free joint: pose straight from qpos (position + unit quaternion); its 3 translational dofs act like slides along
+          // the world axes and its 3 rotational dofs like hinges about the body axes through the body origin
+          int qa = W.dof_qposadr[da];
+          pos[0] = E[Y.qpos + qa]; pos[1] = E[Y.qpos + qa + 1]; pos[2] = E[Y.qpos + qa + 2];
+          float q[4] = {E[Y.qpos + qa + 3], E[Y.qpos + qa + 4], E[Y.qpos + qa + 5], E[Y.qpos + qa + 6]};
+          float qn = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+          q[0] *= qn; q[1] *= qn; q[2] *= qn; q[3] *= qn;
+          quat2mat(R, q);
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            E[Y.axis + 3 * (da + k)] = k == 0 ? 1.f : 0.f; E[Y.axis + 3 * (da + k) + 1] = k == 1 ? 1.f : 0.f; E[Y.axis + 3 * (da + k) + 2] = k == 2 ? 1.f : 0.f;
+            E[Y.axis + 3 * (da + 3 + k)] = R[k]; E[Y.axis + 3 * (da + 3 + k) + 1] = R[3 + k]; E[Y.axis + 3 * (da + 3 + k) + 2] = R[6 + k];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { E[Y.anchor + 3 * (da + k) + c] = pos[c]; E[Y.anchor + 3 * (da + 3 + k) + c] = pos[c]; }
+          }
+          dn = 0;
+        }
         for (int k = 0; k < dn; k++) {
           int d = da + k;
           const float* al = M.dof_axis + 3 * d;
@@ -1602,7 +1632,7 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
           an[0] += pos[0]; an[1] += pos[1]; an[2] += pos[2];
           E[Y.axis + 3 * d] = ax[0]; E[Y.axis + 3 * d + 1] = ax[1]; E[Y.axis + 3 * d + 2] = ax[2];
           E[Y.anchor + 3 * d] = an[0]; E[Y.anchor + 3 * d + 1] = an[1]; E[Y.anchor + 3 * d + 2] = an[2];
-          float ang = E[Y.qpos + d] - M.qpos0[d];
+          float ang = E[Y.qpos + W.dof_qposadr[d]] - M.qpos0[W.dof_qposadr[d]];
           if (M.dof_type[d] == 3) {
             float sn, cs;
             sincosf(ang, &sn, &cs);
@@ -1624,9 +1654,11 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
       }
       SYNC();
     }
+    // reference point of the spatial (6-D) quantities: fixed for fixed-base models, the root link's origin for free-floating ones
+    const float c0[3] = {has_free ? E[Y.lpos] : M.c0[0], has_free ? E[Y.lpos + 1] : M.c0[1], has_free ? E[Y.lpos + 2] : M.c0[2]};
     STAMP(1);
     // ---------------------------------------------------------------- tendons: lane = segment
-    float tlen_r = 0.f, tvel_r = 0.f;
+    float tlen_r[NTR], tvel_r[NTR];
     for (int base = 0; base < M.nseg; base += 64) {
       int idx = base + lane;
       if (idx < M.nseg) {
@@ -1666,8 +1698,11 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
       }
     }
     SYNC();
-    if (lane < M.ngt) {  // lane = tendon: gather its segments, then the muscle
-      int gt = lane;
+#pragma unroll
+    for (int rr = 0; rr < NTR; rr++) {  // lane = tendon (NTR rounds of 64): gather its segments, then the muscle
+      int gt = lane + 64 * rr;
+      tlen_r[rr] = 0.f; tvel_r[rr] = 0.f;
+      if (gt >= M.ngt) continue;
       float* Jrow = E + Y.tJ + gt * M.maxnnz;
       for (int k = 0; k < M.maxnnz; k++) Jrow[k] = 0;
       float L = 0;
@@ -1675,18 +1710,19 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
       int e0 = W.gt_dl[2 * gt], en = W.gt_dl[2 * gt + 1];
       for (int e = e0; e < e0 + en; e++) Jrow[M.dl[3 * e + 2]] += E[Y.dlval + e];
       E[Y.tlen + gt] = L;
-      tlen_r = L;
+      tlen_r[rr] = L;
       float vel = 0;
       for (int k = 0; k < M.maxnnz; k++) {
         int d = M.gt_dofs[gt * M.maxnnz + k];
         if (d >= 0) vel += Jrow[k] * E[Y.qvel + d];
         if (W.has_tl) E[Y.tJp + gt * M.maxnnz + k] = Jrow[k];
       }
-      tvel_r = vel;
+      tvel_r[rr] = vel;
       if (gt < nu) {
         const float* A = M.act + 16 * gt;
-        float f;
-        muscle(A, A[14] * L, A[14] * vel, E[Y.act + gt], E[Y.ctrl + gt], &f, &actdot);
+        float f, ad;
+        muscle(A, A[14] * L, A[14] * vel, E[Y.act + gt], E[Y.ctrl + gt], &f, &ad);
+        actdot[rr] = ad;
         E[Y.tforce + gt] = f * A[14];
       }
     }
@@ -1698,9 +1734,8 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
         qfa += E[Y.tJ + t * M.maxnnz + slot] * E[Y.tforce + t];
       }
     }
-    if (step == nsub - 1 && lane < nu) {   // diagnostics of the last substep
-      Bt.tenlen[(size_t)env * nu + lane] = E[Y.tlen + lane];
-      Bt.actforce[(size_t)env * nu + lane] = E[Y.tforce + lane];
+    if (step == nsub - 1) {   // diagnostics of the last substep
+      for (int i = lane; i < nu; i += 64) { Bt.tenlen[(size_t)env * nu + i] = E[Y.tlen + i]; Bt.actforce[(size_t)env * nu + i] = E[Y.tforce + i]; }
     }
     SYNC();  // region X changes owner: tendon scratch -> spatial dynamics
     STAMP(2);
@@ -1717,7 +1752,7 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
         for (int j = 0; j < 3; j++) Iw[3 * i + j] = T[3 * i] * R[3 * j] + T[3 * i + 1] * R[3 * j + 1] + T[3 * i + 2] * R[3 * j + 2];
       matvec(com, R, M.link_com + 3 * l);
       float mass = M.link_mass[l];
-      float dif[3] = {E[Y.lpos + 3 * l] + com[0] - M.c0[0], E[Y.lpos + 3 * l + 1] + com[1] - M.c0[1], E[Y.lpos + 3 * l + 2] + com[2] - M.c0[2]};
+      float dif[3] = {E[Y.lpos + 3 * l] + com[0] - c0[0], E[Y.lpos + 3 * l + 1] + com[1] - c0[1], E[Y.lpos + 3 * l + 2] + com[2] - c0[2]};
       float ci[10];
       ci[0] = Iw[0] + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
       ci[1] = Iw[4] + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
@@ -1734,7 +1769,7 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
       const float* ax = E + Y.axis + 3 * d;
       float c[6];
       if (M.dof_type[d] == 3) {
-        float off[3] = {M.c0[0] - E[Y.anchor + 3 * d], M.c0[1] - E[Y.anchor + 3 * d + 1], M.c0[2] - E[Y.anchor + 3 * d + 2]};
+        float off[3] = {c0[0] - E[Y.anchor + 3 * d], c0[1] - E[Y.anchor + 3 * d + 1], c0[2] - E[Y.anchor + 3 * d + 2]};
         c[0] = ax[0]; c[1] = ax[1]; c[2] = ax[2];
         cross3(c + 3, ax, off);
       } else { c[0] = c[1] = c[2] = 0; c[3] = ax[0]; c[4] = ax[1]; c[5] = ax[2]; }
@@ -1756,12 +1791,18 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
           for (int k = 0; k < 6; k++) { cvel[k] = E[Y.cvel + 6 * par + k]; cacc[k] = E[Y.cacc + 6 * par + k]; }
         }
         int da = M.link_dofadr[l], dn = M.link_dofnum[l];
+        const bool isfree = has_free && W.link_free[l];
+        float cvel_rot[6];
         for (int j = 0; j < dn; j++) {
           int d = da + j;
           float cd[6], cdd[6], qv = E[Y.qvel + d];
 #pragma unroll
           for (int k = 0; k < 6; k++) cd[k] = E[Y.cdof + 6 * d + k];
-          cross_motion(cdd, cvel, cd);
+          if (isfree && j == 3) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) cvel_rot[k] = cvel[k];   // velocity after the translations, before any of the 3 rotations
+          }
+          cross_motion(cdd, (isfree && j >= 3) ? cvel_rot : cvel, cd);
 #pragma unroll
           for (int k = 0; k < 6; k++) { cacc[k] += cdd[k] * qv; cvel[k] += cd[k] * qv; }
         }
@@ -1833,12 +1874,13 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
         bool hit = false;
         if (p < M.npair) {
           const int* P = M.pair_i + 6 * p;
-          if (!(M.disable_ellipsoid && !P[4])) {
+          if (!(M.disable_ellipsoid && P[4] == 0)) {
             int g1 = P[0], g2 = P[1];
             const float *x1 = E + Y.gpos + 3 * g1, *x2 = E + Y.gpos + 3 * g2;
             float dif[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
             float bound = M.cg_rbound[g1] + M.cg_rbound[g2] + M.pair_f[12 * p];
-            hit = dot3(dif, dif) <= bound * bound;
+            if (FULL && P[4] >= 2) hit = dot3(dif, E + Y.gax + 3 * g1) <= M.cg_rbound[g2] + M.pair_f[12 * p];   // plane: signed distance of the bounding sphere
+            else hit = dot3(dif, dif) <= bound * bound;
             if (hit && !P[4]) {
               // conservative refinement before the expensive MPR: replace a capsule's bounding sphere by the distance
               // from the other geom's centre to the capsule's SEGMENT (a bound on the true distance, never excludes a contact)
@@ -1872,8 +1914,8 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
       SYNC();
       for (int base = 0; base < ncand; base += 64) {
         int ci = base + lane;
-        bool hit = false;
-        float dist = 0, cpos[3] = {0, 0, 0}, nrm[3] = {1, 0, 0};
+        bool hit = false, hit2 = false;   // a plane-capsule pair can give two contacts (one per end sphere)
+        float dist = 0, dist2 = 0, cpos[3] = {0, 0, 0}, cpos2[3] = {0, 0, 0}, nrm[3] = {1, 0, 0};
         int p = -1;
         if (ci < ncand) {
           p = cand[ci];
@@ -1882,7 +1924,7 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
           float margin = M.pair_f[12 * p];
           const float *x1 = E + Y.gpos + 3 * g1, *x2 = E + Y.gpos + 3 * g2;
           const float *sz1 = M.cg_size + 3 * g1, *sz2 = M.cg_size + 3 * g2;
-          if (P[4]) {
+          if (P[4] == 1) {
             const float *a1 = E + Y.gax + 3 * g1, *a2 = E + Y.gax + 3 * g2;
             float dif[3] = {x1[0] - x2[0], x1[1] - x2[1], x1[2] - x2[2]};
             float mb = -dot3(a1, a2), u = -dot3(a1, dif), v = dot3(a2, dif), det = 1 - mb * mb, xa, xb;
@@ -1908,6 +1950,42 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
 #pragma unroll
               for (int k = 0; k < 3; k++) { cpos[k] = v1[k] + dd[k] * (sz1[0] + 0.5f * dist); nrm[k] = dd[k]; }
               hit = true;
+            }
+          } else if (FULL && P[4] == 2) {   // plane - capsule (mjc_PlaneCapsule): the two end spheres against the plane
+            const float *n = E + Y.gax + 3 * g1, *ax = E + Y.gax + 3 * g2;
+            float r = sz2[0], hh = sz2[1];
+#pragma unroll
+            for (int k = 0; k < 3; k++) nrm[k] = n[k];
+            float eA[3] = {x2[0] - hh * ax[0] - x1[0], x2[1] - hh * ax[1] - x1[1], x2[2] - hh * ax[2] - x1[2]};
+            float eB[3] = {x2[0] + hh * ax[0] - x1[0], x2[1] + hh * ax[1] - x1[1], x2[2] + hh * ax[2] - x1[2]};
+            float dA = dot3(eA, n) - r, dB = dot3(eB, n) - r;
+            if (dA <= margin) {
+              hit = true; dist = dA;
+#pragma unroll
+              for (int k = 0; k < 3; k++) cpos[k] = eA[k] + x1[k] - n[k] * (r + 0.5f * dA);
+            }
+            if (dB <= margin) {
+              hit2 = true; dist2 = dB;
+#pragma unroll
+              for (int k = 0; k < 3; k++) cpos2[k] = eB[k] + x1[k] - n[k] * (r + 0.5f * dB);
+            }
+          } else if (FULL && P[4] == 3) {   // plane - ellipsoid (mjc_PlaneConvex): deepest support point along -normal
+            const float* n = E + Y.gax + 3 * g1;
+            float R2[9], nl[3], sp[3], pw[3];
+            geom_world_mat(M, Y, E, g2, R2);
+            matTvec(nl, R2, n);
+            float sv[3] = {sz2[0] * nl[0], sz2[1] * nl[1], sz2[2] * nl[2]};
+            float nn = norm3(sv), inv = nn > MINVALF ? -1.0f / nn : 0.f;
+            sp[0] = sz2[0] * sv[0] * inv; sp[1] = sz2[1] * sv[1] * inv; sp[2] = sz2[2] * sv[2] * inv;
+            matvec(pw, R2, sp);
+            float rel[3] = {x2[0] - x1[0] + pw[0], x2[1] - x1[1] + pw[1], x2[2] - x1[2] + pw[2]};
+            float d = dot3(rel, n);
+#pragma unroll
+            for (int k = 0; k < 3; k++) nrm[k] = n[k];
+            if (d <= margin) {
+              hit = true; dist = d;
+#pragma unroll
+              for (int k = 0; k < 3; k++) cpos[k] = x2[k] + pw[k] - n[k] * 0.5f * d;
             }
           } else {
             const float zero3[3] = {0.f, 0.f, 0.f};
@@ -1943,18 +2021,30 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
             }
           }
           if (hit && !(dist < margin - M.pair_f[12 * p + 1])) hit = false;
+          if (hit2 && !(dist2 < margin - M.pair_f[12 * p + 1])) hit2 = false;
         }
         unsigned long long bal = __ballot(hit);
         int pos = ncon + __popcll(bal & ((1ull << lane) - 1ull));
-        if (hit && pos < NCONW) {
+        if (hit && pos < NC) {
           E[Y.cdist + pos] = dist;
 #pragma unroll
           for (int k = 0; k < 3; k++) { E[Y.cpos + 3 * pos + k] = cpos[k]; E[Y.cnrm + 3 * pos + k] = nrm[k]; }
           ((int*)(E + Y.cpair))[pos] = p;
         }
         ncon += __popcll(bal);
+        bal = FULL ? __ballot(hit2) : 0ull;
+        if (bal) {
+          pos = ncon + __popcll(bal & ((1ull << lane) - 1ull));
+          if (hit2 && pos < NC) {
+            E[Y.cdist + pos] = dist2;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { E[Y.cpos + 3 * pos + k] = cpos2[k]; E[Y.cnrm + 3 * pos + k] = nrm[k]; }
+            ((int*)(E + Y.cpair))[pos] = p;
+          }
+          ncon += __popcll(bal);
+        }
       }
-      if (ncon > NCONW) { flags |= MYO_FLAG_CONTACT_OVERFLOW; ncon = NCONW; }
+      if (ncon > NC) { flags |= MYO_FLAG_CONTACT_OVERFLOW; ncon = NC; }
       SYNC();
     }
     STAMP(4);
@@ -1963,7 +2053,7 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
     if (lane < nv && !M.disable_limit) {
       const float* J = M.jl + 12 * lane;
       if (J[0] != 0) {
-        float q = E[Y.qpos + lane], margin = J[3];
+        float q = E[Y.qpos + W.dof_qposadr[lane]], margin = J[3];
         float dlo = q - J[1], dhi = J[2] - q, dist = 0;
         if (dlo < margin && dlo <= dhi) { lsign = 1; dist = dlo; }
         else if (dhi < margin) { lsign = -1; dist = dhi; }
@@ -1986,12 +2076,24 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
       float n[3] = {E[Y.cnrm + 3 * c], E[Y.cnrm + 3 * c + 1], E[Y.cnrm + 3 * c + 2]}, t1[3], t2[3];
       float cp[3] = {E[Y.cpos + 3 * c], E[Y.cpos + 3 * c + 1], E[Y.cpos + 3 * c + 2]};
       make_frame(n, t1, t2);
+      if (FULL && P[4] == 2) {   // plane - capsule: first tangent along the capsule axis (MuJoCo's frame for this pair type)
+        const float* ax = E + Y.gax + 3 * P[1];
+        float t = dot3(ax, n), y[3] = {ax[0] - t * n[0], ax[1] - t * n[1], ax[2] - t * n[2]};
+        float yn = norm3(y);
+        if (yn >= 0.5f) {
+          float inv = 1.0f / yn;
+          t1[0] = y[0] * inv; t1[1] = y[1] * inv; t1[2] = y[2] * inv;
+          cross3(t2, n, t1);
+        }
+      }
       float vn = 0, vt1 = 0, vt2 = 0;
-      float* cJ = E + Y.cJ + c * 3 * KCMAX;
-      unsigned int dpk0 = 0, dpk1 = 0;
+      float* cJ = E + Y.cJ + c * 3 * KC;
+      unsigned int dpk[CDW];
+#pragma unroll
+      for (int k = 0; k < CDW; k++) dpk[k] = 0;
       ckc = P[3];
 #pragma unroll
-      for (int k = 0; k < KCMAX; k++) {
+      for (int k = 0; k < KC; k++) {
         float jn = 0, j1 = 0, j2 = 0;
         int d = 0;
         if (k < ckc) {
@@ -2007,65 +2109,78 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
           float qv = E[Y.qvel + d];
           vn += jn * qv; vt1 += j1 * qv; vt2 += j2 * qv;
         }
-        cJ[k] = jn; cJ[KCMAX + k] = j1; cJ[2 * KCMAX + k] = j2;
-        if (k < 4) dpk0 |= (unsigned int)d << (8 * k); else dpk1 |= (unsigned int)d << (8 * (k - 4));   // padded entries: zero jacobian, dof 0
+        cJ[k] = jn; cJ[KC + k] = j1; cJ[2 * KC + k] = j2;
+        dpk[k >> 2] |= (unsigned int)d << (8 * (k & 3));   // padded entries: zero jacobian, dof 0
       }
-      ((unsigned int*)(E + Y.cdofs))[2 * c] = dpk0;
-      ((unsigned int*)(E + Y.cdofs))[2 * c + 1] = dpk1;
+#pragma unroll
+      for (int k = 0; k < CDW; k++) ((unsigned int*)(E + Y.cdofs))[CDW * c + k] = dpk[k];
       float dist = E[Y.cdist + c], incl = F[0] - F[1];
       cmu = F[2];
       float imp = impedance(F + 6, dist, incl), K, B;
       kbi(F[4], F[5], F[7], M.timestep, &K, &B);
-      float R0 = fmaxf(MINVALF, (1 - imp) / imp * F[3] * (1 + cmu * cmu));
-      cD = 1.0f / fmaxf(MINVALF, 2 * cmu * cmu * R0);
+      if (FULL && P[5] == 1) {
+        // condim 1 (explicit <pair>): one frictionless row = four identical "pyramid" rows with mu = 0 and D/4 each
+        cmu = 0.f;
+        cD = 0.25f / fmaxf(MINVALF, (1 - imp) / imp * F[3]);
+      } else {
+        float R0 = fmaxf(MINVALF, (1 - imp) / imp * F[3] * (1 + cmu * cmu));
+        cD = 1.0f / fmaxf(MINVALF, 2 * cmu * cmu * R0);
+      }
       float pos = -K * imp * (dist - incl);
       caref[0] = -B * (vn + cmu * vt1) + pos; caref[1] = -B * (vn - cmu * vt1) + pos;
       caref[2] = -B * (vn + cmu * vt2) + pos; caref[3] = -B * (vn - cmu * vt2) + pos;
     }
-    int nefc = __popcll(__ballot(lsign != 0.f)) + 4 * ncon;
+    // efc row count as MuJoCo reports it: 4 pyramid rows per condim-3 contact, 1 per frictionless (condim-1) contact
+    int nefc = __popcll(__ballot(lsign != 0.f)) + 4 * ncon - 3 * __popcll(__ballot(lane < ncon && cmu == 0.f));
     const int ncon_real = ncon;
     if (W.has_tl) {
       // an active tendon limit becomes a frictionless pseudo-contact: jacobian = +-(sparse tendon row), mu = 0 and D/4 on each
       // of the four identical "pyramid" rows, which together act exactly like the single MuJoCo limit row
+      int nt = ncon;
+#pragma unroll
+      for (int rr = 0; rr < NTR; rr++) {
+      const int gt = lane + 64 * rr;
       bool tact = false;
       float t_aref = 0.f, t_D = 0.f, t_sign = 0.f;
-      if (lane < M.ngt && !M.disable_limit) {
-        const float* T = W.tl + 12 * lane;
+      if (gt < M.ngt && !M.disable_limit) {
+        const float* T = W.tl + 12 * gt;
         if (T[0] != 0) {
-          float margin = T[3], dlo = tlen_r - T[1], dhi = T[2] - tlen_r, dist = 0;
+          float margin = T[3], dlo = tlen_r[rr] - T[1], dhi = T[2] - tlen_r[rr], dist = 0;
           if (dlo < margin && dlo <= dhi) { t_sign = 1; dist = dlo; }
           else if (dhi < margin) { t_sign = -1; dist = dhi; }
           if (t_sign != 0) {
             float imp = impedance(T + 6, dist, margin), K, B;
             float R = fmaxf(MINVALF, (1 - imp) / imp * T[11]);
             kbi(T[4], T[5], T[7], M.timestep, &K, &B);
-            t_aref = -B * (t_sign * tvel_r) - K * imp * (dist - margin);
+            t_aref = -B * (t_sign * tvel_r[rr]) - K * imp * (dist - margin);
             t_D = 1.0f / R;
             tact = true;
           }
         }
       }
       unsigned long long bal = __ballot(tact);
-      int slot = ncon + __popcll(bal & ((1ull << lane) - 1ull));
-      if (tact && slot < NCONW) {
-        float* cJ = E + Y.cJ + slot * 3 * KCMAX;
-        unsigned int dpk0 = 0, dpk1 = 0;
+      int slot = nt + __popcll(bal & ((1ull << lane) - 1ull));
+      if (tact && slot < NC) {
+        float* cJ = E + Y.cJ + slot * 3 * KC;
+        unsigned int dpk[CDW];
+#pragma unroll
+        for (int k = 0; k < CDW; k++) dpk[k] = 0;
         int kc = 0;
 #pragma unroll
-        for (int k = 0; k < KCMAX; k++) {
-          int d = k < M.maxnnz ? M.gt_dofs[lane * M.maxnnz + k] : -1;
-          float jv = d >= 0 ? t_sign * E[Y.tJp + lane * M.maxnnz + k] : 0.f;
+        for (int k = 0; k < KC; k++) {
+          int d = k < M.maxnnz ? M.gt_dofs[gt * M.maxnnz + k] : -1;
+          float jv = d >= 0 ? t_sign * E[Y.tJp + gt * M.maxnnz + k] : 0.f;
           if (d >= 0) kc = k + 1; else d = 0;
-          cJ[k] = jv; cJ[KCMAX + k] = 0.f; cJ[2 * KCMAX + k] = 0.f;
-          if (k < 4) dpk0 |= (unsigned int)d << (8 * k); else dpk1 |= (unsigned int)d << (8 * (k - 4));
+          cJ[k] = jv; cJ[KC + k] = 0.f; cJ[2 * KC + k] = 0.f;
+          dpk[k >> 2] |= (unsigned int)d << (8 * (k & 3));
         }
-        ((unsigned int*)(E + Y.cdofs))[2 * slot] = dpk0;
-        ((unsigned int*)(E + Y.cdofs))[2 * slot + 1] = dpk1;
+#pragma unroll
+        for (int k = 0; k < CDW; k++) ((unsigned int*)(E + Y.cdofs))[CDW * slot + k] = dpk[k];
         E[Y.cdist + slot] = t_aref; E[Y.cpos + 3 * slot] = t_D; E[Y.cpos + 3 * slot + 1] = (float)kc;
       }
-      int ntl = __popcll(bal);
-      int nt = min(ncon + ntl, NCONW);
-      if (ncon + ntl > NCONW) flags |= MYO_FLAG_CONTACT_OVERFLOW;
+      nt += __popcll(bal);
+      }
+      if (nt > NC) { flags |= MYO_FLAG_CONTACT_OVERFLOW; nt = NC; }
       SYNC();
       if (lane >= ncon && lane < nt) {
         float a = E[Y.cdist + lane];
@@ -2075,6 +2190,25 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
       nefc += nt - ncon;
       ncon = nt;
     }
+    // joint-coupling equalities q1 - q1_0 = poly(q2 - q2_0) (mj_instantiateEquality, mjEQ_JOINT): lane = equality, two
+    // jacobian entries (+1 at dof 1, -poly' at dof 2), always active (quadratic cost on both sides)
+    float eJ2 = 0.f, eD = 0.f, earef = 0.f, ejar = 0.f, ejv = 0.f;
+    int ed1 = 0, ed2 = 0;
+    const bool eact = lane < neq;
+    if (eact) {
+      const int* Q = W.eq_i + 4 * lane;
+      const float* F = W.eq_f + 16 * lane;
+      ed1 = Q[0]; ed2 = Q[1];
+      float x = E[Y.qpos + Q[3]] - F[6];
+      float pos = E[Y.qpos + Q[2]] - F[5] - (F[0] + x * (F[1] + x * (F[2] + x * (F[3] + x * F[4]))));
+      eJ2 = -(F[1] + x * (2 * F[2] + x * (3 * F[3] + x * 4 * F[4])));
+      float vel = E[Y.qvel + ed1] + eJ2 * E[Y.qvel + ed2];
+      float imp = impedance(F + 9, pos, 0.f), K, B;
+      kbi(F[7], F[8], F[10], M.timestep, &K, &B);
+      earef = -B * vel - K * imp * pos;
+      eD = 1.0f / fmaxf(MINVALF, (1 - imp) / imp * F[14]);
+    }
+    nefc += neq;
     SYNC();
     // the mass matrix moves from the square buffer (about to be reused for the Hessian) to a packed copy that
     // aliases the now dead broad-phase scratch
@@ -2098,12 +2232,13 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
       if (lane < nv) E[Y.xv + lane] = qacc;
       SYNC();
       if (lane < ncon) {
-        const float* cJ = E + Y.cJ + lane * 3 * KCMAX;
+        const float* cJ = E + Y.cJ + lane * 3 * KC;
         float an = 0, a1 = 0, a2 = 0;
 #pragma unroll
-        for (int k = 0; k < KCMAX; k++) { float xv = E[Y.xv + CDOF(E, Y, lane, k)]; an += cJ[k] * xv; a1 += cJ[KCMAX + k] * xv; a2 += cJ[2 * KCMAX + k] * xv; }
+        for (int k = 0; k < KC; k++) { float xv = E[Y.xv + CDOF(E, Y, lane, k)]; an += cJ[k] * xv; a1 += cJ[KC + k] * xv; a2 += cJ[2 * KC + k] * xv; }
         cjar[0] = an + cmu * a1 - caref[0]; cjar[1] = an - cmu * a1 - caref[1]; cjar[2] = an + cmu * a2 - caref[2]; cjar[3] = an - cmu * a2 - caref[3];
       }
+      if (eact) ejar = E[Y.xv + ed1] + eJ2 * E[Y.xv + ed2] - earef;
     }
     bool first = true;
     const int lane_s = lane;
@@ -2120,10 +2255,11 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
         WFOR(i, NVT * (NVT + 1)) E[Y.sq + i] = 0;
         SYNC();
         if (lane < ncon) {
-          const float* cJ = E + Y.cJ + lane * 3 * KCMAX;
+          const float* cJ = E + Y.cJ + lane * 3 * KC;
           float Fn = f0 + f1 + f2 + f3, Ft1 = cmu * (f0 - f1), Ft2 = cmu * (f2 - f3);
-          for (int k = 0; k < ckc; k++) atomicAdd(&E[Y.qfc + CDOF(E, Y, lane, k)], Fn * cJ[k] + Ft1 * cJ[KCMAX + k] + Ft2 * cJ[2 * KCMAX + k]);
+          for (int k = 0; k < ckc; k++) atomicAdd(&E[Y.qfc + CDOF(E, Y, lane, k)], Fn * cJ[k] + Ft1 * cJ[KC + k] + Ft2 * cJ[2 * KC + k]);
         }
+        if (eact) { float f = -eD * ejar; atomicAdd(&E[Y.qfc + ed1], f); atomicAdd(&E[Y.qfc + ed2], eJ2 * f); }
         if (lane < nv && lact) E[Y.sq + lane * (NVT + 1) + lane] = lD;
         float Wn = w0 + w1 + w2 + w3, A1 = cmu * (w0 - w1), A2 = cmu * (w2 - w3), B1 = cmu * cmu * (w0 + w1), B2 = cmu * cmu * (w2 + w3);
         SYNC();
@@ -2131,19 +2267,25 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
           int kc = rdlanei(ckc, c);
           float sW = rdlane(Wn, c), sA1 = rdlane(A1, c), sA2 = rdlane(A2, c), sB1 = rdlane(B1, c), sB2 = rdlane(B2, c);
           if (sW == 0.f) continue;
-          if (lane < kc * kc) {
-            int a = lane / kc, b = lane - a * kc;
-            const float* cJ = E + Y.cJ + c * 3 * KCMAX;
+          for (int t = lane; t < kc * kc; t += 64) {
+            int a = t / kc, b = t - a * kc;
+            const float* cJ = E + Y.cJ + c * 3 * KC;
             int da = CDOF(E, Y, c, a), db = CDOF(E, Y, c, b);
             if (da >= db) {
-              float na = cJ[a], nb = cJ[b], ta = cJ[KCMAX + a], tb = cJ[KCMAX + b], ua = cJ[2 * KCMAX + a], ub = cJ[2 * KCMAX + b];
+              float na = cJ[a], nb = cJ[b], ta = cJ[KC + a], tb = cJ[KC + b], ua = cJ[2 * KC + a], ub = cJ[2 * KC + b];
               atomicAdd(&E[Y.sq + da * (NVT + 1) + db], sW * na * nb + sA1 * (na * tb + ta * nb) + sA2 * (na * ub + ua * nb) + sB1 * ta * tb + sB2 * ua * ub);
             }
           }
         }
+        if (eact) {
+          atomicAdd(&E[Y.sq + ed1 * (NVT + 1) + ed1], eD);
+          atomicAdd(&E[Y.sq + ed2 * (NVT + 1) + ed2], eD * eJ2 * eJ2);
+          atomicAdd(&E[Y.sq + max(ed1, ed2) * (NVT + 1) + min(ed1, ed2)], eD * eJ2);
+        }
         SYNC();
         qfc = lane < nv ? E[Y.qfc + lane] : 0.f;
         float cst = lact ? 0.5f * lD * ljar * ljar : 0.f;
+        cst += 0.5f * eD * ejar * ejar;
         cst += 0.5f * (w0 * cjar[0] * cjar[0] + w1 * cjar[1] * cjar[1] + w2 * cjar[2] * cjar[2] + w3 * cjar[3] * cjar[3]);
         cst += 0.5f * qacc * Ma - qacc * smooth;          // Gauss term up to a constant
         float newcost = wave_sum(cst);
@@ -2186,12 +2328,13 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
       if (lane < nv) E[Y.xv + lane] = search;
       SYNC();
       if (lane < ncon) {
-        const float* cJ = E + Y.cJ + lane * 3 * KCMAX;
+        const float* cJ = E + Y.cJ + lane * 3 * KC;
         float an = 0, a1 = 0, a2 = 0;
 #pragma unroll
-        for (int k = 0; k < KCMAX; k++) { float xv = E[Y.xv + CDOF(E, Y, lane, k)]; an += cJ[k] * xv; a1 += cJ[KCMAX + k] * xv; a2 += cJ[2 * KCMAX + k] * xv; }
+        for (int k = 0; k < KC; k++) { float xv = E[Y.xv + CDOF(E, Y, lane, k)]; an += cJ[k] * xv; a1 += cJ[KC + k] * xv; a2 += cJ[2 * KC + k] * xv; }
         cjv[0] = an + cmu * a1; cjv[1] = an - cmu * a1; cjv[2] = an + cmu * a2; cjv[3] = an - cmu * a2;
       }
+      if (eact) ejv = E[Y.xv + ed1] + eJ2 * E[Y.xv + ed2];
       float g1 = wave_sum(search * (Ma - smooth)), g2 = wave_sum(0.5f * search * Mv), sn = sqrtf(wave_sum(search * search));
       float alpha = 0, lo = 0, hi = -1, dlo = 0, d2lo = 0, dhi = 0, d2hi = 0, d1init = 0;
       bool ls_on = sn >= MINVALF;
@@ -2199,6 +2342,7 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
         float a = (lsit < 0) ? 0.f : alpha;
         float p1 = 0, p2 = 0;
         if (lsign != 0.f) { float xx = ljar + a * ljv; if (xx < 0) { p1 += lD * xx * ljv; p2 += lD * ljv * ljv; } }
+        p1 += eD * (ejar + a * ejv) * ejv; p2 += eD * ejv * ejv;
 #pragma unroll
         for (int k = 0; k < 4; k++) { float xx = cjar[k] + a * cjv[k]; if (xx < 0) { p1 += cD * xx * cjv[k]; p2 += cD * cjv[k] * cjv[k]; } }
         float d1 = wave_sum(p1) + g1 + 2 * a * g2;
@@ -2226,7 +2370,7 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
         }
       }
       if (!(alpha > 0)) { phase = 2; continue; }   // no descent left: keep qacc / qfc of this iterate
-      qacc += alpha * search; Ma += alpha * Mv; ljar += alpha * ljv;
+      qacc += alpha * search; Ma += alpha * Mv; ljar += alpha * ljv; ejar += alpha * ejv;
 #pragma unroll
       for (int k = 0; k < 4; k++) cjar[k] += alpha * cjv[k];
     }
@@ -2239,27 +2383,52 @@ __global__ void __launch_bounds__(64, 4) step_kernel_w(const DevModel* __restric
     }
     warm = qacc;
     if (alive) {
-      if (lane < nu) E[Y.act + lane] += h * actdot;
-      if (lane < nv) { float v = E[Y.qvel + lane] + h * qaccE; E[Y.qvel + lane] = v; E[Y.qpos + lane] += h * v; }
+#pragma unroll
+      for (int rr = 0; rr < NTR; rr++) if (lane + 64 * rr < nu) E[Y.act + lane + 64 * rr] += h * actdot[rr];
+      if (lane < nv) {
+        float v = E[Y.qvel + lane] + h * qaccE;
+        E[Y.qvel + lane] = v;
+        if (!(has_free && lane >= 3 && lane < 6)) E[Y.qpos + W.dof_qposadr[lane]] += h * v;
+      }
+      if (has_free) {   // root free joint: quaternion integrated with the body-frame angular velocity (mju_quatIntegrate)
+        SYNC();
+        if (lane == 3) {
+          float w[3] = {E[Y.qvel + 3], E[Y.qvel + 4], E[Y.qvel + 5]};
+          float wn = norm3(w), ang = h * wn;
+          float q[4] = {E[Y.qpos + 3], E[Y.qpos + 4], E[Y.qpos + 5], E[Y.qpos + 6]};
+          if (wn >= MINVALF) {
+            float sn, cs;
+            sincosf(0.5f * ang, &sn, &cs);
+            float inv = sn / wn, r[4] = {cs, w[0] * inv, w[1] * inv, w[2] * inv}, o[4];
+            o[0] = q[0] * r[0] - q[1] * r[1] - q[2] * r[2] - q[3] * r[3];
+            o[1] = q[0] * r[1] + q[1] * r[0] + q[2] * r[3] - q[3] * r[2];
+            o[2] = q[0] * r[2] - q[1] * r[3] + q[2] * r[0] + q[3] * r[1];
+            o[3] = q[0] * r[3] + q[1] * r[2] - q[2] * r[1] + q[3] * r[0];
+            float on = 1.0f / sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+            E[Y.qpos + 3] = o[0] * on; E[Y.qpos + 4] = o[1] * on; E[Y.qpos + 5] = o[2] * on; E[Y.qpos + 6] = o[3] * on;
+          }
+        }
+      }
       time += h;
     }
     SYNC();
     STAMP(8);
   }
   if (!alive) {  // a bad env is reset like mj_resetData (mj_sim_scene.py:56-61)
-    if (lane_id < nv) { E[Y.qpos + lane_id] = M.qpos0[lane_id]; E[Y.qvel + lane_id] = 0; warm = 0; }
-    if (lane_id < nu) { E[Y.act + lane_id] = 0; E[Y.ctrl + lane_id] = 0; }
+    if (lane_id < nq) E[Y.qpos + lane_id] = M.qpos0[lane_id];
+    if (lane_id < nv) { E[Y.qvel + lane_id] = 0; warm = 0; }
+    for (int i = lane_id; i < nu; i += 64) { E[Y.act + i] = 0; E[Y.ctrl + i] = 0; }
     time = 0;
   }
+  if (lane_id < nq) Bt.qpos[(size_t)env * nq + lane_id] = E[Y.qpos + lane_id];
   if (lane_id < nv) {
-    Bt.qpos[(size_t)env * nv + lane_id] = E[Y.qpos + lane_id];
     Bt.qvel[(size_t)env * nv + lane_id] = E[Y.qvel + lane_id];
     Bt.warm[(size_t)env * nv + lane_id] = warm;
     Bt.qacc[(size_t)env * nv + lane_id] = qacc;
   }
-  if (lane_id < nu) {
-    Bt.act[(size_t)env * nu + lane_id] = E[Y.act + lane_id];
-    Bt.ctrl[(size_t)env * nu + lane_id] = E[Y.ctrl + lane_id];
+  for (int i = lane_id; i < nu; i += 64) {
+    Bt.act[(size_t)env * nu + i] = E[Y.act + i];
+    Bt.ctrl[(size_t)env * nu + i] = E[Y.ctrl + i];
   }
   if (lane_id == 0) {
     Bt.time[env] = time;
@@ -2324,7 +2493,7 @@ __global__ void random_action_kernel(float* action, int B, int nu, uint64_t seed
 }
 
 // auto_max > 0: gym TimeLimit / done auto-reset (reset iff done or elapsed >= auto_max); else mask-driven reset
-__global__ void reset_kernel(DevBatch Bt, TaskDev T, int nv, int nu, const float* qpos0, const uint8_t* mask, uint64_t seed, int env_offset,
+__global__ void reset_kernel(DevBatch Bt, TaskDev T, int nq, int nv, int nu, const float* qpos0, const uint8_t* mask, uint64_t seed, int env_offset,
                              int auto_max) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= Bt.B) return;
@@ -2334,10 +2503,12 @@ __global__ void reset_kernel(DevBatch Bt, TaskDev T, int nv, int nu, const float
   Bt.elapsed[e] = 0;
   Bt.done[e] = 0.f;
   uint64_t ge = (uint64_t)(e + env_offset);
-  for (int i = 0; i < nv; i++) {
+  for (int i = 0; i < nq; i++) {
     float q = T.init_qpos ? T.init_qpos[i] : qpos0[i];
-    if (T.reset_random) q = T.jnt_lo[i] + (T.jnt_hi[i] - T.jnt_lo[i]) * u01(seed, ge * 4096 + i, 1);
-    Bt.qpos[(size_t)e * nv + i] = q;
+    if (T.reset_random) q = T.jnt_lo[i] + (T.jnt_hi[i] - T.jnt_lo[i]) * u01(seed, ge * 4096 + i, 1);   // nq == nv checked at configure
+    Bt.qpos[(size_t)e * nq + i] = q;
+  }
+  for (int i = 0; i < nv; i++) {
     Bt.qvel[(size_t)e * nv + i] = 0;
     Bt.warm[(size_t)e * nv + i] = 0;
   }
@@ -2447,7 +2618,9 @@ struct myo_model {
   DevModel* d_dm = nullptr;     // device copies of the model structs for the wave kernel
   DevModelW* d_dw = nullptr;
   int env_lds_bytes_w = 0;
-  bool wave_ok = false;
+  bool wave_ok = false, generic_ok = false;
+  int wave_cfg = 0;             // 0: step_kernel_w<24,8,32,1,4> (hand / finger), 1: step_kernel_w<36,20,48,2,2> (legs)
+  int nq = 0;
   int has_tl = 0;
   myo_dims dims{};
   std::vector<void*> dev_allocs;
@@ -2512,12 +2685,12 @@ static int load_i(myo_model* m, const uint8_t* blob, const char* name, const int
   return upload<int>(m, v, out);
 }
 
-static void build_layout_w(const DevModel& d, DevModelW& w, int nvt) {
+static void build_layout_w(const DevModel& d, DevModelW& w, int nvt, int kc, int nc) {
   LayW& Y = w.lay;
   int o = 0;
   auto take = [&](int n) { int r = o; o += n; return r; };
   int nv = d.nv, nu = d.nu, nl = d.nl;
-  Y.qpos = take(nv); Y.qvel = take(nv); Y.act = take(nu); Y.ctrl = take(nu);
+  Y.qpos = take(w.nq); Y.qvel = take(nv); Y.act = take(nu); Y.ctrl = take(nu);
   Y.lpos = take(3 * nl); Y.lmat = take(9 * nl); Y.axis = take(3 * nv); Y.anchor = take(3 * nv);
   Y.xv = take(nvt); Y.qfc = take(nvt); Y.sq = take(nvt * (nvt + 1));
   Y.tJp = w.has_tl ? take(d.ngt * d.maxnnz) : 0;
@@ -2531,8 +2704,8 @@ static void build_layout_w(const DevModel& d, DevModelW& w, int nvt) {
   Y.Mp = o;
   Y.gpos = take(3 * d.ncg); Y.gax = take(3 * d.ncg);
   Y.cand = take(NCAND);
-  if (o - Y.Mp < (nvt * (nvt + 1)) / 2) o = Y.Mp + (nvt * (nvt + 1)) / 2; Y.cdist = take(NCONW); Y.cpos = take(3 * NCONW); Y.cnrm = take(3 * NCONW); Y.cpair = take(NCONW);
-  Y.cJ = take(NCONW * 3 * KCMAX); Y.cdofs = take(NCONW * 2);   // 8 dof ids per contact, one byte each
+  if (o - Y.Mp < (nvt * (nvt + 1)) / 2) o = Y.Mp + (nvt * (nvt + 1)) / 2; Y.cdist = take(nc); Y.cpos = take(3 * nc); Y.cnrm = take(3 * nc); Y.cpair = take(nc);
+  Y.cJ = take(nc * 3 * kc); Y.cdofs = take(nc * ((kc + 3) / 4));   // kc dof ids per contact, one byte each
   if (o < endT) o = endT;
   if (o < endD) o = endD;
   Y.total = o;
@@ -2591,7 +2764,7 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
   const double* O = (const double*)(blob + op->offset);
   d.nl = H[0]; d.nlevel = H[1]; d.nv = H[2]; d.nu = H[3]; d.ngt = H[4]; d.nseg = H[5]; d.maxnnz = H[7]; d.nwg = H[8];
   d.ncg = H[9]; d.npair = H[10]; d.maxkc = H[11]; d.ns = H[12]; d.nM = S[11];
-  if (d.maxkc > KCMAX) { delete m; return fail(MYO_E_UNSUPPORTED, "contact pair spans more dofs than KCMAX"); }
+  m->nq = S[0];
   if (d.ngt != d.nu) { delete m; return fail(MYO_E_UNSUPPORTED, "limited-only tendons are not supported by the HIP path yet"); }
   d.timestep = (float)O[0]; d.grav[0] = (float)O[1]; d.grav[1] = (float)O[2]; d.grav[2] = (float)O[3];
   d.tolerance = (float)O[4]; d.iterations = (int)O[5]; d.ls_iterations = (int)O[6]; d.ls_tolerance = (float)O[7];
@@ -2642,9 +2815,26 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
       for (int t = 0; t < d.ngt; t++) if (tlv[12 * t] != 0) w.has_tl = 1;
       m->has_tl = w.has_tl;
     }
-    m->wave_ok = d.nv <= 24 && d.nu <= 64 && d.ngt <= 64 && d.nl <= 64 && d.ncg <= 64;
-    build_layout_w(d, w, 24);
+    bool plane_pairs = false, condim1 = false;
+    {
+      std::vector<int> fl, pi;
+      if ((rc = load_i(m, blob, "hip_flags", &tmpi, &fl)) || (rc = load_i(m, blob, "hip_link_free", &w.link_free)) ||
+          (rc = load_i(m, blob, "hip_dof_qposadr", &w.dof_qposadr)) || (rc = load_i(m, blob, "hip_eq_i", &w.eq_i)) ||
+          (rc = load_f(m, blob, "hip_eq_f", &w.eq_f)) || (rc = load_i(m, blob, "hip_pair_i", &tmpi, &pi))) { myo_model_free(m); return rc; }
+      w.has_free = fl[0]; w.nq = fl[1]; w.neq = fl[2];
+      if (w.nq != m->nq) { myo_model_free(m); return fail(MYO_E_BLOB, "hip_flags disagrees with sizes"); }
+      for (int p = 0; p < d.npair; p++) { if (pi[6 * p + 4] >= 2) plane_pairs = true; if (pi[6 * p + 5] == 1) condim1 = true; }
+      // the 16/32-lane generic kernel covers fixed-base models with hinge / slide joints and capsule / convex pairs only
+      m->generic_ok = !w.has_free && w.neq == 0 && !plane_pairs && !condim1 && w.nq == d.nv && d.maxkc <= KCMAX && !w.has_tl;
+    }
+    const bool common = d.nl <= 64 && d.ncg <= 64 && w.nq <= 64 && w.neq <= 64 && d.maxnnz <= 20;
+    const bool needs_full = w.has_free || w.neq > 0 || plane_pairs || condim1;
+    if (common && !needs_full && d.nv <= 24 && d.nu <= 64 && d.ngt <= 64 && d.maxkc <= 8) { m->wave_ok = true; m->wave_cfg = 0; build_layout_w(d, w, 24, 8, 32); }
+    else if (common && d.nv <= 36 && d.nu <= 128 && d.ngt <= 128 && d.maxkc <= 20) { m->wave_ok = true; m->wave_cfg = 1; build_layout_w(d, w, 36, 20, 48); }
+    else { m->wave_ok = false; build_layout_w(d, w, 24, 8, 32); }
+    if (!m->wave_ok && !m->generic_ok) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "model exceeds the limits of both step kernels (nv <= 36, nu <= 128, pair dofs <= 20)"); }
     m->env_lds_bytes_w = w.lay.total * 4;
+    if (m->wave_ok && m->env_lds_bytes_w > 64 * 1024) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "wave kernel working set exceeds 64 KB of LDS"); }
     void* p1 = nullptr; void* p2 = nullptr;
     if (hipMalloc(&p1, sizeof(DevModel)) != hipSuccess || hipMalloc(&p2, sizeof(DevModelW)) != hipSuccess) { myo_model_free(m); return fail(MYO_E_NOMEM, "hipMalloc model structs"); }
     m->dev_allocs.push_back(p1); m->dev_allocs.push_back(p2);
@@ -2652,7 +2842,10 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
     if (hipMemcpy(p1, &d, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(p2, &w, sizeof(DevModelW), hipMemcpyHostToDevice) != hipSuccess) { myo_model_free(m); return fail(MYO_E_HIP, "upload model structs"); }
   }
   m->dims = myo_dims{S[0], S[1], S[2], S[3], S[4], S[8], S[7], d.nl, 0, m->env_lds_bytes, 64, NCON, d.timestep};
-  if (4 * m->env_lds_bytes > 160 * 1024) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "model working set exceeds 160 KB of LDS per workgroup"); }
+  if (4 * m->env_lds_bytes > 160 * 1024) {
+    if (!m->wave_ok) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "model working set exceeds 160 KB of LDS per workgroup"); }
+    m->generic_ok = false;
+  }
   *out = m;
   return MYO_OK;
 }
@@ -2690,15 +2883,15 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   b->model = m;
   DevBatch& d = b->db;
   d.B = B;
-  int nv = m->dm.nv, nu = m->dm.nu, rc;
+  int nv = m->dm.nv, nu = m->dm.nu, nq = m->nq, rc;
   b->ntarget_alloc = nv > 24 ? nv : 24;
   b->obs_alloc = 3 * nv + 2 * nu + 64;
 #define BA(ptr, n) if ((rc = balloc(b, (void**)&ptr, (size_t)(n) * 4))) { myo_batch_free(b); return rc; }
-  BA(d.qpos, (size_t)B * nv) BA(d.qvel, (size_t)B * nv) BA(d.act, (size_t)B * nu) BA(d.ctrl, (size_t)B * nu) BA(d.warm, (size_t)B * nv)
+  BA(d.qpos, (size_t)B * nq) BA(d.qvel, (size_t)B * nv) BA(d.act, (size_t)B * nu) BA(d.ctrl, (size_t)B * nu) BA(d.warm, (size_t)B * nv)
   BA(d.time, B) BA(d.target, (size_t)B * b->ntarget_alloc) BA(d.obs, (size_t)B * b->obs_alloc) BA(d.reward, B) BA(d.done, B)
   BA(d.solved, B) BA(d.qacc, (size_t)B * nv) BA(d.tenlen, (size_t)B * nu) BA(d.actforce, (size_t)B * nu) BA(d.sitexpos, (size_t)B * 24)
   BA(d.flags, B) BA(d.diag, (size_t)B * 8) BA(d.elapsed, B) BA(d.episode, B)
-  BA(b->d_tlo, b->ntarget_alloc) BA(b->d_thi, b->ntarget_alloc) BA(b->d_init, nv) BA(b->d_jlo, nv) BA(b->d_jhi, nv)
+  BA(b->d_tlo, b->ntarget_alloc) BA(b->d_thi, b->ntarget_alloc) BA(b->d_init, nq) BA(b->d_jlo, nv) BA(b->d_jhi, nv)
   BA(b->d_action, (size_t)B * nu)
   BA(b->d_stamps, (size_t)B * 12 * 2)
   BA(b->d_order, B)
@@ -2706,10 +2899,10 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   if (const char* e = getenv("MYO_LANES")) { int g = atoi(e); if (g == 16 || g == 32 || g == 64) g_lanes = g; }
   HIPCHK(hipMemcpy(b->d_jlo, m->jnt_lo.data(), nv * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(b->d_jhi, m->jnt_hi.data(), nv * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(b->d_init, m->qpos0.data(), nv * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->d_init, m->qpos0.data(), nq * 4, hipMemcpyHostToDevice));
   // default: every env at qpos0
-  std::vector<float> q((size_t)B * nv);
-  for (int e = 0; e < B; e++) memcpy(&q[(size_t)e * nv], m->qpos0.data(), nv * 4);
+  std::vector<float> q((size_t)B * nq);
+  for (int e = 0; e < B; e++) memcpy(&q[(size_t)e * nq], m->qpos0.data(), nq * 4);
   HIPCHK(hipMemcpy(d.qpos, q.data(), q.size() * 4, hipMemcpyHostToDevice));
   b->task.task = MYO_TASK_NONE; b->task.frame_skip = 1; b->task.obs_dim = 0; b->task.ntarget = 0;
   b->task.jnt_lo = b->d_jlo; b->task.jnt_hi = b->d_jhi; b->task.init_qpos = b->d_init; b->task.target_lo = b->d_tlo; b->task.target_hi = b->d_thi;
@@ -2750,7 +2943,8 @@ int myo_batch_configure(myo_batch* b, const myo_task_config* c) {
     HIPCHK(hipMemcpy(b->d_tlo, c->target_lo, c->ntarget * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(b->d_thi, c->target_hi ? c->target_hi : c->target_lo, c->ntarget * 4, hipMemcpyHostToDevice));
   }
-  HIPCHK(hipMemcpy(b->d_init, c->init_qpos ? c->init_qpos : b->model->qpos0.data(), nv * 4, hipMemcpyHostToDevice));
+  if (c->reset_random && b->model->nq != nv) return fail(MYO_E_ARG, "reset_random needs a model without free / ball joints");
+  HIPCHK(hipMemcpy(b->d_init, c->init_qpos ? c->init_qpos : b->model->qpos0.data(), b->model->nq * 4, hipMemcpyHostToDevice));
   return MYO_OK;
 }
 
@@ -2759,7 +2953,7 @@ static int field_info(myo_batch* b, int f, void** p, size_t* pitch, size_t* widt
   DevBatch& d = b->db;
   size_t nv = dm.nv, nu = dm.nu;
   switch (f) {
-    case MYO_F_QPOS: *p = d.qpos; *pitch = *width = nv; break;
+    case MYO_F_QPOS: *p = d.qpos; *pitch = *width = (size_t)b->model->nq; break;
     case MYO_F_QVEL: *p = d.qvel; *pitch = *width = nv; break;
     case MYO_F_ACT: *p = d.act; *pitch = *width = nu; break;
     case MYO_F_CTRL: *p = d.ctrl; *pitch = *width = nu; break;
@@ -2816,7 +3010,7 @@ int myo_reset(myo_batch* b, const uint8_t* mask_dev, uint64_t seed, void* stream
   const DevModel& dm = b->model->dm;
   HIPCHK(hipSetDevice(b->model->device));
   int B = b->db.B;
-  hipLaunchKernelGGL(reset_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->db, b->task, dm.nv, dm.nu, dm.qpos0, mask_dev, seed,
+  hipLaunchKernelGGL(reset_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->db, b->task, b->model->nq, dm.nv, dm.nu, dm.qpos0, mask_dev, seed,
                      b->env_offset, 0);
   HIPCHK(hipGetLastError());
   return MYO_OK;
@@ -2827,7 +3021,7 @@ int myo_autoreset(myo_batch* b, int max_episode_steps, uint64_t seed, void* stre
   const DevModel& dm = b->model->dm;
   HIPCHK(hipSetDevice(b->model->device));
   int B = b->db.B;
-  hipLaunchKernelGGL(reset_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->db, b->task, dm.nv, dm.nu, dm.qpos0,
+  hipLaunchKernelGGL(reset_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->db, b->task, b->model->nq, dm.nv, dm.nu, dm.qpos0,
                      (const uint8_t*)nullptr, seed, b->env_offset, max_episode_steps);
   HIPCHK(hipGetLastError());
   return MYO_OK;
@@ -2844,7 +3038,7 @@ int myo_set_state(myo_batch* b, const float* qpos, const float* qvel, const floa
   const DevModel& dm = b->model->dm;
   size_t B = b->db.B;
   hipStream_t s = (hipStream_t)stream;
-  if (qpos) HIPCHK(hipMemcpyAsync(b->db.qpos, qpos, B * dm.nv * 4, hipMemcpyDeviceToDevice, s));
+  if (qpos) HIPCHK(hipMemcpyAsync(b->db.qpos, qpos, B * b->model->nq * 4, hipMemcpyDeviceToDevice, s));
   if (qvel) HIPCHK(hipMemcpyAsync(b->db.qvel, qvel, B * dm.nv * 4, hipMemcpyDeviceToDevice, s));
   if (act) HIPCHK(hipMemcpyAsync(b->db.act, act, B * dm.nu * 4, hipMemcpyDeviceToDevice, s));
   if (time) HIPCHK(hipMemcpyAsync(b->db.time, time, B * 4, hipMemcpyDeviceToDevice, s));
@@ -2853,7 +3047,8 @@ int myo_set_state(myo_batch* b, const float* qpos, const float* qvel, const floa
 
 static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, hipStream_t s) {
   const myo_model* m = b->model;
-  const int G = (g_lanes == 64 && !m->wave_ok) ? 16 : g_lanes, EPW = 64 / G;   // models the wave kernel cannot take fall back to 16 lanes
+  // models the wave kernel cannot take fall back to 16 lanes; models only the wave kernel can take always use it
+  const int G = (g_lanes == 64 && !m->wave_ok) ? 16 : ((g_lanes != 64 && !m->generic_ok) ? 64 : g_lanes), EPW = 64 / G;
   int grid = (b->db.B + EPW - 1) / EPW;
   size_t lds = (size_t)EPW * m->env_lds_bytes;
   static bool attr_set = false;
@@ -2865,18 +3060,27 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     attr_set = true;
   }
   long long* st = b->d_stamps;
-  if (m->has_tl && !(G == 64 && m->wave_ok)) return fail(MYO_E_UNSUPPORTED, "tendon limits are only implemented in the wave-per-env kernel (lanes = 64)");
+  if (!(G == 64 && m->wave_ok) && !m->generic_ok)
+    return fail(MYO_E_UNSUPPORTED, "this model (tendon limits / free joint / equalities / plane contacts) needs the wave-per-env kernel (lanes = 64)");
   if (G == 64 && m->wave_ok) {
     static bool attr_w = false;
-    if (!attr_w) { HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr_w = true; }
+    if (!attr_w) {
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 48, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      attr_w = true;
+    }
     const int* order = nullptr;
     int Bn = b->db.B;
     if (b->balance && Bn >= 1024 && Bn % 4 == 0) {
       hipLaunchKernelGGL(balance_kernel, dim3(1), dim3(1024), 0, s, (const int*)b->db.diag, Bn, b->d_order, Bn / 4);
       order = b->d_order;
     }
-    hipLaunchKernelGGL(step_kernel_w<24>, dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm, (const DevModelW*)m->d_dw, b->db, action,
-                       actmap, nsub, st, order);
+    if (m->wave_cfg == 0)
+      hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order);
+    else
+      hipLaunchKernelGGL((step_kernel_w<36, 20, 48, 2, 2>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order);
     HIPCHK(hipGetLastError());
     return MYO_OK;
   }

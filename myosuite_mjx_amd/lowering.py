@@ -22,7 +22,7 @@ import math
 
 import numpy as np
 
-from .mjcf import (GEOM_CAPSULE, GEOM_CYLINDER, GEOM_ELLIPSOID, GEOM_PLANE, GEOM_SPHERE, JNT_HINGE, JNT_SLIDE,
+from .mjcf import (GEOM_CAPSULE, GEOM_CYLINDER, GEOM_ELLIPSOID, GEOM_PLANE, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE,
                    WRAP_CYLINDER, WRAP_PULLEY, WRAP_SITE, WRAP_SPHERE, mat2quat, quat2mat, quat_mul)
 from . import setconst as sc
 
@@ -56,9 +56,15 @@ def lower(cm):
     A = cm.arrays
     nb = len(m.body_parentid)
     nv = len(m.dof_bodyid)
+    has_free = False
     for j in range(len(m.jnt_type)):
-        if m.jnt_type[j] not in (JNT_HINGE, JNT_SLIDE):
-            raise NotImplementedError("HIP path: only hinge/slide joints so far")
+        if m.jnt_type[j] == JNT_FREE:
+            b = m.jnt_bodyid[j]
+            if m.body_parentid[b] != 0 or m.body_jntnum[b] != 1 or has_free:
+                raise NotImplementedError("HIP path: a free joint must be the only joint of a single root body")
+            has_free = True
+        elif m.jnt_type[j] not in (JNT_HINGE, JNT_SLIDE):
+            raise NotImplementedError("HIP path: ball joints")
     head, Rrel, prel = _rel_transforms(m)
     heads = [b for b in range(1, nb) if m.body_jntnum[b] > 0]
     # parent link of each head body
@@ -123,12 +129,28 @@ def lower(cm):
         child_adr[l] = len(childs)
         childs += [c for c in range(nl) if link_parent[c] == l]
     child_adr[nl] = len(childs)
-    # dofs (hinge/slide: dof id == joint id ordering, qpos adr == dof adr)
+    # dofs.  A free joint's 3 translational dofs behave like slides along the world axes and its 3 rotational dofs like hinges
+    # about the body axes through the body origin: the kernels get type 2 / 3 for them (axis / anchor are written by the
+    # kinematics stage) plus a per-link `free` flag for the places that differ (pose from qpos, RNE, quaternion integration)
     dof_link = np.array([lid[m.dof_bodyid[d]] for d in range(nv)], np.int32)
-    assert all(m.jnt_qposadr[j] == m.jnt_dofadr[j] for j in range(len(m.jnt_type)))
-    dof_type = m.jnt_type[m.dof_jntid].astype(np.int32)
-    dof_pos = m.jnt_pos[m.dof_jntid]
-    dof_axis = m.jnt_axis[m.dof_jntid]
+    dof_type = np.zeros(nv, np.int32)
+    dof_qposadr = np.zeros(nv, np.int32)
+    dof_pos = np.zeros((nv, 3))
+    dof_axis = np.zeros((nv, 3))
+    link_free = np.zeros(nl, np.int32)
+    for j in range(len(m.jnt_type)):
+        d, qa = m.jnt_dofadr[j], m.jnt_qposadr[j]
+        if m.jnt_type[j] == JNT_FREE:
+            dof_type[d:d + 3] = JNT_SLIDE
+            dof_type[d + 3:d + 6] = JNT_HINGE
+            dof_qposadr[d:d + 3] = qa + np.arange(3)
+            dof_qposadr[d + 3:d + 6] = qa + 3
+            link_free[lid[m.jnt_bodyid[j]]] = 1
+        else:
+            dof_type[d] = m.jnt_type[j]
+            dof_qposadr[d] = qa
+            dof_pos[d] = m.jnt_pos[j]
+            dof_axis[d] = m.jnt_axis[j]
     # ancestors (dof chains) helpers
     def dof_chain(link):  # all dofs from root to this link (inclusive), as a set
         s = []
@@ -302,7 +324,7 @@ def lower(cm):
     for l in range(nl):
         par = link_parent[l]
         if par < 0:
-            reach[l] = link_extra(l)
+            reach[l] = np.inf if link_free[l] else link_extra(l)
             root_anchor[l] = link_pos[l] + link_mat0[l] @ first_anchor(l)
         else:
             a_in_parent = link_pos[l] + link_mat0[l] @ first_anchor(l)
@@ -334,12 +356,14 @@ def lower(cm):
             R = geom_lmat[stat].reshape(3, 3)
             axis = R[:, 2]
             top = geom_lpos[stat] + (axis * m.geom_size[stat, 1] if m.geom_type[stat] == GEOM_CYLINDER else 0)
-            if (c - top) @ axis - r > margin:
+            if np.isfinite(r) and (c - top) @ axis - r > margin:
                 pruned += 1
                 continue
-            raise NotImplementedError(f"HIP path: cannot prune static geom {stat} against moving geom {mov}")
+            if not (m.geom_type[stat] == GEOM_PLANE and stat == g1 and m.geom_type[mov] in (GEOM_CAPSULE, GEOM_ELLIPSOID)):
+                raise NotImplementedError(f"HIP path: cannot prune static geom {stat} against moving geom {mov}")
         ok = (GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_SPHERE, GEOM_CYLINDER)
-        if t1 not in ok or t2 not in ok:
+        plane_pair = t1 == GEOM_PLANE
+        if not plane_pair and (t1 not in ok or t2 not in ok):
             raise NotImplementedError(f"HIP path: geom pair types {t1},{t2}")
         lst = dof_list(geom_link[g1], geom_link[g2])
         # contact parameter mixing (mj_contactParam), equal priorities
@@ -354,11 +378,16 @@ def lower(cm):
             solimp = mix * m.geom_solimp[g1] + (1 - mix) * m.geom_solimp[g2]
             fric = np.maximum(m.geom_friction[g1], m.geom_friction[g2])
             condim = max(m.geom_condim[g1], m.geom_condim[g2])
-        if condim != 3:
-            raise NotImplementedError("HIP path: condim != 3")
+        pidx = [k for k in range(len(m.pair_geom)) if m.pair_geom[k, 0] == g1 and m.pair_geom[k, 1] == g2][-1]
+        if "pair_condim" in A and A["pair_condim"][pidx] > 0:
+            condim = int(A["pair_condim"][pidx])
+        if condim not in (1, 3):
+            raise NotImplementedError("HIP path: condim must be 1 or 3")
         b1, b2 = m.geom_bodyid[g1], m.geom_bodyid[g2]
         invw = m.body_invweight0[b1, 0] + m.body_invweight0[b2, 0]
-        pairs_i.append([cg_index(g1), cg_index(g2), len(pair_dl), len(lst), int(t1 == GEOM_CAPSULE and t2 == GEOM_CAPSULE), 0])
+        # narrow-phase type: 1 capsule-capsule (analytic), 2 plane-capsule, 3 plane-ellipsoid, 0 generic convex (MPR)
+        ptype = 1 if (t1 == GEOM_CAPSULE and t2 == GEOM_CAPSULE) else (2 if (plane_pair and t2 == GEOM_CAPSULE) else (3 if plane_pair else 0))
+        pairs_i.append([cg_index(g1), cg_index(g2), len(pair_dl), len(lst), ptype, condim])
         pairs_f.append([margin, max(m.geom_gap[g1], m.geom_gap[g2]), fric[0], invw, solref[0], solref[1],
                         solimp[0], solimp[1], solimp[2], solimp[3], solimp[4], 0.0])
         pair_dl += lst
@@ -381,13 +410,31 @@ def lower(cm):
     c0 = sum(m.body_mass[b] * (xpos0[b] + quat2mat(xquat0[b]) @ m.body_ipos[b]) for b in mv) / sum(m.body_mass[b] for b in mv)
     # shift the world origin to c0: float coordinates stay < ~0.3 m instead of ~1.4 m (free precision);
     # everything is translation invariant, outputs that are world positions add hip_origin back
+    if has_free:
+        c0 = np.zeros(3)       # free-floating model: no origin shift; the spatial reference point follows the root link
     for l in range(nl):
-        if link_parent[l] < 0:
+        if link_parent[l] < 0 and not link_free[l]:
             link_pos[l] = link_pos[l] - c0
     site_lpos[site_link < 0] -= c0
     geom_lpos[geom_link < 0] -= c0
     A["hip_origin"] = np.asarray(c0).copy()
     c0 = np.zeros(3)
+    # equality rows (joint couplings): ints [dof1, dof2, qadr1, qadr2], floats [a0..a4, q0_1, q0_2, solref0, solref1, solimp0..4, invweight]
+    neq = int(A["sizes"][12])
+    eq_i = np.zeros((neq, 4), np.int32)
+    eq_f = np.zeros((neq, 16))
+    for e in range(neq):
+        j1, j2 = int(m.eq_obj1id[e]), int(m.eq_obj2id[e])
+        if j2 < 0 or m.jnt_type[j1] == JNT_FREE or m.jnt_type[j2] == JNT_FREE:
+            raise NotImplementedError("HIP path: equality must couple two scalar joints")
+        d1, d2 = int(m.jnt_dofadr[j1]), int(m.jnt_dofadr[j2])
+        eq_i[e] = [d1, d2, m.jnt_qposadr[j1], m.jnt_qposadr[j2]]
+        eq_f[e] = [*m.eq_data[e], m.qpos0[m.jnt_qposadr[j1]], m.qpos0[m.jnt_qposadr[j2]], *m.eq_solref[e], *m.eq_solimp[e],
+                   m.dof_invweight0[d1] + m.dof_invweight0[d2], 0.0]
+    A["hip_eq_i"], A["hip_eq_f"] = eq_i, eq_f
+    A["hip_dof_qposadr"] = dof_qposadr
+    A["hip_link_free"] = link_free
+    A["hip_flags"] = np.array([int(has_free), int(A["sizes"][0]), neq], np.int32)
     A["hip_sizes"] = np.array([nl, nlevel, nv, nu, ngt, len(segs), len(dls), maxnnz, len(wgs), len(cgs), len(pairs_i),
                                maxkc, ns, len(cols), len(childs), pruned], np.int32)
     A["hip_level_adr"] = level_adr

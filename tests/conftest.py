@@ -43,3 +43,9 @@ def oracle32(hand):
 
 REFERENCE = "/root/reference/myosuite"
 needs_reference = pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree not present (GPU box)")
+
+
+@pytest.fixture(scope="session")
+def legoracle64(legs):
+    from oracle.oracle import Oracle
+    return Oracle(legs.blob())
