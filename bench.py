@@ -62,7 +62,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--env", default=ENV_ID, help="env id (default: the BASELINE.json headline workload); other ids are extra measurements")
     args = ap.parse_args()
+    env_id = args.env
 
     import torch
     from myosuite_mjx_amd import capi
@@ -81,7 +83,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP stepper has no CPU fallback")
     torch.cuda.set_device(local)
     B = args.batch
-    env = BatchedMyoEnv(ENV_ID, num_envs=B, device=local, seed=0, env_offset=rank * B)
+    env = BatchedMyoEnv(env_id, num_envs=B, device=local, seed=0, env_offset=rank * B)
     env.reset(seed=0)
     stream = torch.cuda.current_stream(local).cuda_stream
     mode = capi.BENCH_OBS | capi.BENCH_FRESH_ACTIONS | capi.BENCH_AUTORESET
@@ -126,31 +128,36 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "r1_d_pmc_step_kernel_wave.json")) as f:
             t = json.load(f)["traffic"]
-        if B == B_PER_GPU:
+        if B == B_PER_GPU and env_id == ENV_ID:
             traffic = t["hbm_bytes_per_launch_raw"]
     except Exception:
         pass
     if rank == 0:
         value = world * B * args.steps / el
-        achieved = B_ALG * B / (k_ms * 1e-3) / 1e9
+        mm = env.mjmodel
+        # algorithmic HBM bytes per env-step: SURVEY.md 8d's figure for the headline workload; for other envs the same accounting
+        # (state + action read once, state + diagnostics + observation written once)
+        b_alg = B_ALG if env_id == ENV_ID else 4.0 * ((mm.nq + 2 * mm.nv + 2 * mm.nu) + (mm.nq + 3 * mm.nv + 4 * mm.nu + env.obs_dim + 12))
+        achieved = b_alg * B / (k_ms * 1e-3) / 1e9
         out = {
-            "metric": "env-steps/s (whole node) myoHandPoseRandom-v0 batch 4096", "value": value, "unit": "env-steps/s",
+            "metric": f"env-steps/s (whole node) {env_id} batch {B}", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{ENV_ID}, {B} envs per GPU, frame_skip=10 (dt=0.002), U(-1,1) device-generated actions, "
-                                   "obs+reward+TimeLimit(100)/done auto-reset inside the timed region"
+            "config": {"workload": f"{env_id}, {B} envs per GPU, frame_skip={env.frame_skip} (dt={env.dt:g}), U(-1,1) device-generated actions, "
+                                   f"obs+reward+TimeLimit({env.max_episode_steps})/done auto-reset inside the timed region"
                                    + (", RCCL obs all-gather per step" if world > 1 else ""),
                        "global_batch": world * B, "parallelism": f"env-shard x{world}", "lanes_per_env": 64,
                        "substeps_per_s": value * env.frame_skip},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "step_kernel_w<24>", "kernel_ms": k_ms, "alg_bytes_per_launch": B_ALG * B,
+                         "traffic": traffic, "kernel": "step_kernel_w<24,8,32,1,4>" if mm.nv <= 24 else "step_kernel_w<36,20,48,2,2>", "kernel_ms": k_ms,
+                         "alg_bytes_per_launch": b_alg * B,
                          "note": "path is FP32-VALU/latency bound, not HBM bound (SURVEY.md 8d); fp32 view alongside",
                          "fp32": {"achieved_tflops_est": F_ALG_EST * B / (k_ms * 1e-3) / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
                                   "frac_est": F_ALG_EST * B / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "flop_per_env_step": "SURVEY 8d estimate"}},
             "event_ms_per_step_rank0": ev_ms / args.steps,
             "flagged_envs": int((flags != 0).sum()),
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and env_id == ENV_ID:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if dist:

@@ -69,7 +69,7 @@ enum { MYO_FLAG_BAD_STATE = 1, MYO_FLAG_BAD_QACC = 2, MYO_FLAG_CONTACT_OVERFLOW 
 enum { MYO_ACTMAP_NONE = 0, MYO_ACTMAP_MUSCLE_SIGMOID = 1 };
 
 /* tasks understood by myo_obs / myo_reset */
-typedef enum myo_task { MYO_TASK_NONE = 0, MYO_TASK_POSE = 1, MYO_TASK_REACH = 2 } myo_task;
+typedef enum myo_task { MYO_TASK_NONE = 0, MYO_TASK_POSE = 1, MYO_TASK_REACH = 2, MYO_TASK_WALK = 3 } myo_task;
 
 typedef struct myo_task_config {
   int task;              /* myo_task */
@@ -86,6 +86,22 @@ typedef struct myo_task_config {
   const float* init_qpos; /* host pointer, nq floats (copied); NULL = qpos0 */
 } myo_task_config;
 
+/* walk task (WalkEnvV0: envs/myo/myobase/walk_v0.py:187-470, registered as myoLegWalk-v0 in envs/myo/myobase/__init__.py:443-459).
+ * Observation = qpos[2:], qvel*dt, com_vel(2), torso xquat(4), feet heights(2), COM height, feet - pelvis(6), phase, muscle
+ * length / clipped velocity / clipped force/1000 (nu each), act (nu).  With this task configured, myo_step itself produces
+ * MYO_F_OBS / REWARD / DONE / SOLVED at the post-step state (one fused pass); myo_obs recomputes them without stepping. */
+typedef struct myo_walk_config {
+  int frame_skip, hip_period;
+  float min_height, max_rot, target_x_vel, target_y_vel;
+  float target_rot[4];                                         /* reference root quaternion (walk_v0.py:425-431) */
+  int body_talus_l, body_talus_r, body_pelvis, body_torso;     /* compiled-model body ids */
+  int qadr_hip_flexion_l, qadr_hip_flexion_r;                  /* qpos addresses (walk_v0.py:413-420) */
+  int qadr_joint_angle[4];                                     /* hip_adduction_l, hip_adduction_r, hip_rotation_l, hip_rotation_r */
+  float w_vel_reward, w_done, w_cyclic_hip, w_ref_rot, w_joint_angle_rew;
+  const float* init_qpos;                                      /* host, nq floats: reset pose (reset_type "init": key_qpos[2]) */
+  const float* init_qvel;                                      /* host, nv floats or NULL (zero) */
+} myo_walk_config;
+
 const char* myo_last_error(void);
 int myo_version(void);
 
@@ -99,6 +115,7 @@ int myo_batch_create(const myo_model*, int B, myo_batch** out);
 void myo_batch_free(myo_batch*);
 int myo_batch_size(const myo_batch*);
 int myo_batch_configure(myo_batch*, const myo_task_config* cfg);
+int myo_batch_configure_walk(myo_batch*, const myo_walk_config* cfg);
 /* device pointer + pitch (elements per env row) of a field */
 int myo_batch_field(myo_batch*, int field, void** dev_ptr, size_t* pitch, size_t* width);
 /* synchronous host copies (tests / plumbing without torch); host buffers are [B][width] */
@@ -115,6 +132,8 @@ int myo_step(myo_batch*, const float* action_dev, int actmap, int nsubsteps, voi
 int myo_obs(myo_batch*, void* stream);
 /* observation vector only (reward / done / solved untouched): used after an auto-reset */
 int myo_obs_only(myo_batch*, void* stream);
+/* observation vector only, and only for envs whose elapsed-step counter is 0 (i.e. those myo_autoreset just reset) */
+int myo_obs_reset_only(myo_batch*, void* stream);
 /* gym TimeLimit + done handling (envs/myo/myobase/__init__.py max_episode_steps): reset every env whose done flag is
  * set or whose elapsed env-step counter reached max_episode_steps, with the configured reset / target sampling */
 int myo_autoreset(myo_batch*, int max_episode_steps, uint64_t seed, void* stream);

@@ -36,6 +36,16 @@ class TaskConfig(C.Structure):
                 ("target_lo", C.POINTER(C.c_float)), ("target_hi", C.POINTER(C.c_float)), ("init_qpos", C.POINTER(C.c_float))]
 
 
+class WalkConfig(C.Structure):
+    """ctypes mirror of `myo_walk_config` (include/myo_hip.h)."""
+    _fields_ = [("frame_skip", C.c_int), ("hip_period", C.c_int), ("min_height", C.c_float), ("max_rot", C.c_float),
+                ("target_x_vel", C.c_float), ("target_y_vel", C.c_float), ("target_rot", C.c_float * 4),
+                ("body_talus_l", C.c_int), ("body_talus_r", C.c_int), ("body_pelvis", C.c_int), ("body_torso", C.c_int),
+                ("qadr_hip_flexion_l", C.c_int), ("qadr_hip_flexion_r", C.c_int), ("qadr_joint_angle", C.c_int * 4),
+                ("w_vel_reward", C.c_float), ("w_done", C.c_float), ("w_cyclic_hip", C.c_float), ("w_ref_rot", C.c_float),
+                ("w_joint_angle_rew", C.c_float), ("init_qpos", C.POINTER(C.c_float)), ("init_qvel", C.POINTER(C.c_float))]
+
+
 def build_library(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> libmyo_hip.so next to this file (cross-compiles without a GPU)."""
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= os.path.getmtime(SRC_PATH):
@@ -58,6 +68,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
                                "(the HIP stepper has no CPU fallback)")
+        # PyTorch-ROCm bundles its own HIP runtime.  Two HIP runtimes in one process do not share the device (the second one
+        # reports "no HIP GPUs"), so when torch is installed let it load its runtime first: libmyo_hip.so's libamdhip64
+        # dependency then resolves to that same, already loaded, library whichever side touches the GPU first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.myo_last_error.restype = C.c_char_p
         L.myo_model_load.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
@@ -86,6 +103,8 @@ def lib():
         L.myo_set_lanes.argtypes = [C.c_int]
         L.myo_set_balance.argtypes = [C.c_void_p, C.c_int]
         L.myo_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.myo_batch_configure_walk.argtypes = [C.c_void_p, C.POINTER(WalkConfig)]
+        L.myo_obs_reset_only.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -156,6 +175,27 @@ class HipBatch:
         c.target_hi = hi.ctypes.data_as(C.POINTER(C.c_float)) if hi.size else None
         c.init_qpos = iq.ctypes.data_as(C.POINTER(C.c_float)) if iq is not None else None
         _chk(lib().myo_batch_configure(self.h, C.byref(c)))
+
+    def configure_walk(self, *, frame_skip, hip_period, min_height, max_rot, target_x_vel, target_y_vel, target_rot, bodies, qadr_hip_flexion,
+                       qadr_joint_angle, weights, init_qpos, init_qvel=None):
+        """walk task (WalkEnvV0).  bodies = (talus_l, talus_r, pelvis, torso) body ids; weights = (vel_reward, done, cyclic_hip,
+        ref_rot, joint_angle_rew)."""
+        c = WalkConfig()
+        c.frame_skip, c.hip_period = int(frame_skip), int(hip_period)
+        c.min_height, c.max_rot, c.target_x_vel, c.target_y_vel = float(min_height), float(max_rot), float(target_x_vel), float(target_y_vel)
+        c.target_rot = (C.c_float * 4)(*[float(x) for x in target_rot])
+        c.body_talus_l, c.body_talus_r, c.body_pelvis, c.body_torso = [int(x) for x in bodies]
+        c.qadr_hip_flexion_l, c.qadr_hip_flexion_r = [int(x) for x in qadr_hip_flexion]
+        c.qadr_joint_angle = (C.c_int * 4)(*[int(x) for x in qadr_joint_angle])
+        c.w_vel_reward, c.w_done, c.w_cyclic_hip, c.w_ref_rot, c.w_joint_angle_rew = [float(x) for x in weights]
+        iq = np.ascontiguousarray(init_qpos, np.float32)
+        iv = np.ascontiguousarray(init_qvel, np.float32) if init_qvel is not None else None
+        c.init_qpos = iq.ctypes.data_as(C.POINTER(C.c_float))
+        c.init_qvel = iv.ctypes.data_as(C.POINTER(C.c_float)) if iv is not None else None
+        _chk(lib().myo_batch_configure_walk(self.h, C.byref(c)))
+
+    def obs_reset_only(self, stream=None):
+        _chk(lib().myo_obs_reset_only(self.h, stream))
 
     def field_ptr(self, field):
         p, pitch, width = C.c_void_p(), C.c_size_t(), C.c_size_t()

@@ -80,7 +80,22 @@ struct TaskDev {
   int tip_site[8];
   float pose_thd, far_th, near_th, w_pose, w_bonus, w_act_reg, w_penalty, w_reach;
   const float *target_lo, *target_hi, *init_qpos, *jnt_lo, *jnt_hi;
+  const float* init_qvel;   // walk task: reset velocity (NULL = zero)
 };
+
+// walk task (walk_v0.py:WalkEnvV0): its observation needs a forward pass at the post-step state, which the wave kernel
+// runs itself as one extra kinematics / tendon / velocity pass after the last substep (no second kernel, no state re-read)
+struct DevWalk {
+  int obs_dim, hip_period;
+  float dt, min_height, max_rot, target_x_vel, target_y_vel;
+  float target_rot[4];
+  int link_tl, link_tr, link_pel, link_tor;          // links holding talus_l, talus_r, pelvis, torso
+  float lpos_tl[3], lpos_tr[3], lpos_pel[3], lquat_tor[4];
+  int qadr_hfl, qadr_hfr, qadr_ja[4];
+  float w_vel, w_done, w_cyc, w_rot, w_ja;
+  float mass_total, static_mcom[3];
+};
+enum { KF_AUX = 1, KF_OBS_ONLY = 2, KF_RESET_ONLY = 4 };   // step_kernel_w flags: observation pass without stepping / without reward / only for just-reset envs
 
 // ------------------------------------------------------------------------------------------------
 // small device math
@@ -1527,7 +1542,7 @@ __device__ __forceinline__ float straight_w(const DevModel& M, const LayW& Y, fl
 template <int NVT, int KC, int NC, int NTR, int WPE>
 __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restrict__ Mp, const DevModelW* __restrict__ Wp, DevBatch Bt,
                                                         const float* __restrict__ action, int actmap, int nsub, long long* stamps,
-                                                        const int* __restrict__ order) {
+                                                        const int* __restrict__ order, const DevWalk* __restrict__ wk, int kflags) {
   extern __shared__ __align__(16) float E[];
   // the model structs stay in (scalar-cached) global memory: fields are s_load-ed where they are used instead of
   // pinning ~150 SGPRs for the whole kernel
@@ -1545,6 +1560,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   constexpr bool FULL = NVT > 24;
   const bool has_free = FULL && W.has_free;
   const int neq = FULL ? W.neq : 0;
+  const bool walk = FULL && wk != nullptr;   // fused observation / reward pass of the walk task after the last substep
+  if (FULL && (kflags & KF_RESET_ONLY) && Bt.elapsed[env] != 0) return;   // wave-uniform: refresh only the envs an auto-reset just touched
 #if MYO_STAMPS
   long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long st_t0 = clock64();
@@ -1574,7 +1591,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
   const float damping = lane_id < nv ? M.dof_damping[lane_id] : 0.f;
   SYNC();
-  for (int step = 0; step < nsub; step++) {
+  for (int step = 0; step < nsub + (walk ? 1 : 0); step++) {
+    const bool op = walk && step == nsub;   // observation pass: position / velocity stages at the post-step state, then out
     // compiler-only barrier: keeps the (substep-invariant) model-table loads inside the loop body instead of hoisting
     // ~60 values per lane out of it and spilling them to scratch
     asm volatile("" ::: "memory");
@@ -1584,7 +1602,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       bool bad = false;
       if (lane < nq) { float a = E[Y.qpos + lane]; bad = !(a == a) || fabsf(a) > MAXVALF; }
       if (lane < nv) { float b = E[Y.qvel + lane]; bad = bad || !(b == b) || fabsf(b) > MAXVALF; }
-      if (__any(bad) && alive) { flags |= MYO_FLAG_BAD_STATE; alive = false; }
+      if (__any(bad) && alive && !op) { flags |= MYO_FLAG_BAD_STATE; alive = false; }
     }
     STAMP(0);
     // ---------------------------------------------------------------- kinematics (lane = link, level by level)
@@ -1737,6 +1755,20 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     if (step == nsub - 1) {   // diagnostics of the last substep
       for (int i = lane; i < nu; i += 64) { Bt.tenlen[(size_t)env * nu + i] = E[Y.tlen + i]; Bt.actforce[(size_t)env * nu + i] = E[Y.tforce + i]; }
     }
+    if (FULL && op) {   // walk observation, muscle block (walk_v0.py:283-285,354-361): length, clipped velocity, clipped force / 1000, then act
+      float* o = Bt.obs + (size_t)env * wk->obs_dim + (nq - 2 + nv + 16);
+#pragma unroll
+      for (int rr = 0; rr < NTR; rr++) {
+        int gt = lane + 64 * rr;
+        if (gt < nu) {
+          float g = M.act[16 * gt + 14];
+          o[gt] = g * tlen_r[rr];
+          o[nu + gt] = clipf(g * tvel_r[rr], -100.f, 100.f);
+          o[2 * nu + gt] = clipf(E[Y.tforce + gt] / (g != 0.f ? g : 1.f) * 1e-3f, -100.f, 100.f);
+          o[3 * nu + gt] = E[Y.act + gt];
+        }
+      }
+    }
     SYNC();  // region X changes owner: tendon scratch -> spatial dynamics
     STAMP(2);
     // ---------------------------------------------------------------- CRB + RNE (lane = link / dof)
@@ -1816,6 +1848,79 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         for (int k = 0; k < 6; k++) { E[Y.cvel + 6 * l + k] = cvel[k]; E[Y.cacc + 6 * l + k] = cacc[k]; E[Y.cfrc + 6 * l + k] = f[k] + t1[k]; }
       }
       SYNC();
+    }
+    if (FULL && op) {
+      // ---- walk observation / reward (walk_v0.py:268-316, 363-470) from link frames and link velocities of this pass
+      float* o = Bt.obs + (size_t)env * wk->obs_dim;
+      if (lane < nq - 2) o[lane] = E[Y.qpos + 2 + lane];                    // qpos_without_xy
+      if (lane < nv) o[nq - 2 + lane] = E[Y.qvel + lane] * wk->dt;          // qvel * dt
+      float mc[3] = {0.f, 0.f, 0.f}, ml = 0.f;
+      if (lane < M.nl) {
+        float cw[3];
+        matvec(cw, E + Y.lmat + 9 * lane, M.link_com + 3 * lane);
+        ml = M.link_mass[lane];
+#pragma unroll
+        for (int k = 0; k < 3; k++) mc[k] = ml * (E[Y.lpos + 3 * lane + k] + cw[k]);
+      }
+      const float mmov = wave_sum(ml);
+      const float sx = wave_sum(mc[0]), sy = wave_sum(mc[1]), sz = wave_sum(mc[2]);
+      // MuJoCo's cvel is the velocity of the body-fixed point that coincides with the root's subtree COM (COM of the moving bodies)
+      const float cm[3] = {sx / mmov, sy / mmov, sz / mmov};
+      float mv[2] = {0.f, 0.f};
+      if (lane < M.nl) {
+        const float* cv = E + Y.cvel + 6 * lane;
+        float r[3] = {cm[0] - c0[0], cm[1] - c0[1], cm[2] - c0[2]}, wr[3];
+        cross3(wr, cv, r);
+        mv[0] = ml * (cv[3] + wr[0]); mv[1] = ml * (cv[4] + wr[1]);
+      }
+      const float cvx = -wave_sum(mv[0]) / wk->mass_total, cvy = -wave_sum(mv[1]) / wk->mass_total;   // walk_v0.py:438-444 (note the minus)
+      const float height = (sz + wk->static_mcom[2]) / wk->mass_total;                                  // walk_v0.py:446-450,465-470
+      if (lane == 0) {
+        const int sb = nq - 2 + nv;
+        o[sb] = cvx; o[sb + 1] = cvy;
+        float q[4] = {E[Y.qpos + 3], E[Y.qpos + 4], E[Y.qpos + 5], E[Y.qpos + 6]};
+        float qn = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        float u[4] = {q[0] * qn, q[1] * qn, q[2] * qn, q[3] * qn};
+        const float* t = wk->lquat_tor;
+        float tq[4] = {u[0] * t[0] - u[1] * t[1] - u[2] * t[2] - u[3] * t[3], u[0] * t[1] + u[1] * t[0] + u[2] * t[3] - u[3] * t[2],
+                       u[0] * t[2] - u[1] * t[3] + u[2] * t[0] + u[3] * t[1], u[0] * t[3] + u[1] * t[2] - u[2] * t[1] + u[3] * t[0]};
+        float tn = 1.0f / sqrtf(tq[0] * tq[0] + tq[1] * tq[1] + tq[2] * tq[2] + tq[3] * tq[3]);
+        o[sb + 2] = tq[0] * tn; o[sb + 3] = tq[1] * tn; o[sb + 4] = tq[2] * tn; o[sb + 5] = tq[3] * tn;   // torso xquat
+        float pl[3], pr[3], pp[3], v[3];
+        matvec(v, E + Y.lmat + 9 * wk->link_tl, wk->lpos_tl);
+#pragma unroll
+        for (int k = 0; k < 3; k++) pl[k] = E[Y.lpos + 3 * wk->link_tl + k] + v[k];
+        matvec(v, E + Y.lmat + 9 * wk->link_tr, wk->lpos_tr);
+#pragma unroll
+        for (int k = 0; k < 3; k++) pr[k] = E[Y.lpos + 3 * wk->link_tr + k] + v[k];
+        matvec(v, E + Y.lmat + 9 * wk->link_pel, wk->lpos_pel);
+#pragma unroll
+        for (int k = 0; k < 3; k++) pp[k] = E[Y.lpos + 3 * wk->link_pel + k] + v[k];
+        o[sb + 6] = pl[2]; o[sb + 7] = pr[2];                                    // feet heights (talus_l, talus_r)
+        o[sb + 8] = height;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { o[sb + 9 + k] = pl[k] - pp[k]; o[sb + 12 + k] = pr[k] - pp[k]; }   // feet relative to the pelvis
+        const float phase = fmodf((float)Bt.elapsed[env] / (float)wk->hip_period, 1.0f);
+        o[sb + 15] = phase;
+        if (!(kflags & KF_OBS_ONLY)) {
+          float dvy = wk->target_y_vel - cvy, dvx = wk->target_x_vel - cvx;
+          float vel_reward = expf(-dvy * dvy) + expf(-dvx * dvx);
+          float d0 = 0.8f * cosf(phase * 6.283185307179586f + 3.141592653589793f) - E[Y.qpos + wk->qadr_hfl];
+          float d1 = 0.8f * cosf(phase * 6.283185307179586f) - E[Y.qpos + wk->qadr_hfr];
+          float cyclic = sqrtf(d0 * d0 + d1 * d1);
+          float dq[4] = {q[0] - wk->target_rot[0], q[1] - wk->target_rot[1], q[2] - wk->target_rot[2], q[3] - wk->target_rot[3]};
+          float ref_rot = expf(-5.0f * sqrtf(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]));
+          float mag = 0.25f * (fabsf(E[Y.qpos + wk->qadr_ja[0]]) + fabsf(E[Y.qpos + wk->qadr_ja[1]]) + fabsf(E[Y.qpos + wk->qadr_ja[2]]) +
+                               fabsf(E[Y.qpos + wk->qadr_ja[3]]));
+          float ja = expf(-5.0f * mag);
+          float r00 = 1.0f - 2.0f * (q[2] * q[2] + q[3] * q[3]) / (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+          float done = (height < wk->min_height || fabsf(r00) > wk->max_rot) ? 1.f : 0.f;
+          Bt.reward[env] = wk->w_vel * vel_reward + wk->w_done * done + wk->w_cyc * cyclic + wk->w_rot * ref_rot + wk->w_ja * ja;
+          Bt.done[env] = done;
+          Bt.solved[env] = vel_reward >= 1.0f ? 1.f : 0.f;
+        }
+      }
+      break;
     }
     for (int L = M.nlevel - 2; L >= 0; L--) {
       int l = M.level_adr[L] + lane;
@@ -2414,6 +2519,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     SYNC();
     STAMP(8);
   }
+  if (FULL && (kflags & KF_AUX)) return;   // observation-only launch: the state arrays are not touched
   if (!alive) {  // a bad env is reset like mj_resetData (mj_sim_scene.py:56-61)
     if (lane_id < nq) E[Y.qpos + lane_id] = M.qpos0[lane_id];
     if (lane_id < nv) { E[Y.qvel + lane_id] = 0; warm = 0; }
@@ -2509,7 +2615,7 @@ __global__ void reset_kernel(DevBatch Bt, TaskDev T, int nq, int nv, int nu, con
     Bt.qpos[(size_t)e * nq + i] = q;
   }
   for (int i = 0; i < nv; i++) {
-    Bt.qvel[(size_t)e * nv + i] = 0;
+    Bt.qvel[(size_t)e * nv + i] = T.init_qvel ? T.init_qvel[i] : 0.f;
     Bt.warm[(size_t)e * nv + i] = 0;
   }
   for (int i = 0; i < nu; i++) { Bt.act[(size_t)e * nu + i] = 0; Bt.ctrl[(size_t)e * nu + i] = 0; }
@@ -2625,6 +2731,8 @@ struct myo_model {
   myo_dims dims{};
   std::vector<void*> dev_allocs;
   std::vector<float> qpos0, jnt_lo, jnt_hi;
+  std::vector<int> body_link;                       // body -> link, pose of the body inside the link frame (walk task)
+  std::vector<float> body_lpos, body_lquat, mass;   // mass = [total, static bodies' mass-weighted COM xyz]
   float* d_qpos0 = nullptr;
   int env_lds_bytes = 0;
 };
@@ -2636,6 +2744,8 @@ struct myo_batch {
   int ntarget_alloc = 0, obs_alloc = 0, env_offset = 0;
   std::vector<void*> dev_allocs;
   float *d_tlo = nullptr, *d_thi = nullptr, *d_init = nullptr, *d_jlo = nullptr, *d_jhi = nullptr, *d_action = nullptr;
+  float* d_initv = nullptr;
+  DevWalk* d_walk = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint64_t bench_step = 0;
   long long* d_stamps = nullptr;
@@ -2822,6 +2932,9 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
           (rc = load_i(m, blob, "hip_dof_qposadr", &w.dof_qposadr)) || (rc = load_i(m, blob, "hip_eq_i", &w.eq_i)) ||
           (rc = load_f(m, blob, "hip_eq_f", &w.eq_f)) || (rc = load_i(m, blob, "hip_pair_i", &tmpi, &pi))) { myo_model_free(m); return rc; }
       w.has_free = fl[0]; w.nq = fl[1]; w.neq = fl[2];
+      const float* tf;
+      if ((rc = load_i(m, blob, "hip_body_link", &tmpi, &m->body_link)) || (rc = load_f(m, blob, "hip_body_lpos", &tf, &m->body_lpos)) ||
+          (rc = load_f(m, blob, "hip_body_lquat", &tf, &m->body_lquat)) || (rc = load_f(m, blob, "hip_mass", &tf, &m->mass))) { myo_model_free(m); return rc; }
       if (w.nq != m->nq) { myo_model_free(m); return fail(MYO_E_BLOB, "hip_flags disagrees with sizes"); }
       for (int p = 0; p < d.npair; p++) { if (pi[6 * p + 4] >= 2) plane_pairs = true; if (pi[6 * p + 5] == 1) condim1 = true; }
       // the 16/32-lane generic kernel covers fixed-base models with hinge / slide joints and capsule / convex pairs only
@@ -2885,7 +2998,7 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   d.B = B;
   int nv = m->dm.nv, nu = m->dm.nu, nq = m->nq, rc;
   b->ntarget_alloc = nv > 24 ? nv : 24;
-  b->obs_alloc = 3 * nv + 2 * nu + 64;
+  b->obs_alloc = 3 * nv + 4 * nu + 64;
 #define BA(ptr, n) if ((rc = balloc(b, (void**)&ptr, (size_t)(n) * 4))) { myo_batch_free(b); return rc; }
   BA(d.qpos, (size_t)B * nq) BA(d.qvel, (size_t)B * nv) BA(d.act, (size_t)B * nu) BA(d.ctrl, (size_t)B * nu) BA(d.warm, (size_t)B * nv)
   BA(d.time, B) BA(d.target, (size_t)B * b->ntarget_alloc) BA(d.obs, (size_t)B * b->obs_alloc) BA(d.reward, B) BA(d.done, B)
@@ -2893,6 +3006,8 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   BA(d.flags, B) BA(d.diag, (size_t)B * 8) BA(d.elapsed, B) BA(d.episode, B)
   BA(b->d_tlo, b->ntarget_alloc) BA(b->d_thi, b->ntarget_alloc) BA(b->d_init, nq) BA(b->d_jlo, nv) BA(b->d_jhi, nv)
   BA(b->d_action, (size_t)B * nu)
+  BA(b->d_initv, nv)
+  { void* pw = nullptr; if ((rc = balloc(b, &pw, sizeof(DevWalk)))) { myo_batch_free(b); return rc; } b->d_walk = (DevWalk*)pw; }
   BA(b->d_stamps, (size_t)B * 12 * 2)
   BA(b->d_order, B)
 #undef BA
@@ -2906,6 +3021,7 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   HIPCHK(hipMemcpy(d.qpos, q.data(), q.size() * 4, hipMemcpyHostToDevice));
   b->task.task = MYO_TASK_NONE; b->task.frame_skip = 1; b->task.obs_dim = 0; b->task.ntarget = 0;
   b->task.jnt_lo = b->d_jlo; b->task.jnt_hi = b->d_jhi; b->task.init_qpos = b->d_init; b->task.target_lo = b->d_tlo; b->task.target_hi = b->d_thi;
+  b->task.init_qvel = nullptr;
   HIPCHK(hipEventCreate(&b->ev0));
   HIPCHK(hipEventCreate(&b->ev1));
   *out = b;
@@ -2929,6 +3045,8 @@ int myo_batch_configure(myo_batch* b, const myo_task_config* c) {
   TaskDev& T = b->task;
   int nv = dm.nv, nu = dm.nu;
   if (c->ntarget > b->ntarget_alloc || c->ntip > 8) return fail(MYO_E_ARG, "myo_batch_configure: ntarget/ntip too large");
+  if (c->task == MYO_TASK_WALK) return fail(MYO_E_ARG, "use myo_batch_configure_walk for the walk task");
+  T.init_qvel = nullptr;
   T.task = c->task; T.frame_skip = c->frame_skip; T.reset_random = c->reset_random; T.target_generate = c->target_generate;
   T.ntarget = c->ntarget; T.ntip = c->ntip;
   for (int i = 0; i < 8; i++) T.tip_site[i] = c->tip_site[i];
@@ -2945,6 +3063,45 @@ int myo_batch_configure(myo_batch* b, const myo_task_config* c) {
   }
   if (c->reset_random && b->model->nq != nv) return fail(MYO_E_ARG, "reset_random needs a model without free / ball joints");
   HIPCHK(hipMemcpy(b->d_init, c->init_qpos ? c->init_qpos : b->model->qpos0.data(), b->model->nq * 4, hipMemcpyHostToDevice));
+  return MYO_OK;
+}
+
+int myo_batch_configure_walk(myo_batch* b, const myo_walk_config* c) {
+  if (!b || !c) return fail(MYO_E_ARG, "myo_batch_configure_walk: null");
+  const myo_model* m = b->model;
+  const DevModel& dm = m->dm;
+  const int nq = m->nq, nv = dm.nv, nu = dm.nu, nb = (int)m->body_link.size();
+  if (!(m->wave_ok && m->wave_cfg == 1 && m->dw.has_free)) return fail(MYO_E_UNSUPPORTED, "walk task needs a free-floating model on the large wave kernel");
+  const int bodies[4] = {c->body_talus_l, c->body_talus_r, c->body_pelvis, c->body_torso};
+  for (int k = 0; k < 4; k++) if (bodies[k] < 1 || bodies[k] >= nb || m->body_link[bodies[k]] < 0) return fail(MYO_E_ARG, "walk task: bad body id");
+  if (m->body_link[c->body_torso] != 0) return fail(MYO_E_UNSUPPORTED, "walk task: torso must be welded to the free root body");
+  const int qa[6] = {c->qadr_hip_flexion_l, c->qadr_hip_flexion_r, c->qadr_joint_angle[0], c->qadr_joint_angle[1], c->qadr_joint_angle[2], c->qadr_joint_angle[3]};
+  for (int k = 0; k < 6; k++) if (qa[k] < 0 || qa[k] >= nq) return fail(MYO_E_ARG, "walk task: bad qpos address");
+  if (c->frame_skip <= 0 || c->hip_period <= 0 || !c->init_qpos) return fail(MYO_E_ARG, "walk task: frame_skip, hip_period, init_qpos required");
+  DevWalk w{};
+  w.obs_dim = (nq - 2) + nv + 16 + 4 * nu;
+  if (w.obs_dim > b->obs_alloc) return fail(MYO_E_ARG, "obs_dim too large");
+  w.hip_period = c->hip_period; w.dt = (float)c->frame_skip * dm.timestep;
+  w.min_height = c->min_height; w.max_rot = c->max_rot; w.target_x_vel = c->target_x_vel; w.target_y_vel = c->target_y_vel;
+  for (int k = 0; k < 4; k++) { w.target_rot[k] = c->target_rot[k]; w.lquat_tor[k] = m->body_lquat[4 * c->body_torso + k]; w.qadr_ja[k] = c->qadr_joint_angle[k]; }
+  w.link_tl = m->body_link[c->body_talus_l]; w.link_tr = m->body_link[c->body_talus_r];
+  w.link_pel = m->body_link[c->body_pelvis]; w.link_tor = m->body_link[c->body_torso];
+  for (int k = 0; k < 3; k++) {
+    w.lpos_tl[k] = m->body_lpos[3 * c->body_talus_l + k]; w.lpos_tr[k] = m->body_lpos[3 * c->body_talus_r + k];
+    w.lpos_pel[k] = m->body_lpos[3 * c->body_pelvis + k]; w.static_mcom[k] = m->mass[1 + k];
+  }
+  w.qadr_hfl = c->qadr_hip_flexion_l; w.qadr_hfr = c->qadr_hip_flexion_r;
+  w.w_vel = c->w_vel_reward; w.w_done = c->w_done; w.w_cyc = c->w_cyclic_hip; w.w_rot = c->w_ref_rot; w.w_ja = c->w_joint_angle_rew;
+  w.mass_total = m->mass[0];
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(b->d_walk, &w, sizeof w, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->d_init, c->init_qpos, (size_t)nq * 4, hipMemcpyHostToDevice));
+  if (c->init_qvel) HIPCHK(hipMemcpy(b->d_initv, c->init_qvel, (size_t)nv * 4, hipMemcpyHostToDevice));
+  TaskDev& T = b->task;
+  T.task = MYO_TASK_WALK; T.frame_skip = c->frame_skip; T.reset_random = 0; T.target_generate = 0; T.ntarget = 0; T.ntip = 0;
+  T.obs_dim = w.obs_dim;
+  T.init_qvel = c->init_qvel ? b->d_initv : nullptr;
   return MYO_OK;
 }
 
@@ -3045,8 +3202,10 @@ int myo_set_state(myo_batch* b, const float* qpos, const float* qvel, const floa
   return MYO_OK;
 }
 
-static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, hipStream_t s) {
+static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, hipStream_t s, int kflags = 0) {
   const myo_model* m = b->model;
+  const DevWalk* wk = b->task.task == MYO_TASK_WALK ? b->d_walk : nullptr;
+  if (kflags && !(wk && g_lanes == 64)) return fail(MYO_E_ARG, "observation pass: walk task on the wave kernel only");
   // models the wave kernel cannot take fall back to 16 lanes; models only the wave kernel can take always use it
   const int G = (g_lanes == 64 && !m->wave_ok) ? 16 : ((g_lanes != 64 && !m->generic_ok) ? 64 : g_lanes), EPW = 64 / G;
   int grid = (b->db.B + EPW - 1) / EPW;
@@ -3071,16 +3230,16 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     }
     const int* order = nullptr;
     int Bn = b->db.B;
-    if (b->balance && Bn >= 1024 && Bn % 4 == 0) {
+    if (b->balance && Bn >= 1024 && Bn % 4 == 0 && !kflags) {
       hipLaunchKernelGGL(balance_kernel, dim3(1), dim3(1024), 0, s, (const int*)b->db.diag, Bn, b->d_order, Bn / 4);
       order = b->d_order;
     }
     if (m->wave_cfg == 0)
       hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
-                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order);
+                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0);
     else
       hipLaunchKernelGGL((step_kernel_w<36, 20, 48, 2, 2>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
-                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order);
+                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, wk, kflags);
     HIPCHK(hipGetLastError());
     return MYO_OK;
   }
@@ -3097,10 +3256,13 @@ int myo_step(myo_batch* b, const float* action_dev, int actmap, int nsubsteps, v
   return launch_step(b, action_dev, actmap, nsubsteps, (hipStream_t)stream);
 }
 
-static int launch_obs(myo_batch* b, hipStream_t s, int obs_only = 0) {
+static int launch_obs(myo_batch* b, hipStream_t s, int obs_only = 0, int reset_only = 0) {
   const myo_model* m = b->model;
   int B = b->db.B;
-  if (b->task.task == MYO_TASK_POSE) {
+  if (b->task.task == MYO_TASK_WALK) {
+    // the walk observation lives in the step kernel: run it with zero substeps as an observation-only pass
+    return launch_step(b, nullptr, MYO_ACTMAP_NONE, 0, s, KF_AUX | (obs_only ? KF_OBS_ONLY : 0) | (reset_only ? KF_RESET_ONLY : 0));
+  } else if (b->task.task == MYO_TASK_POSE) {
     hipLaunchKernelGGL(obs_kernel, dim3((B + 63) / 64), dim3(64), 0, s, m->dm, b->db, b->task, obs_only);
   } else if (b->task.task == MYO_TASK_REACH) {
     const int EPW = 4;
@@ -3122,6 +3284,12 @@ int myo_obs_only(myo_batch* b, void* stream) {
   if (!b) return fail(MYO_E_ARG, "myo_obs_only: null");
   HIPCHK(hipSetDevice(b->model->device));
   return launch_obs(b, (hipStream_t)stream, 1);
+}
+
+int myo_obs_reset_only(myo_batch* b, void* stream) {
+  if (!b) return fail(MYO_E_ARG, "myo_obs_reset_only: null");
+  HIPCHK(hipSetDevice(b->model->device));
+  return launch_obs(b, (hipStream_t)stream, 1, 1);
 }
 
 int myo_status(myo_batch* b, int32_t* host_flags) {
@@ -3181,10 +3349,10 @@ int myo_bench_rollout(myo_batch* b, int steps, int nsubsteps, uint64_t seed, int
     rc = launch_step(b, b->d_action, MYO_ACTMAP_MUSCLE_SIGMOID, nsubsteps, s);
     if (rc) return rc;
     HIPCHK(hipEventRecord(b->kev[2 * i + 1], s));
-    if ((mode & MYO_BENCH_OBS) && b->task.task != MYO_TASK_NONE) { rc = launch_obs(b, s); if (rc) return rc; }
+    if ((mode & MYO_BENCH_OBS) && b->task.task != MYO_TASK_NONE && b->task.task != MYO_TASK_WALK) { rc = launch_obs(b, s); if (rc) return rc; }   // walk: fused into the step launch
     if ((mode & MYO_BENCH_AUTORESET) && max_episode_steps > 0) {
       rc = myo_autoreset(b, max_episode_steps, seed, stream); if (rc) return rc;
-      if ((mode & MYO_BENCH_OBS) && b->task.task != MYO_TASK_NONE) { rc = launch_obs(b, s, 1); if (rc) return rc; }
+      if ((mode & MYO_BENCH_OBS) && b->task.task != MYO_TASK_NONE) { rc = launch_obs(b, s, 1, 1); if (rc) return rc; }
     }
   }
   HIPCHK(hipEventRecord(b->ev1, s));

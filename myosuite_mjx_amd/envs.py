@@ -78,9 +78,14 @@ REGISTRY["myoFingerPoseFixed-v0"] = _pose_spec([0, 0, 0.75, 0.75], [0, 0, 0.75, 
 REGISTRY["myoFingerPoseRandom-v0"] = _pose_spec([-0.2, -0.4, 0.1, 0.1], [0.2, 1.0, 1.0, 1.0], "init", "generate", 0.35, "myofinger_v0")
 for _k in range(10):
     REGISTRY[f"myoHandPose{_k}Fixed-v0"] = _pose_spec(ASL_QPOS[_k], ASL_QPOS[_k], "init", "fixed")
-# registered by the reference but not runnable on the HIP path yet (DESIGN.md "out of scope this round")
+# myoLegWalk-v0 (envs/myo/myobase/__init__.py:443-459; WalkEnvV0 defaults walk_v0.py:187-266)
+REGISTRY["myoLegWalk-v0"] = dict(
+    model="myolegs", task="walk", max_episode_steps=1000, frame_skip=10, normalize_act=True, reset_type="init",
+    min_height=0.8, max_rot=0.8, hip_period=100, target_x_vel=0.0, target_y_vel=1.2, target_rot=None,
+    weights=dict(vel_reward=5.0, done=-100.0, cyclic_hip=-10.0, ref_rot=10.0, joint_angle_rew=5.0))
+# registered by the reference but not runnable on the HIP path (DESIGN.md "out of scope")
 UNSUPPORTED = {
-    "myoLegWalk-v0": "leg model needs free/slide joints, equality rows and plane contacts in the HIP kernel",
+    "myoLegRoughTerrainWalk-v0": "height-field terrain contacts are not implemented in the HIP kernel",
 }
 
 
@@ -142,6 +147,24 @@ class BatchedMyoEnv:
                                  pose_thd=spec["pose_thd"], far_th=4 * np.pi / 2,
                                  w_pose=w["pose"], w_bonus=w["bonus"], w_act_reg=w["act_reg"], w_penalty=w["penalty"])
             self.obs_dim = 3 * m.nq + m.na
+        elif spec["task"] == "walk":
+            key_qpos = np.asarray(m.key_qpos).reshape(-1, m.nq)
+            key_qvel = np.asarray(m.key_qvel).reshape(-1, m.nv)
+            # walk_v0.py:254 init_qpos = key_qpos[0] (the reference orientation of ref_rot); reset "init" starts from keyframe 2
+            # (walk_v0.py:339-349), "random" is host-side only in the reference and not offered here
+            if spec["reset_type"] != "init":
+                raise NotImplementedError("myoLegWalk: only reset_type='init' (keyframe 2) is implemented")
+            jadr = lambda n: int(m.jnt_qposadr[m.name2id("joint", n)])
+            self.batch.configure_walk(
+                frame_skip=self.frame_skip, hip_period=spec["hip_period"], min_height=spec["min_height"], max_rot=spec["max_rot"],
+                target_x_vel=spec["target_x_vel"], target_y_vel=spec["target_y_vel"],
+                target_rot=spec["target_rot"] if spec["target_rot"] is not None else key_qpos[0][3:7],
+                bodies=[m.name2id("body", n) for n in ("talus_l", "talus_r", "pelvis", "torso")],
+                qadr_hip_flexion=[jadr("hip_flexion_l"), jadr("hip_flexion_r")],
+                qadr_joint_angle=[jadr(n) for n in ("hip_adduction_l", "hip_adduction_r", "hip_rotation_l", "hip_rotation_r")],
+                weights=[w[k] for k in ("vel_reward", "done", "cyclic_hip", "ref_rot", "joint_angle_rew")],
+                init_qpos=key_qpos[2], init_qvel=key_qvel[2])
+            self.obs_dim = (m.nq - 2) + m.nv + 16 + 4 * m.nu
         else:
             tips = [m.name2id("site", t) for t in spec["tips"]]
             n = len(tips)
@@ -200,7 +223,8 @@ class BatchedMyoEnv:
             # host actions go through the CTRL field: apply the muscle sigmoid here (base_v0.py:87-91)
             self.batch.write(capi.F_CTRL, 1.0 / (1.0 + np.exp(-5.0 * (a - 0.5))))
             self.batch.step(None, capi.ACTMAP_NONE, self.frame_skip, s)
-        self.batch.obs(s)
+        if self.spec["task"] != "walk":      # the walk task's observation / reward pass is fused into the step kernel
+            self.batch.obs(s)
         if self.as_torch:
             reward = self.view(capi.F_REWARD)[:, 0].clone()
             done = self.view(capi.F_DONE)[:, 0] > 0
@@ -214,7 +238,7 @@ class BatchedMyoEnv:
             solved = self.batch.read(capi.F_SOLVED)[:, 0] > 0
         if self.autoreset:
             self.batch.autoreset(self.max_episode_steps, self._episode_seed, s)
-            self.batch.obs_only(s)
+            self.batch.obs_reset_only(s)
         info = {"solved": solved, "time": self.view(capi.F_TIME)}
         return self.view(capi.F_OBS), reward, done, truncated, info
 

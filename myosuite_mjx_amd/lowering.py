@@ -432,6 +432,20 @@ def lower(cm):
         eq_f[e] = [*m.eq_data[e], m.qpos0[m.jnt_qposadr[j1]], m.qpos0[m.jnt_qposadr[j2]], *m.eq_solref[e], *m.eq_solimp[e],
                    m.dof_invweight0[d1] + m.dof_invweight0[d2], 0.0]
     A["hip_eq_i"], A["hip_eq_f"] = eq_i, eq_f
+    # every body's pose inside its link frame (walk-task observations read body positions / orientations): the quaternion is the
+    # product of the body_quat chain from the link's head body, as mj_kinematics accumulates it (no sign canonicalisation)
+    body_lquat = np.zeros((nb, 4))
+    body_lquat[:, 0] = 1.0
+    for b in range(1, nb):
+        if m.body_jntnum[b] == 0 and head[b]:
+            body_lquat[b] = quat_mul(body_lquat[m.body_parentid[b]], m.body_quat[b])
+    A["hip_body_link"] = body_link
+    A["hip_body_lpos"] = np.array([prel[b] if head[b] else (xpos0[b] - A["hip_origin"]) for b in range(nb)])
+    A["hip_body_lquat"] = np.array([body_lquat[b] if head[b] else xquat0[b] for b in range(nb)])
+    # total mass and the (constant) mass-weighted COM of the world-welded bodies, for whole-model COM observations
+    xipos0 = [xpos0[b] + quat2mat(xquat0[b]) @ m.body_ipos[b] for b in range(nb)]
+    st = [b for b in range(nb) if not head[b]]
+    A["hip_mass"] = np.array([float(np.sum(m.body_mass)), *(sum((m.body_mass[b] * (xipos0[b] - A["hip_origin"]) for b in st), np.zeros(3)))])
     A["hip_dof_qposadr"] = dof_qposadr
     A["hip_link_free"] = link_free
     A["hip_flags"] = np.array([int(has_free), int(A["sizes"][0]), neq], np.int32)

@@ -66,7 +66,11 @@ def test_registry_matches_reference_specs():
     assert np.allclose(f["target_lo"], HAND_POSE_FIXED) and f["reset_type"] == "init"
     rr = REGISTRY["myoHandReachRandom-v0"]
     assert rr["far_th"] == 0.034 and np.allclose(rr["target_lo"][:3], [-0.185, -0.577, 1.455]) and np.allclose(rr["target_hi"][:3], [-0.125, -0.517, 1.535])
-    assert "myoLegWalk-v0" in UNSUPPORTED
+    assert "myoLegRoughTerrainWalk-v0" in UNSUPPORTED
+    lw = REGISTRY["myoLegWalk-v0"]                               # envs/myo/myobase/__init__.py:443-459, walk_v0.py:203-209
+    assert lw["model"] == "myolegs" and lw["max_episode_steps"] == 1000 and lw["frame_skip"] == 10 and lw["reset_type"] == "init"
+    assert (lw["min_height"], lw["max_rot"], lw["hip_period"], lw["target_x_vel"], lw["target_y_vel"]) == (0.8, 0.8, 100, 0.0, 1.2)
+    assert lw["weights"] == dict(vel_reward=5.0, done=-100.0, cyclic_hip=-10.0, ref_rot=10.0, joint_angle_rew=5.0)
     ff = REGISTRY["myoFingerPoseFixed-v0"]                       # envs/myo/myobase/__init__.py:222-236
     assert ff["model"] == "myofinger_v0" and ff["pose_thd"] == 0.35 and ff["target_lo"].tolist() == [0, 0, 0.75, 0.75]
 
