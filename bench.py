@@ -137,7 +137,8 @@ def main():
         mm = env.mjmodel
         # algorithmic HBM bytes per env-step: SURVEY.md 8d's figure for the headline workload; for other envs the same accounting
         # (state + action read once, state + diagnostics + observation written once)
-        b_alg = B_ALG if env_id == ENV_ID else 4.0 * ((mm.nq + 2 * mm.nv + 2 * mm.nu) + (mm.nq + 3 * mm.nv + 4 * mm.nu + env.obs_dim + 12))
+        # (state + action read once, state + observation + reward/done written once; L-walk: 3 412 B)
+        b_alg = B_ALG if env_id == ENV_ID else 4.0 * ((mm.nq + 2 * mm.nv + 2 * mm.nu + 1) + (mm.nq + 2 * mm.nv + mm.nu + 1) + env.obs_dim + 2)
         achieved = b_alg * B / (k_ms * 1e-3) / 1e9
         out = {
             "metric": f"env-steps/s (whole node) {env_id} batch {B}", "value": value, "unit": "env-steps/s",
