@@ -140,3 +140,32 @@ def test_functional_mjx_style_api(hand):
     myo.step(m, d, np.full((4, 39), 0.3, np.float32), nsubsteps=5)
     assert np.allclose(myo.get(d, "time"), 5 * 0.002, atol=1e-7) and myo.get(d, "qpos").shape == (4, 23)
     assert (myo.get(d, "act") > 0).all()
+
+
+def test_hip_sim_scene_mirrors_the_backend_abc(hand, oracle64):
+    """HipSimScene = batched `SimScene` (physics/sim_scene.py:38-209): advance / forward / reset / get_state / set_state,
+    checked like Robot.step drives it (data.ctrl[:] = ...; sim.advance(n_frames)) against the oracle."""
+    import myosuite_mjx_amd as myo
+    B = 6
+    sim = myo.HipSimScene("myohand_pose", num_envs=B)
+    assert abs(sim.step_duration - 0.002) < 1e-9 and sim.init_qpos.shape == (23,) and sim.data.qpos.shape == (B, 23)
+    rng = np.random.default_rng(0)
+    lo, hi = hand.jnt_range[:, 0], hand.jnt_range[:, 1]
+    q = (0.5 * (lo + hi) + 0.4 * (hi - lo) * rng.uniform(-1, 1, (B, 23))).astype(np.float32)
+    v = rng.normal(0, 0.3, (B, 23)).astype(np.float32)
+    a = rng.uniform(0, 1, (B, 39)).astype(np.float32)
+    sim.set_state(time=np.zeros((B, 1)), qpos=q, qvel=v, act=a)
+    sim.data.ctrl[:] = rng.uniform(0, 1, (B, 39))
+    sim.advance(substeps=10)
+    assert (sim.last_flags == 0).all() and np.allclose(sim.data.time, 0.02, atol=1e-6)
+    st = sim.get_state()
+    for e in range(B):
+        oracle64.reset()
+        oracle64.set_state(qpos=q[e], qvel=v[e], act=a[e], ctrl=sim.data.ctrl[e])
+        oracle64.step(10)
+        assert np.abs(oracle64.field("qpos") - st["qpos"][e]).max() < 1e-4
+        assert np.abs(oracle64.field("qvel") - st["qvel"][e]).max() < 2e-2
+    sim.reset()
+    assert np.allclose(sim.data.qpos, hand.qpos0) and not sim.data.qvel.any() and not sim.data.time.any()
+    sim.advance(1)
+    assert np.isfinite(sim.data.qpos).all()
