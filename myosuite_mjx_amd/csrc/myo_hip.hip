@@ -440,35 +440,41 @@ __device__ __forceinline__ void make_frame(const float* n, float* t1, float* t2)
 // ------------------------------------------------------------------------------------------------
 // convex collision for ellipsoid pads: margin-inflated MPR (float twin of the oracle's mpr_penetration)
 struct CObj { float pos[3], mat[9], size[3]; int type; float margin; };  // by value: keeps everything in registers
-__device__ void support_world(const CObj& o, const float* dir, float* out) {
-  float dl[3], pl[3];
-  matTvec(dl, o.mat, dir);
-  if (o.type == GEOM_ELLIPSOID) {
-    float s[3] = {o.size[0] * dl[0], o.size[1] * dl[1], o.size[2] * dl[2]};
+// support point of the un-inflated shape in its own frame, for a direction given in that frame
+__device__ __forceinline__ void support_local(int type, const float* size, const float* dl, float* pl) {
+  if (type == GEOM_ELLIPSOID) {
+    float s[3] = {size[0] * dl[0], size[1] * dl[1], size[2] * dl[2]};
     float n = norm3(s);
     float inv = n > MINVALF ? 1.0f / n : 0.f;
-    pl[0] = o.size[0] * s[0] * inv; pl[1] = o.size[1] * s[1] * inv; pl[2] = o.size[2] * s[2] * inv;
-  } else if (o.type == GEOM_CYLINDER) {
+    pl[0] = size[0] * s[0] * inv; pl[1] = size[1] * s[1] * inv; pl[2] = size[2] * s[2] * inv;
+  } else if (type == GEOM_CYLINDER) {
     float n = sqrtf(dl[0] * dl[0] + dl[1] * dl[1]);
-    float inv = n > MINVALF ? o.size[0] / n : 0.f;
-    pl[0] = dl[0] * inv; pl[1] = dl[1] * inv; pl[2] = dl[2] >= 0 ? o.size[1] : -o.size[1];
+    float inv = n > MINVALF ? size[0] / n : 0.f;
+    pl[0] = dl[0] * inv; pl[1] = dl[1] * inv; pl[2] = dl[2] >= 0 ? size[1] : -size[1];
   } else {  // sphere / capsule
     float n = norm3(dl);
-    float inv = n > MINVALF ? o.size[0] / n : 0.f;
+    float inv = n > MINVALF ? size[0] / n : 0.f;
     pl[0] = dl[0] * inv; pl[1] = dl[1] * inv; pl[2] = dl[2] * inv;
-    if (o.type == GEOM_CAPSULE) pl[2] += dl[2] >= 0 ? o.size[1] : -o.size[1];
+    if (type == GEOM_CAPSULE) pl[2] += dl[2] >= 0 ? size[1] : -size[1];
   }
-  matvec(out, o.mat, pl);
-  float n = norm3(dir);
-  float sc = n > MINVALF ? o.margin / n : 0.f;
-  out[0] += o.pos[0] + dir[0] * sc; out[1] += o.pos[1] + dir[1] * sc; out[2] += o.pos[2] + dir[2] * sc;
 }
 struct Sup { float v[3], v1[3]; };  // Minkowski point and its witness on obj1 (the witness on obj2 is v1 - v)
+// Minkowski-difference support of the two margin-inflated shapes.  Contract of the wave kernel's caller: obj `a` sits in the
+// identity frame at the origin (the pair is expressed in geom 1's frame) and `dir` is a unit vector, so a's support needs no
+// rotation and the spherical inflation is just +-margin * dir (no norm, no division).
 __device__ void mink_support(const CObj& a, const CObj& b, const float* dir, Sup& s) {
-  float nd[3] = {-dir[0], -dir[1], -dir[2]}, w2[3];
-  support_world(a, dir, s.v1);
-  support_world(b, nd, w2);
-  s.v[0] = s.v1[0] - w2[0]; s.v[1] = s.v1[1] - w2[1]; s.v[2] = s.v1[2] - w2[2];
+  float nd[3] = {-dir[0], -dir[1], -dir[2]}, dl[3], pl[3], w2[3];
+  support_local(a.type, a.size, dir, s.v1);
+  matTvec(dl, b.mat, nd);
+  support_local(b.type, b.size, dl, pl);
+  matvec(w2, b.mat, pl);
+  const float m2 = a.margin + b.margin;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    s.v1[k] += a.margin * dir[k];
+    s.v[k] = s.v1[k] - (w2[k] + b.pos[k]) + b.margin * dir[k];
+  }
+  (void)m2;
 }
 __device__ __forceinline__ void portal_dir(const Sup* p, float* dir) {
   float a[3] = {p[2].v[0] - p[1].v[0], p[2].v[1] - p[1].v[1], p[2].v[2] - p[1].v[2]};
@@ -482,7 +488,7 @@ __device__ __forceinline__ void expand_portal(Sup* p, const Sup& v4) {
   if (dot3(p[1].v, va) > 0) { if (dot3(p[2].v, va) > 0) p[1] = v4; else p[3] = v4; }
   else { if (dot3(p[3].v, va) > 0) p[2] = v4; else p[1] = v4; }
 }
-__device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout) {
+__device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup = nullptr) {
   Sup p[4];
   float dir[3], va[3], vb[3];
 #pragma unroll
@@ -542,7 +548,7 @@ __device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int m
     mink_support(o1, o2, dir, v4);
     float dv4 = dot3(v4.v, dir);
     float dmin = fminf(fminf(dv4 - dot3(p[1].v, dir), dv4 - dot3(p[2].v, dir)), dv4 - dot3(p[3].v, dir));
-    if (dmin <= tol || it > maxit) break;
+    if (dmin <= tol || it > maxit) { if (nsup) *nsup = it; break; }
     expand_portal(p, v4);
   }
   // output from the final support plane (see the oracle's mpr_penetration for the rationale)
@@ -979,21 +985,28 @@ template <int G> __device__ int stage_collision(const DevModel& M, float* E, int
           hit = true;
         }
       } else {
-        // MPR in coordinates relative to geom1's centre (float resolution ~1e-9 m), converged tolerance
-        const float zero3[3] = {0.f, 0.f, 0.f};
+        // MPR in geom1's own frame (identity for obj1, relative pose R1^T R2, R1^T (x2 - x1) for obj2; float resolution ~1e-9 m)
         float rel[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
         CObj o1, o2;
 #pragma unroll
-        for (int k = 0; k < 3; k++) { o1.pos[k] = zero3[k]; o2.pos[k] = rel[k]; o1.size[k] = sz1[k]; o2.size[k] = sz2[k]; }
+        for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int k = 0; k < 9; k++) { o1.mat[k] = R1[k]; o2.mat[k] = R2[k]; }
+          for (int j = 0; j < 3; j++) o2.mat[3 * i + j] = R1[i] * R2[j] + R1[3 + i] * R2[3 + j] + R1[6 + i] * R2[6 + j];
+        matTvec(o2.pos, R1, rel);
+#pragma unroll
+        for (int k = 0; k < 9; k++) o1.mat[k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { o1.pos[k] = 0.f; o1.size[k] = sz1[k]; o2.size[k] = sz2[k]; }
         o1.type = M.cg_type[g1]; o2.type = M.cg_type[g2]; o1.margin = o2.margin = 0.5f * margin;
         float depth, dir[3], pos[3];
         if (mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos)) {
           dist = margin - depth;
           normalize3(dir);
+          float dw[3], pw[3];
+          matvec(dw, R1, dir);
+          matvec(pw, R1, pos);
 #pragma unroll
-          for (int k = 0; k < 3; k++) { cpos[k] = pos[k] + x1[k]; nrm[k] = dir[k]; }
+          for (int k = 0; k < 3; k++) { cpos[k] = pw[k] + x1[k]; nrm[k] = dw[k]; }
           hit = true;
         }
       }
@@ -1552,7 +1565,16 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   const int lane_id = threadIdx.x;
   // workgroup -> env map: a speed-only placement hint (envs sorted by last step's cost, see balance_kernel); results of an
   // env never depend on which workgroup steps it
-  const int env = order ? order[blockIdx.x] : blockIdx.x;
+  const int oe = order ? order[blockIdx.x] : blockIdx.x;
+  const int env = oe & 0x0FFFFFFF;
+  // the four waves of a SIMD come from different cost quartiles (balance_kernel); the predicted-heavy ones get a higher issue
+  // priority so that the launch's critical path -- its heaviest waves -- is not slowed down by lighter neighbours that have slack
+  switch (oe >> 28) {
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    default: break;
+  }
   const int nv = M.nv, nu = M.nu, nq = W.nq;
   constexpr int CDW = (KC + 3) / 4;   // ints per contact holding its KC byte-packed dof ids
   // the small instantiation (hand / finger class) is compiled without the free-joint, equality, plane-contact and condim-1 code;
@@ -1586,6 +1608,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   }
   float time = Bt.time[env];
   int flags = 0, d_nefc = 0, d_ncon = 0, d_iter = 0, d_cost = 0;
+  int f_cand = 0, f_mpr = 0, f_ncon = 0, f_iter = 0, f_itcon = 0, f_ls = 0;   // work features of this env step (placement cost model)
   bool alive = true;
   const float h = M.timestep;
   const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
@@ -2007,6 +2030,31 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
               float d2[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
               float bb = b1 + b2 + M.pair_f[12 * p];
               hit = dot3(d2, d2) <= bb * bb;
+              if (hit) {
+                // separating-axis test along the centre line: the two (margin-inflated) convex shapes cannot touch if their
+                // support widths along that axis do not reach across the centre distance.  MPR would report "no contact" for
+                // exactly these pairs, after a dozen support evaluations; this costs one support width per shape
+                float dn = norm3(dif);
+                if (dn > MINVALF) {
+                  float inv = 1.0f / dn, ax[3] = {dif[0] * inv, dif[1] * inv, dif[2] * inv}, wsum = M.pair_f[12 * p];
+#pragma unroll
+                  for (int side = 0; side < 2; side++) {
+                    const int g = side ? g2 : g1;
+                    const float* sz = M.cg_size + 3 * g;
+                    const int ty = M.cg_type[g];
+                    if (ty == GEOM_CAPSULE) wsum += sz[0] + sz[1] * fabsf(dot3(E + Y.gax + 3 * g, ax));
+                    else if (ty == GEOM_SPHERE) wsum += sz[0];
+                    else {
+                      float R[9], dl[3];
+                      geom_world_mat(M, Y, E, g, R);
+                      matTvec(dl, R, ax);
+                      if (ty == GEOM_ELLIPSOID) { float sv[3] = {sz[0] * dl[0], sz[1] * dl[1], sz[2] * dl[2]}; wsum += norm3(sv); }
+                      else wsum += sz[0] * sqrtf(dl[0] * dl[0] + dl[1] * dl[1]) + sz[1] * fabsf(dl[2]);   // cylinder
+                    }
+                  }
+                  hit = dn <= wsum * 1.0001f + 1e-6f;   // conservative: never excludes a touching pair
+                }
+              }
             }
           }
         }
@@ -2016,9 +2064,12 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         ncand += __popcll(bal);
       }
       if (ncand > NCAND) { flags |= MYO_FLAG_CAND_OVERFLOW; ncand = NCAND; }
+      f_cand += ncand;
       SYNC();
+      STAMP(6);
       for (int base = 0; base < ncand; base += 64) {
         int ci = base + lane;
+        int nsup = -8;                    // support evaluations of this lane's MPR refinement (-8: not an MPR pair)
         bool hit = false, hit2 = false;   // a plane-capsule pair can give two contacts (one per end sphere)
         float dist = 0, dist2 = 0, cpos[3] = {0, 0, 0}, cpos2[3] = {0, 0, 0}, nrm[3] = {1, 0, 0};
         int p = -1;
@@ -2094,6 +2145,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             }
           } else {
             const float zero3[3] = {0.f, 0.f, 0.f};
+            nsup = 0;
             // MPR in geom1's own frame: obj1 needs no rotation / translation at all (identity frame), obj2 carries the
             // relative pose R1^T R2, R1^T (x2 - x1); normal and position are rotated back afterwards
             float R1[9];
@@ -2114,7 +2166,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             for (int k = 0; k < 3; k++) { o1.pos[k] = 0.f; o1.size[k] = sz1[k]; o2.size[k] = sz2[k]; }
             o1.type = M.cg_type[g1]; o2.type = M.cg_type[g2]; o1.margin = o2.margin = 0.5f * margin;
             float depth, dir[3], pos[3];
-            if (mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos)) {
+            if (mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup)) {
               dist = margin - depth;
               normalize3(dir);
               float dw[3], pw[3];
@@ -2127,6 +2179,14 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           }
           if (hit && !(dist < margin - M.pair_f[12 * p + 1])) hit = false;
           if (hit2 && !(dist2 < margin - M.pair_f[12 * p + 1])) hit2 = false;
+        }
+        {  // slowest lane of this round: MPR lanes cost ~8 + refinement steps, analytic pairs ~1
+          int w = nsup + 8;
+          w = max(w, __builtin_amdgcn_update_dpp(0, w, 0xB1, 0xf, 0xf, true));
+          w = max(w, __builtin_amdgcn_update_dpp(0, w, 0x4E, 0xf, 0xf, true));
+          w = max(w, __builtin_amdgcn_update_dpp(0, w, 0x141, 0xf, 0xf, true));
+          w = max(w, __builtin_amdgcn_update_dpp(0, w, 0x140, 0xf, 0xf, true));
+          f_mpr += max(max(rdlanei(w, 0), rdlanei(w, 16)), max(rdlanei(w, 32), rdlanei(w, 48)));
         }
         unsigned long long bal = __ballot(hit);
         int pos = ncon + __popcll(bal & ((1ull << lane) - 1ull));
@@ -2399,6 +2459,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           float improvement = scale * (cost - newcost);
           float gn = scale * sqrtf(wave_sum(grad * grad));
           iters++;
+          f_itcon += ncon;
           if (improvement < fmaxf(M.tolerance, 1e-6f * scale * fabsf(newcost)) || gn < M.tolerance || iters >= M.iterations) phase = 2;
         }
         cost = newcost;
@@ -2458,6 +2519,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           alpha = -d1 / d2;
           continue;
         }
+        f_ls++;
         float gtol = fmaxf(M.tolerance * M.ls_tolerance * sn / scale, 1e-6f * d1init);
         if (fabsf(d1) < gtol) break;
         if (d1 < 0) { lo = alpha; dlo = d1; d2lo = d2; } else { hi = alpha; dhi = d1; d2hi = d2; }
@@ -2481,7 +2543,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     }
     STAMP(7);
     d_nefc = nefc; d_ncon = ncon_real; d_iter = max(d_iter, iters);
-    d_cost += 40 + 3 * ncon + (iters + 1) * (24 + ncon);   // crude work estimate for the placement hint
+    f_ncon += ncon; f_iter += iters;
     {  // mj_checkAcc
       bool bad = lane < nv && (!(qacc == qacc) || fabsf(qacc) > MAXVALF);
       if (__any(bad) && alive) { flags |= MYO_FLAG_BAD_QACC; alive = false; }
@@ -2541,12 +2603,20 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     Bt.elapsed[env] += 1;
     Bt.flags[env] |= flags;
     Bt.diag[(size_t)env * 8 + 0] = d_nefc; Bt.diag[(size_t)env * 8 + 1] = d_ncon; Bt.diag[(size_t)env * 8 + 2] = d_iter;
+    // predicted work of this env's NEXT step for the placement hint, in units of 1024 single-wave cycles: linear model of this
+    // step's work features and the last substep's contact / row counts, fitted on one-wave-per-SIMD runs where a wave's duration is
+    // its own work (tools/gpu_cost_fit2.py; correlation with the next step's measured duration 0.92 hand / 0.90 legs)
+    d_cost = FULL ? 1909 + ((7436 * f_cand - 28892 * f_ncon + 1362 * f_mpr + 25014 * f_iter + 2046 * f_itcon - 1413 * f_ls + 13292 * d_nefc + 343707 * d_ncon) >> 10)
+                  : 2236 + ((-141 * f_cand - 3413 * f_ncon + 2188 * f_mpr + 8971 * f_iter - 107 * f_itcon - 122 * f_ls - 518 * d_nefc + 74475 * d_ncon) >> 10);
+    d_cost = max(d_cost, 1);
     Bt.diag[(size_t)env * 8 + 3] = d_cost;
+    Bt.diag[(size_t)env * 8 + 4] = f_cand | (f_ncon << 16); Bt.diag[(size_t)env * 8 + 5] = f_mpr;
+    Bt.diag[(size_t)env * 8 + 6] = f_itcon | (f_iter << 16); Bt.diag[(size_t)env * 8 + 7] = f_ls;
   }
 #if MYO_STAMPS
   STAMP(9);
   st_acc[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: wave/simd/cu/sh/se ids (placement census)
-  st_acc[11] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+  st_acc[11] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFF) | ((long long)(oe >> 28) << 8) | ((long long)d_cost << 16);   // HW_REG_XCC_ID, issue priority, cost estimate
   if (stamps && lane_id == 0) for (int k = 0; k < 12; k++) stamps[(size_t)blockIdx.x * 12 + k] = st_acc[k];
 #endif
 }
@@ -2566,7 +2636,7 @@ __device__ __host__ inline float u01(uint64_t seed, uint64_t a, uint64_t b) {
 // env step to the next.  Sort envs by last step's cost (counting sort, one workgroup) and deal them out so that the waves
 // that land on one SIMD come from different cost quartiles (snake order over `nslot` = B/4 slots).  Dispatch order is not
 // a contract: this only ever changes speed.
-__global__ void __launch_bounds__(1024) balance_kernel(const int* __restrict__ diag, int B, int* __restrict__ order, int nslot) {
+__global__ void __launch_bounds__(1024) balance_kernel(const int* __restrict__ diag, int B, int* __restrict__ order, int nslot, int prio_mode) {
   __shared__ int hist[256], start[256];
   __shared__ int cmax_s;
   const int t = threadIdx.x;
@@ -2587,7 +2657,8 @@ __global__ void __launch_bounds__(1024) balance_kernel(const int* __restrict__ d
     int r = atomicAdd(&start[b], 1);                       // rank by descending cost (ties in arbitrary order)
     int q = r / nslot, i = r - q * nslot;
     int wg = q * nslot + ((q & 1) ? nslot - 1 - i : i);    // snake: slot i gets ranks i, 2*nslot-1-i, 2*nslot+i, ...
-    order[wg < B ? wg : r] = e;
+    int pr = prio_mode == 2 ? (q < 3 ? 3 - q : 0) : (prio_mode == 1 ? (q == 0 ? 1 : 0) : (prio_mode == 3 ? (q < 2 ? 1 : 0) : 0));
+    order[wg < B ? wg : r] = e | (pr << 28);   // env id + issue priority of its cost quartile
   }
 }
 
@@ -2943,7 +3014,7 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
     const bool common = d.nl <= 64 && d.ncg <= 64 && w.nq <= 64 && w.neq <= 64 && d.maxnnz <= 20;
     const bool needs_full = w.has_free || w.neq > 0 || plane_pairs || condim1;
     if (common && !needs_full && d.nv <= 24 && d.nu <= 64 && d.ngt <= 64 && d.maxkc <= 8) { m->wave_ok = true; m->wave_cfg = 0; build_layout_w(d, w, 24, 8, 32); }
-    else if (common && d.nv <= 36 && d.nu <= 128 && d.ngt <= 128 && d.maxkc <= 20) { m->wave_ok = true; m->wave_cfg = 1; build_layout_w(d, w, 36, 20, 48); }
+    else if (common && d.nv <= 36 && d.nu <= 128 && d.ngt <= 128 && d.maxkc <= 20) { m->wave_ok = true; m->wave_cfg = 1; build_layout_w(d, w, 36, 20, 32); }
     else { m->wave_ok = false; build_layout_w(d, w, 24, 8, 32); }
     if (!m->wave_ok && !m->generic_ok) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "model exceeds the limits of both step kernels (nv <= 36, nu <= 128, pair dofs <= 20)"); }
     m->env_lds_bytes_w = w.lay.total * 4;
@@ -2954,7 +3025,8 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
     m->d_dm = (DevModel*)p1; m->d_dw = (DevModelW*)p2;
     if (hipMemcpy(p1, &d, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(p2, &w, sizeof(DevModelW), hipMemcpyHostToDevice) != hipSuccess) { myo_model_free(m); return fail(MYO_E_HIP, "upload model structs"); }
   }
-  m->dims = myo_dims{S[0], S[1], S[2], S[3], S[4], S[8], S[7], d.nl, 0, m->env_lds_bytes, 64, NCON, d.timestep};
+  m->dims = myo_dims{S[0], S[1], S[2], S[3], S[4], S[8], S[7], d.nl, 0, m->wave_ok ? m->env_lds_bytes_w : m->env_lds_bytes, 64,
+                     m->wave_ok ? (m->wave_cfg == 1 ? 32 : NCONW) : NCON, d.timestep};
   if (4 * m->env_lds_bytes > 160 * 1024) {
     if (!m->wave_ok) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "model working set exceeds 160 KB of LDS per workgroup"); }
     m->generic_ok = false;
@@ -3225,20 +3297,22 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     static bool attr_w = false;
     if (!attr_w) {
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 48, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       attr_w = true;
     }
     const int* order = nullptr;
     int Bn = b->db.B;
     if (b->balance && Bn >= 1024 && Bn % 4 == 0 && !kflags) {
-      hipLaunchKernelGGL(balance_kernel, dim3(1), dim3(1024), 0, s, (const int*)b->db.diag, Bn, b->d_order, Bn / 4);
+      static int prio_mode = -1;
+      if (prio_mode < 0) { const char* e = getenv("MYO_PRIO"); prio_mode = e ? atoi(e) : 2; }
+      hipLaunchKernelGGL(balance_kernel, dim3(1), dim3(1024), 0, s, (const int*)b->db.diag, Bn, b->d_order, Bn / 4, prio_mode);
       order = b->d_order;
     }
     if (m->wave_cfg == 0)
       hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                          (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0);
     else
-      hipLaunchKernelGGL((step_kernel_w<36, 20, 48, 2, 2>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+      hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                          (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, wk, kflags);
     HIPCHK(hipGetLastError());
     return MYO_OK;

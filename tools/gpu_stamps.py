@@ -7,14 +7,15 @@ from myosuite_mjx_amd import capi
 from myosuite_mjx_amd.envs import BatchedMyoEnv
 
 B = int(os.environ.get("B", 4096))
-NAMES = ["load/check", "kinematics", "tendon+muscle", "dynamics(CRB/RNE)", "collision", "constraint rows", "chol+solve(qacc_smooth)", "newton", "euler", "store"]
-env = BatchedMyoEnv("myoHandPoseRandom-v0", num_envs=B, as_torch=False)
+NAMES = ["load/check", "kinematics", "tendon+muscle", "dynamics(CRB/RNE)", "collision (wave kernel: narrow phase)", "constraint rows", "wave kernel: geom frames + broad phase", "newton", "euler", "store"]
+ENV = os.environ.get("ENV", "myoHandPoseRandom-v0")
+env = BatchedMyoEnv(ENV, num_envs=B, as_torch=False)
 mode = capi.BENCH_OBS | capi.BENCH_FRESH_ACTIONS | capi.BENCH_AUTORESET
 for lanes, bal in ((64, 0), (64, 1)):
     capi.set_lanes(lanes)
     env.batch.set_balance(bal)
     env.reset(seed=1)
-    env.batch.bench_rollout(30, 10, 0, mode, 100, None)
+    env.batch.bench_rollout(30, 10, 0, mode, env.max_episode_steps, None)
     ms = env.batch.bench_rollout(10, 10, 0, 0, 0, None) / 10
     nwg = B // (64 // lanes)
     st, ok = capi.read_stamps(env.batch, nwg)
