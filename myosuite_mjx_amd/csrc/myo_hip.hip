@@ -63,7 +63,7 @@ struct DevModel {
   const int *cg_link, *cg_type, *pair_i, *pair_dl;
   const float *link_pos, *link_quat, *link_mass, *link_com, *link_inertia, *dof_pos, *dof_axis, *qpos0, *dof_damping,
       *dof_armature;
-  const float *site_lpos, *wg_lpos, *wg_lmat, *wg_radius, *seg_div, *act, *cg_lpos, *cg_lmat, *cg_size, *cg_rbound,
+  const float *site_lpos, *wg_lpos, *wg_lmat, *wg_radius, *seg_div, *gt_len0, *act, *cg_lpos, *cg_lmat, *cg_size, *cg_rbound,
       *pair_f, *jl;
   Lay lay;
 };
@@ -722,7 +722,7 @@ template <int G> __device__ void stage_tendon(const DevModel& M, float* E, int s
   for (int gt = sub; gt < M.ngt; gt += G) {
     float* Jrow = E + Y.tJ + gt * M.maxnnz;
     for (int k = 0; k < M.maxnnz; k++) Jrow[k] = 0;
-    float L = 0;
+    float L = M.gt_len0[gt];   // constant same-link segments, folded at lowering time
     int s0 = M.gt_seg_adr[gt], sn = M.gt_seg_num[gt];
     for (int si = s0; si < s0 + sn; si++) {
       const int* S = M.seg + 12 * si;
@@ -1746,7 +1746,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       if (gt >= M.ngt) continue;
       float* Jrow = E + Y.tJ + gt * M.maxnnz;
       for (int k = 0; k < M.maxnnz; k++) Jrow[k] = 0;
-      float L = 0;
+      float L = M.gt_len0[gt];   // constant same-link segments, folded at lowering time
       for (int si = M.gt_seg_adr[gt]; si < M.gt_seg_adr[gt] + M.gt_seg_num[gt]; si++) L += E[Y.seglen + si];
       int e0 = W.gt_dl[2 * gt], en = W.gt_dl[2 * gt + 1];
       for (int e = e0; e < e0 + en; e++) Jrow[M.dl[3 * e + 2]] += E[Y.dlval + e];
@@ -2963,7 +2963,7 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
   LF(link_pos, "hip_link_pos") LF(link_quat, "hip_link_quat") LF(link_mass, "hip_link_mass") LF(link_com, "hip_link_com")
   LF(link_inertia, "hip_link_inertia") LF(dof_pos, "hip_dof_pos") LF(dof_axis, "hip_dof_axis") LF(dof_damping, "dof_damping")
   LF(dof_armature, "dof_armature") LF(site_lpos, "hip_site_lpos") LF(wg_lpos, "hip_wg_lpos") LF(wg_lmat, "hip_wg_lmat")
-  LF(wg_radius, "hip_wg_radius") LF(seg_div, "hip_seg_div") LF(act, "hip_act") LF(cg_lpos, "hip_cg_lpos") LF(cg_lmat, "hip_cg_lmat")
+  LF(wg_radius, "hip_wg_radius") LF(seg_div, "hip_seg_div") LF(gt_len0, "hip_gt_len0") LF(act, "hip_act") LF(cg_lpos, "hip_cg_lpos") LF(cg_lmat, "hip_cg_lmat")
   LF(cg_size, "hip_cg_size") LF(cg_rbound, "hip_cg_rbound") LF(pair_f, "hip_pair_f")
 #undef LF
 #undef LI

@@ -208,6 +208,7 @@ def lower(cm):
             gt_tendon.append(t)
     segs, seg_div, dls = [], [], []
     gt_seg_adr, gt_seg_num, gt_dofs = [], [], []
+    gt_len0 = []    # per tendon: summed length of its constant (same-link) straight segments
     wg_ids = {}     # geom id -> wrap geom index
 
     def wrap_index(g):
@@ -218,6 +219,7 @@ def lower(cm):
     for t in gt_tendon:
         adr, num = m.tendon_adr[t], m.tendon_num[t]
         gt_seg_adr.append(len(segs))
+        gt_len0.append(0.0)
         row = []       # dofs of this tendon's sparse Jacobian row
 
         def add_list(la, lb):
@@ -251,9 +253,14 @@ def lower(cm):
                 j += 2
             else:
                 s1 = int(m.wrap_objid[adr + j + 1])
+                j += 1
+                if site_link[s0] == site_link[s1]:
+                    # both sites ride on the same link (or are both world-fixed): constant length, no moment arm.  Folded into a
+                    # per-tendon offset (97 of MyoHand's 150 straight segments are of this kind)
+                    gt_len0[-1] += float(np.linalg.norm(site_lpos[s1] - site_lpos[s0])) / div
+                    continue
                 d_adr, d_n = add_list(site_link[s0], site_link[s1])
                 segs.append([s0, s1, -1, -1, d_adr, d_n, 0, 0, 0, 0, 0, 0])
-                j += 1
             seg_div.append(div)
         gt_seg_num.append(len(segs) - gt_seg_adr[-1])
         gt_dofs.append(row)
@@ -474,6 +481,7 @@ def lower(cm):
     A["hip_wg_radius"] = m.geom_size[wgs, 0] if wgs else np.zeros(0)
     A["hip_gt_tendon"] = np.array(gt_tendon, np.int32)
     A["hip_gt_seg_adr"] = np.array(gt_seg_adr, np.int32)
+    A["hip_gt_len0"] = np.array(gt_len0)
     A["hip_gt_seg_num"] = np.array(gt_seg_num, np.int32)
     A["hip_gt_dofs"] = gt_dof_tab
     A["hip_gt_dl"] = np.stack([np.array(gt_dl_adr, np.int32), np.array(gt_dl_num, np.int32)], 1).reshape(-1, 2)

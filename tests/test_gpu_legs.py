@@ -63,14 +63,14 @@ def _run_pair(m, hm, oracle, st, nsub, switches):
     return g, r
 
 
-def _check(g, r, tq, tv, min_frac=0.97):
+def _check(g, r, tq, tv, min_frac=0.97, tl=2e-5):
     assert (g["flags"] == 0).all()
     ok = g["diag"][:, 1] == r["ncon"]
     assert ok.mean() >= min_frac, f"contact-count mismatches: {(~ok).sum()}"
     assert np.abs(g["qpos"] - r["qpos"])[ok].max() < tq
     assert np.abs(g["qvel"] - r["qvel"])[ok].max() < tv
     assert np.abs(g["act"] - r["act"])[ok].max() < 1e-6
-    assert np.abs(g["tenlen"] - r["tenlen"])[ok].max() < 2e-5
+    assert np.abs(g["tenlen"] - r["tenlen"])[ok].max() < tl       # lengths of the last substep: moment arm (<= 0.1 m/rad) x qpos error
     return ok
 
 
@@ -85,7 +85,7 @@ def test_leg_smooth_and_equalities(legs, leghip, legoracle64, nsub, tq, tv):
 @pytest.mark.parametrize("nsub,tq,tv", [(1, 2e-5, 2e-2), (10, 1e-4, 5e-2)])
 def test_leg_joint_limits(legs, leghip, legoracle64, nsub, tq, tv):
     g, r = _run_pair(legs, leghip, legoracle64, leg_states(legs, 64, 10 + nsub, dz=0.5, jitter=0.3), nsub, (1, 0, 1))
-    _check(g, r, tq, tv, 1.0)
+    _check(g, r, tq, tv, 1.0, tl=5e-5)
     assert (g["diag"][:, 0] == r["nefc"]).all()
     assert r["nefc"].max() > 20
 
