@@ -1459,8 +1459,9 @@ template <int NVT> __device__ __forceinline__ float chol_rows(float (&r)[NVT], i
     float s = r[j];
 #pragma unroll
     for (int k = 0; k < j; k++) s -= r[k] * rdlane(r[k], j);
-    float dj = sqrtf(fmaxf(rdlane(s, j), MINVALF));
-    float inv = 1.0f / dj;
+    float pj = fmaxf(rdlane(s, j), MINVALF);
+    float inv = __builtin_amdgcn_rsqf(pj);   // v_rsq_f32 (1 ulp); pj >= 1e-15, no denormal handling needed
+    float dj = pj * inv;
     r[j] = (lane == j) ? dj : s * inv;
     if (lane == j) invd = inv;
   }
@@ -1608,7 +1609,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   }
   float time = Bt.time[env];
   int flags = 0, d_nefc = 0, d_ncon = 0, d_iter = 0, d_cost = 0;
-  int f_cand = 0, f_mpr = 0, f_ncon = 0, f_iter = 0, f_itcon = 0, f_ls = 0;   // work features of this env step (placement cost model)
+  int f_cand = 0, f_mpr = 0, f_ncon = 0, f_iter = 0, f_itcon = 0, f_ls = 0, f_fact = 0;   // work features of this env step (placement cost model)
   bool alive = true;
   const float h = M.timestep;
   const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
@@ -2406,18 +2407,20 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       if (eact) ejar = E[Y.xv + ed1] + eJ2 * E[Y.xv + ed2] - earef;
     }
     bool first = true;
+    int sig_prev = -1;
     const int lane_s = lane;
     while (true) {
       int lane;   // opaque copy again: keeps the 24 per-lane symv addresses from being hoisted out of the loop and spilled
       asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane_s));
-      float r[NVT], rhs;
+      float r[NVT], rhs, invd;
+      bool refactor = true;
       if (phase == 0) {
-        // forces of the active rows, J^T f (LDS atomics), cost, gradient, Hessian blocks (LDS atomics)
+        // forces of the active rows, J^T f (LDS atomics), cost, gradient; convergence test; then, only if the iteration goes on and
+        // the active set differs from the one whose Hessian was factorised last, the Hessian blocks (LDS atomics)
         bool lact = lsign != 0.f && ljar < 0;
         float w0 = cjar[0] < 0 ? cD : 0.f, w1 = cjar[1] < 0 ? cD : 0.f, w2 = cjar[2] < 0 ? cD : 0.f, w3 = cjar[3] < 0 ? cD : 0.f;
         float f0 = -w0 * cjar[0], f1 = -w1 * cjar[1], f2 = -w2 * cjar[2], f3 = -w3 * cjar[3];
         if (lane < nv) E[Y.qfc + lane] = lact ? -lsign * lD * ljar : 0.f;
-        WFOR(i, NVT * (NVT + 1)) E[Y.sq + i] = 0;
         SYNC();
         if (lane < ncon) {
           const float* cJ = E + Y.cJ + lane * 3 * KC;
@@ -2425,28 +2428,6 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           for (int k = 0; k < ckc; k++) atomicAdd(&E[Y.qfc + CDOF(E, Y, lane, k)], Fn * cJ[k] + Ft1 * cJ[KC + k] + Ft2 * cJ[2 * KC + k]);
         }
         if (eact) { float f = -eD * ejar; atomicAdd(&E[Y.qfc + ed1], f); atomicAdd(&E[Y.qfc + ed2], eJ2 * f); }
-        if (lane < nv && lact) E[Y.sq + lane * (NVT + 1) + lane] = lD;
-        float Wn = w0 + w1 + w2 + w3, A1 = cmu * (w0 - w1), A2 = cmu * (w2 - w3), B1 = cmu * cmu * (w0 + w1), B2 = cmu * cmu * (w2 + w3);
-        SYNC();
-        for (int c = 0; c < ncon; c++) {   // one contact per step, lanes = entries of its kc x kc block
-          int kc = rdlanei(ckc, c);
-          float sW = rdlane(Wn, c), sA1 = rdlane(A1, c), sA2 = rdlane(A2, c), sB1 = rdlane(B1, c), sB2 = rdlane(B2, c);
-          if (sW == 0.f) continue;
-          for (int t = lane; t < kc * kc; t += 64) {
-            int a = t / kc, b = t - a * kc;
-            const float* cJ = E + Y.cJ + c * 3 * KC;
-            int da = CDOF(E, Y, c, a), db = CDOF(E, Y, c, b);
-            if (da >= db) {
-              float na = cJ[a], nb = cJ[b], ta = cJ[KC + a], tb = cJ[KC + b], ua = cJ[2 * KC + a], ub = cJ[2 * KC + b];
-              atomicAdd(&E[Y.sq + da * (NVT + 1) + db], sW * na * nb + sA1 * (na * tb + ta * nb) + sA2 * (na * ub + ua * nb) + sB1 * ta * tb + sB2 * ua * ub);
-            }
-          }
-        }
-        if (eact) {
-          atomicAdd(&E[Y.sq + ed1 * (NVT + 1) + ed1], eD);
-          atomicAdd(&E[Y.sq + ed2 * (NVT + 1) + ed2], eD * eJ2 * eJ2);
-          atomicAdd(&E[Y.sq + max(ed1, ed2) * (NVT + 1) + min(ed1, ed2)], eD * eJ2);
-        }
         SYNC();
         qfc = lane < nv ? E[Y.qfc + lane] : 0.f;
         float cst = lact ? 0.5f * lD * ljar * ljar : 0.f;
@@ -2463,9 +2444,44 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           if (improvement < fmaxf(M.tolerance, 1e-6f * scale * fabsf(newcost)) || gn < M.tolerance || iters >= M.iterations) phase = 2;
         }
         cost = newcost;
+        if (phase == 0) {
+          // H = M + J^T D J depends on the state only through the set of active rows: same set as last time -> same factor
+          const int sig = (lact ? 1 : 0) | (w0 != 0.f ? 2 : 0) | (w1 != 0.f ? 4 : 0) | (w2 != 0.f ? 8 : 0) | (w3 != 0.f ? 16 : 0);
+          refactor = first || __any(sig != sig_prev);
+          sig_prev = sig;
+          if (refactor) {
+            f_fact++;
+            WFOR(i, NVT * (NVT + 1)) E[Y.sq + i] = 0;
+            SYNC();
+            if (lane < nv && lact) E[Y.sq + lane * (NVT + 1) + lane] = lD;
+            float Wn = w0 + w1 + w2 + w3, A1 = cmu * (w0 - w1), A2 = cmu * (w2 - w3), B1 = cmu * cmu * (w0 + w1), B2 = cmu * cmu * (w2 + w3);
+            SYNC();
+            for (int c = 0; c < ncon; c++) {   // one contact per step, lanes = entries of its kc x kc block
+              int kc = rdlanei(ckc, c);
+              float sW = rdlane(Wn, c), sA1 = rdlane(A1, c), sA2 = rdlane(A2, c), sB1 = rdlane(B1, c), sB2 = rdlane(B2, c);
+              if (sW == 0.f) continue;
+              for (int t = lane; t < kc * kc; t += 64) {
+                int a = t / kc, b = t - a * kc;
+                const float* cJ = E + Y.cJ + c * 3 * KC;
+                int da = CDOF(E, Y, c, a), db = CDOF(E, Y, c, b);
+                if (da >= db) {
+                  float na = cJ[a], nb = cJ[b], ta = cJ[KC + a], tb = cJ[KC + b], ua = cJ[2 * KC + a], ub = cJ[2 * KC + b];
+                  atomicAdd(&E[Y.sq + da * (NVT + 1) + db], sW * na * nb + sA1 * (na * tb + ta * nb) + sA2 * (na * ub + ua * nb) + sB1 * ta * tb + sB2 * ua * ub);
+                }
+              }
+            }
+            if (eact) {
+              atomicAdd(&E[Y.sq + ed1 * (NVT + 1) + ed1], eD);
+              atomicAdd(&E[Y.sq + ed2 * (NVT + 1) + ed2], eD * eJ2 * eJ2);
+              atomicAdd(&E[Y.sq + max(ed1, ed2) * (NVT + 1) + min(ed1, ed2)], eD * eJ2);
+            }
+            SYNC();
+          }
+        }
         first = false;
       }
-      {
+      rhs = phase == 0 ? -grad : (phase == 1 ? smooth : smooth + qfc);
+      if (refactor) {
         const int dd = lane < nv ? lane : 0;
         const int based = (dd * (dd + 1)) / 2;
         const float diag_add = phase == 2 ? h * damping : 0.f;
@@ -2475,15 +2491,20 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           float hv = (phase == 0 && lane < nv) ? E[Y.sq + lane * (NVT + 1) + k] : 0.f;              // J^T D J (active rows)
           r[k] = (lane < nv) ? mv + hv + (k == lane ? diag_add : 0.f) : (k == lane ? 1.f : 0.f);
         }
-        rhs = phase == 0 ? -grad : (phase == 1 ? smooth : smooth + qfc);
-      }
-      SYNC();
-      float invd = chol_rows<NVT>(r, lane);
-      if (lane < NVT) {
+        SYNC();
+        invd = chol_rows<NVT>(r, lane);
+        if (lane < NVT) {
 #pragma unroll
-        for (int k = 0; k < NVT; k++) E[Y.sq + lane * (NVT + 1) + k] = r[k];
+          for (int k = 0; k < NVT; k++) E[Y.sq + lane * (NVT + 1) + k] = r[k];
+        }
+        SYNC();
+      } else {
+        // the factor of the previous iteration is still in LDS (row-major L): reload this lane's row
+        const int ll = lane < NVT ? lane : 0;
+#pragma unroll
+        for (int k = 0; k < NVT; k++) r[k] = E[Y.sq + ll * (NVT + 1) + k];
+        invd = 1.0f / E[Y.sq + ll * (NVT + 1) + ll];
       }
-      SYNC();
       float x = chol_solve_rows<NVT>(r, invd, rhs, E + Y.sq, lane);
       if (phase == 1) { qacc = x; qfc = 0.f; phase = 2; continue; }
       if (phase == 2) { qaccE = x; break; }
