@@ -60,13 +60,20 @@ typedef enum myo_field {
   MYO_F_ACTFORCE,    /* [B][nu]  actuator forces of the last substep */
   MYO_F_SITEXPOS,    /* [B][3*ntip] tip site world positions after the step (reach task) */
   MYO_F_ELAPSED,     /* [B][1] int32 env steps since the last reset (gym TimeLimit counter) */
+  MYO_F_ACTION,      /* [B][nu]  library-owned action buffer: write normalised actions here and pass its pointer to myo_step */
+  MYO_F_FATIGUE,     /* [B][3*nu] fatigue compartments MA | MR | MF (muscle condition "fatigue") */
   MYO_F_COUNT
 } myo_field;
 
 enum { MYO_FLAG_BAD_STATE = 1, MYO_FLAG_BAD_QACC = 2, MYO_FLAG_CONTACT_OVERFLOW = 4, MYO_FLAG_CAND_OVERFLOW = 8 };
 
 /* action -> control map applied inside myo_step (base_v0.py:87-91) */
-enum { MYO_ACTMAP_NONE = 0, MYO_ACTMAP_MUSCLE_SIGMOID = 1 };
+enum {
+  MYO_ACTMAP_NONE = 0,
+  MYO_ACTMAP_MUSCLE_SIGMOID = 1,
+  MYO_ACTMAP_SIGMOID_FATIGUE = 2,          /* + muscle condition "fatigue": 3CC-r model, envs/myo/fatigue.py:61-108, base_v0.py:100-104 */
+  MYO_ACTMAP_SIGMOID_REAFFERENTATION = 3   /* + EIP -> EPL tendon transfer, base_v0.py:105-109 (ids set with myo_batch_set_condition) */
+};
 
 /* tasks understood by myo_obs / myo_reset */
 typedef enum myo_task { MYO_TASK_NONE = 0, MYO_TASK_POSE = 1, MYO_TASK_REACH = 2, MYO_TASK_WALK = 3 } myo_task;
@@ -116,6 +123,9 @@ void myo_batch_free(myo_batch*);
 int myo_batch_size(const myo_batch*);
 int myo_batch_configure(myo_batch*, const myo_task_config* cfg);
 int myo_batch_configure_walk(myo_batch*, const myo_walk_config* cfg);
+/* muscle conditions (envs/myo/base_v0.py:61-80): time step of the fatigue model (frame_skip * timestep) and the actuator ids of
+ * the EIP -> EPL tendon transfer (-1: none).  Sarcopenia is a model edit (peak force of gainprm halved) made before myo_model_load. */
+int myo_batch_set_condition(myo_batch*, int frame_skip, int epl_actuator, int eip_actuator);
 /* device pointer + pitch (elements per env row) of a field */
 int myo_batch_field(myo_batch*, int field, void** dev_ptr, size_t* pitch, size_t* width);
 /* synchronous host copies (tests / plumbing without torch); host buffers are [B][width] */
@@ -157,6 +167,21 @@ enum { MYO_BENCH_OBS = 1, MYO_BENCH_FRESH_ACTIONS = 2, MYO_BENCH_AUTORESET = 4 }
 int myo_bench_rollout(myo_batch*, int steps, int nsubsteps, uint64_t seed, int mode, int max_episode_steps, void* stream, float* ms_out);
 /* HIP-event milliseconds spent inside the step-kernel launches of the last myo_bench_rollout (events recorded on its stream) */
 int myo_bench_last_kernel_ms(myo_batch*, float* ms_out);
+
+/* ---- policy inference: the network family of the reference's `mjx_brax_policy` artefact (a brax PPO
+ * policy: running-statistics observation normalisation, MLP with swish hidden layers, tanh-normal head; brax is third-party and
+ * absent from the reference tree, so the formulas are restated from its documentation -- parity unpinned).
+ *   x = (obs - mean) / std ; h_{l+1} = swish(h_l W_l + b_l) ; (loc, raw) = split(h_L W_L + b_L) ;
+ *   action = tanh(loc)                                   (deterministic)
+ *          = tanh(loc + (softplus(raw) + 0.001) * eps)    (sampled; eps ~ N(0,1) from the counter RNG (seed, step, global env id))
+ * Kernels are row-major [in][out] float32, copied at load time.  obs / action are DEVICE pointers, env-major, e.g. the
+ * MYO_F_OBS buffer and the action argument of myo_step: a rollout never leaves the GPU. */
+typedef struct myo_policy myo_policy;
+int myo_policy_load(int device, int obs_dim, int act_dim, int nlayers, const int* layer_out /* nlayers entries, last = 2*act_dim */,
+                    const float* obs_mean, const float* obs_std, const float* const* kernels, const float* const* biases, myo_policy** out);
+void myo_policy_free(myo_policy*);
+int myo_policy_act(myo_policy*, const float* obs_dev, int B, float* action_dev, int deterministic, uint64_t seed, uint64_t step,
+                   int env_offset, void* stream);
 
 #ifdef __cplusplus
 }

@@ -11,6 +11,7 @@ importable, so the directory is `myosuite_mjx_amd`.
     d = myo.make_data(m, 4096); myo.step(m, d, ctrl, nsubsteps=10)
 """
 from .envs import REGISTRY, UNSUPPORTED, BatchedMyoEnv, make  # noqa: F401
+from .policy import BraxPolicy  # noqa: F401
 from .sim import HipSimScene, get, make_data, put_model, set_, step  # noqa: F401
 
 __version__ = "0.1.0"

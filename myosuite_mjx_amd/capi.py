@@ -14,10 +14,10 @@ SRC_PATH = os.path.join(_HERE, "csrc", "myo_hip.hip")
 
 # field ids (myo_field)
 (F_QPOS, F_QVEL, F_ACT, F_CTRL, F_WARMSTART, F_TIME, F_TARGET, F_OBS, F_REWARD, F_DONE, F_SOLVED, F_FLAGS, F_DIAG,
- F_QACC, F_TENLEN, F_ACTFORCE, F_SITEXPOS, F_ELAPSED) = range(18)
+ F_QACC, F_TENLEN, F_ACTFORCE, F_SITEXPOS, F_ELAPSED, F_ACTION, F_FATIGUE) = range(20)
 INT_FIELDS = (F_FLAGS, F_DIAG, F_ELAPSED)
 BENCH_OBS, BENCH_FRESH_ACTIONS, BENCH_AUTORESET = 1, 2, 4
-ACTMAP_NONE, ACTMAP_MUSCLE_SIGMOID = 0, 1
+ACTMAP_NONE, ACTMAP_MUSCLE_SIGMOID, ACTMAP_SIGMOID_FATIGUE, ACTMAP_SIGMOID_REAFFERENTATION = 0, 1, 2, 3
 TASK_NONE, TASK_POSE, TASK_REACH = 0, 1, 2
 FLAG_BAD_STATE, FLAG_BAD_QACC, FLAG_CONTACT_OVERFLOW, FLAG_CAND_OVERFLOW = 1, 2, 4, 8
 
@@ -71,10 +71,11 @@ def lib():
         # PyTorch-ROCm bundles its own HIP runtime.  Two HIP runtimes in one process do not share the device (the second one
         # reports "no HIP GPUs"), so when torch is installed let it load its runtime first: libmyo_hip.so's libamdhip64
         # dependency then resolves to that same, already loaded, library whichever side touches the GPU first.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        if not os.environ.get("MYO_NO_TORCH"):      # MYO_NO_TORCH=1: torch-free processes (profiling drivers) skip the import
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         L.myo_last_error.restype = C.c_char_p
         L.myo_model_load.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
@@ -105,6 +106,7 @@ def lib():
         L.myo_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.myo_batch_configure_walk.argtypes = [C.c_void_p, C.POINTER(WalkConfig)]
         L.myo_obs_reset_only.argtypes = [C.c_void_p, C.c_void_p]
+        L.myo_batch_set_condition.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -193,6 +195,9 @@ class HipBatch:
         c.init_qpos = iq.ctypes.data_as(C.POINTER(C.c_float))
         c.init_qvel = iv.ctypes.data_as(C.POINTER(C.c_float)) if iv is not None else None
         _chk(lib().myo_batch_configure_walk(self.h, C.byref(c)))
+
+    def set_condition(self, frame_skip, epl_actuator=-1, eip_actuator=-1):
+        _chk(lib().myo_batch_set_condition(self.h, int(frame_skip), int(epl_actuator), int(eip_actuator)))
 
     def obs_reset_only(self, stream=None):
         _chk(lib().myo_obs_reset_only(self.h, stream))

@@ -32,6 +32,9 @@
 #define MAXIMPF 0.9999f
 #define NCON 32   // contact slots per env
 #define NCAND 128 // broad-phase survivors per env
+#ifndef LS_FLOOR
+#define LS_FLOOR 1e-6f   // float32 floor of the line-search slope tolerance, relative to the initial slope
+#endif
 #define KCMAX 8   // max dofs in a contact pair's jacobian (checked against the model at load)
 #define GEOM_SPHERE 2
 #define GEOM_CAPSULE 3
@@ -73,6 +76,9 @@ struct DevBatch {
   int B;
   float *qpos, *qvel, *act, *ctrl, *warm, *time, *target, *obs, *reward, *done, *solved, *qacc, *tenlen, *actforce, *sitexpos;
   int *flags, *diag, *elapsed, *episode;
+  float* fatigue;          // [B][3][nu]: MA, MR, MF of the 3CC-r fatigue model (muscle condition "fatigue")
+  float fat_dt;            // its time step = frame_skip * timestep
+  int reaf_epl, reaf_eip;  // actuator ids of the EIP -> EPL tendon transfer (muscle condition "reafferentation")
 };
 
 struct TaskDev {
@@ -394,13 +400,42 @@ __device__ __forceinline__ void muscle(const float* A, float len, float vel, flo
   float gain = -F0 * FL * FV;
   float b = 0.5f * (1 + lmax), bias, x;
   if (L <= 1) bias = 0;
-  else if (L <= b) { x = (L - 1) / fmaxf(MINVALF, b - 1); bias = -F0 * fpmax * 0.5f * x * x; }
-  else { x = (L - b) / fmaxf(MINVALF, b - 1); bias = -F0 * fpmax * (0.5f + x); }
+  else if (L <= b) { x = (L - 1) / fmaxf(MINVALF, b - 1); bias = -A[15] * fpmax * 0.5f * x * x; }   // A[15]: peak force of biasprm
+  else { x = (L - b) / fmaxf(MINVALF, b - 1); bias = -A[15] * fpmax * (0.5f + x); }
   *force = gain * act + bias;
   float cc = clipf(clipf(ctrl, A[12], A[13]), 0.f, 1.f), ac = clipf(act, 0.f, 1.f);
   float tau_act = A[10] * (0.5f + 1.5f * ac), tau_deact = A[11] / (0.5f + 1.5f * ac);
   float dctrl = cc - act;
   *actdot = dctrl / fmaxf(MINVALF, dctrl > 0 ? tau_act : tau_deact);
+}
+
+// normalised action -> muscle excitation (BaseV0.step, envs/myo/base_v0.py:83-109), one actuator of one env:
+//   sigmoid re-projection (:87-91); muscle condition "fatigue": the excitation becomes the 3CC-r model's active compartment MA after
+//   one update with the target load TL = sigmoid(a) (envs/myo/fatigue.py:61-108; F, R, r of :10-18); "reafferentation": EPL is driven
+//   by EIP's command and EIP is silenced (:105-109)
+__device__ __forceinline__ float action_map(const DevBatch& Bt, const float* __restrict__ actprm, const float* __restrict__ action, int env,
+                                            int i, int nu, int actmap) {
+  int src = i;
+  if (actmap == MYO_ACTMAP_SIGMOID_REAFFERENTATION) { if (i == Bt.reaf_epl) src = Bt.reaf_eip; else if (i == Bt.reaf_eip) return 0.f; }
+  float c = action[(size_t)env * nu + src];
+  if (actmap == MYO_ACTMAP_NONE) return c;
+  c = 1.0f / (1.0f + expf(-5.0f * (c - 0.5f)));
+  if (actmap == MYO_ACTMAP_SIGMOID_FATIGUE) {
+    float* S = Bt.fatigue + (size_t)env * 3 * nu;
+    float MA = S[i], MR = S[nu + i], MF = S[2 * nu + i];
+    const float F = 0.00912f, R = 0.1f * 0.00094f, rr = 10.f * 15.f, dt = Bt.fat_dt, TL = c;
+    float LD = (0.5f + 1.5f * MA) / actprm[16 * i + 10], LR = (0.5f + 1.5f * MA) / actprm[16 * i + 11];
+    float C, rR;
+    if (MA < TL) { C = (MR > TL - MA) ? LD * (TL - MA) : LD * MR; rR = R; }
+    else { C = LR * (TL - MA); rR = rr * R; }
+    float lo = fmaxf(-MA / dt + F * MA, (MR - 1) / dt + rR * MF), hi = fminf((1 - MA) / dt + F * MA, MR / dt + rR * MF);
+    C = fminf(fmaxf(C, lo), hi);                    // np.clip(C, lo, hi)
+    S[i] = MA + (C - F * MA) * dt;
+    S[nu + i] = MR + (-C + rR * MF) * dt;
+    S[2 * nu + i] = MF + (F * MA - rR * MF) * dt;
+    c = S[i];
+  }
+  return c;
 }
 
 __device__ __forceinline__ float impedance(const float* solimp, float pos, float margin) {
@@ -1192,10 +1227,8 @@ __global__ void __launch_bounds__(64) step_kernel(DevModel M, DevBatch Bt, const
   GFOR(i, nu) {
     E[Y.act + i] = Bt.act[(size_t)env * nu + i];
     float c;
-    if (action) {
-      c = action[(size_t)env * nu + i];
-      if (actmap == MYO_ACTMAP_MUSCLE_SIGMOID) c = 1.0f / (1.0f + expf(-5.0f * (c - 0.5f)));
-    } else c = Bt.ctrl[(size_t)env * nu + i];
+    if (action) c = action_map(Bt, M.act, action, env, i, nu, actmap);
+    else c = Bt.ctrl[(size_t)env * nu + i];
     E[Y.ctrl + i] = c;
   }
   float time = Bt.time[env];
@@ -1302,7 +1335,7 @@ __global__ void __launch_bounds__(64) step_kernel(DevModel M, DevBatch Bt, const
             alpha = -d1 / d2;
             continue;
           }
-          float gtol = fmaxf(M.tolerance * M.ls_tolerance * sn / scale, 1e-6f * d1init);
+          float gtol = fmaxf(M.tolerance * M.ls_tolerance * sn / scale, LS_FLOOR * d1init);
           if (fabsf(d1) < gtol) { ls_on = false; continue; }
           if (d1 < 0) { lo = alpha; dlo = d1; d2lo = d2; } else { hi = alpha; dhi = d1; d2hi = d2; }
           float cand = alpha - d1 / d2;
@@ -1601,10 +1634,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   for (int i = lane_id; i < nu; i += 64) {
     E[Y.act + i] = Bt.act[(size_t)env * nu + i];
     float c;
-    if (action) {
-      c = action[(size_t)env * nu + i];
-      if (actmap == MYO_ACTMAP_MUSCLE_SIGMOID) c = 1.0f / (1.0f + expf(-5.0f * (c - 0.5f)));
-    } else c = Bt.ctrl[(size_t)env * nu + i];
+    if (action) c = action_map(Bt, M.act, action, env, i, nu, actmap);
+    else c = Bt.ctrl[(size_t)env * nu + i];
     E[Y.ctrl + i] = c;
   }
   float time = Bt.time[env];
@@ -2541,7 +2572,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           continue;
         }
         f_ls++;
-        float gtol = fmaxf(M.tolerance * M.ls_tolerance * sn / scale, 1e-6f * d1init);
+        float gtol = fmaxf(M.tolerance * M.ls_tolerance * sn / scale, LS_FLOOR * d1init);
         if (fabsf(d1) < gtol) break;
         if (d1 < 0) { lo = alpha; dlo = d1; d2lo = d2; } else { hi = alpha; dhi = d1; d2hi = d2; }
         float cand = alpha - d1 / d2;
@@ -2632,7 +2663,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     d_cost = max(d_cost, 1);
     Bt.diag[(size_t)env * 8 + 3] = d_cost;
     Bt.diag[(size_t)env * 8 + 4] = f_cand | (f_ncon << 16); Bt.diag[(size_t)env * 8 + 5] = f_mpr;
-    Bt.diag[(size_t)env * 8 + 6] = f_itcon | (f_iter << 16); Bt.diag[(size_t)env * 8 + 7] = f_ls;
+    Bt.diag[(size_t)env * 8 + 6] = f_itcon | (f_iter << 16); Bt.diag[(size_t)env * 8 + 7] = f_ls | (f_fact << 16);
   }
 #if MYO_STAMPS
   STAMP(9);
@@ -2690,6 +2721,61 @@ __global__ void random_action_kernel(float* action, int B, int nu, uint64_t seed
   action[i] = 2.0f * u01(seed, (uint64_t)(e + env_offset) * 1024 + k, step) - 1.0f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// policy inference (brax PPO network family): 8 envs per 256-thread workgroup, thread = (env, hidden unit); activations ping-pong
+// through LDS, weights are read coalesced across units and shared by the 8 envs through the cache.  ~13 kMAC per env for
+// the hand observation: negligible next to the physics step, so plain FMAs (no MFMA)
+#define POL_ENVS 8
+#define POL_MAXW 64
+struct PolicyDev {
+  int obs_dim, act_dim, nlayers;
+  int width[8];               // output width of each layer
+  const float* W[8];
+  const float* b[8];
+  const float *mean, *std;
+};
+__global__ void __launch_bounds__(POL_ENVS * POL_MAXW) policy_kernel(PolicyDev P, const float* __restrict__ obs, int B, float* __restrict__ action,
+                                                                     int deterministic, uint64_t seed, uint64_t step, int env_offset) {
+  extern __shared__ float sh[];                       // [POL_ENVS][max(obs_dim, POL_MAXW)] x 2
+  const int j = threadIdx.x % POL_MAXW, le = threadIdx.x / POL_MAXW;
+  const int e = blockIdx.x * POL_ENVS + le;
+  int stride = max(P.obs_dim, POL_MAXW);
+  for (int l = 0; l < P.nlayers; l++) stride = max(stride, P.width[l]);
+  float* xin = sh + le * stride;
+  float* xout = sh + (POL_ENVS + le) * stride;
+  if (e < B)
+    for (int i = j; i < P.obs_dim; i += POL_MAXW) xin[i] = (obs[(size_t)e * P.obs_dim + i] - P.mean[i]) / P.std[i];
+  __syncthreads();
+  int nin = P.obs_dim;
+  for (int l = 0; l < P.nlayers; l++) {
+    const int nout = P.width[l];
+    if (e < B) {
+      const float* Wl = P.W[l];
+      for (int jj = j; jj < nout; jj += POL_MAXW) {
+        float acc = P.b[l][jj];
+        for (int i = 0; i < nin; i++) acc += xin[i] * Wl[(size_t)i * nout + jj];
+        xout[jj] = (l + 1 < P.nlayers) ? acc / (1.0f + expf(-acc)) : acc;     // swish on hidden layers, linear head
+      }
+    }
+    __syncthreads();
+    float* t = xin; xin = xout; xout = t;
+    nin = nout;
+  }
+  if (e < B) {
+    for (int jj = j; jj < P.act_dim; jj += POL_MAXW) {
+      float loc = xin[jj], a = loc;
+      if (!deterministic) {
+        float raw = xin[P.act_dim + jj];
+        float scale = (raw > 20.f ? raw : log1pf(expf(raw))) + 0.001f;
+        uint64_t ge = (uint64_t)(e + env_offset);
+        float u1 = fmaxf(u01(seed ^ 0x5851F42D4C957F2Dull, ge * 1024 + jj, step), 1e-7f), u2 = u01(seed ^ 0x14057B7EF767814Full, ge * 1024 + jj, step);
+        a = loc + scale * sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);   // Box-Muller
+      }
+      action[(size_t)e * P.act_dim + jj] = tanhf(a);
+    }
+  }
+}
+
 // auto_max > 0: gym TimeLimit / done auto-reset (reset iff done or elapsed >= auto_max); else mask-driven reset
 __global__ void reset_kernel(DevBatch Bt, TaskDev T, int nq, int nv, int nu, const float* qpos0, const uint8_t* mask, uint64_t seed, int env_offset,
                              int auto_max) {
@@ -2710,7 +2796,11 @@ __global__ void reset_kernel(DevBatch Bt, TaskDev T, int nq, int nv, int nu, con
     Bt.qvel[(size_t)e * nv + i] = T.init_qvel ? T.init_qvel[i] : 0.f;
     Bt.warm[(size_t)e * nv + i] = 0;
   }
-  for (int i = 0; i < nu; i++) { Bt.act[(size_t)e * nu + i] = 0; Bt.ctrl[(size_t)e * nu + i] = 0; }
+  for (int i = 0; i < nu; i++) {
+    Bt.act[(size_t)e * nu + i] = 0; Bt.ctrl[(size_t)e * nu + i] = 0;
+    // fatigue compartments: all motor units resting (CumulativeFatigue.reset defaults, fatigue.py:130-134)
+    Bt.fatigue[(size_t)e * 3 * nu + i] = 0.f; Bt.fatigue[(size_t)e * 3 * nu + nu + i] = 1.f; Bt.fatigue[(size_t)e * 3 * nu + 2 * nu + i] = 0.f;
+  }
   Bt.time[e] = 0;
   for (int i = 0; i < T.ntarget; i++) {
     float lo = T.target_lo[i], hi = T.target_hi[i];
@@ -3099,6 +3189,7 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   BA(d.flags, B) BA(d.diag, (size_t)B * 8) BA(d.elapsed, B) BA(d.episode, B)
   BA(b->d_tlo, b->ntarget_alloc) BA(b->d_thi, b->ntarget_alloc) BA(b->d_init, nq) BA(b->d_jlo, nv) BA(b->d_jhi, nv)
   BA(b->d_action, (size_t)B * nu)
+  BA(d.fatigue, (size_t)B * 3 * nu)
   BA(b->d_initv, nv)
   { void* pw = nullptr; if ((rc = balloc(b, &pw, sizeof(DevWalk)))) { myo_batch_free(b); return rc; } b->d_walk = (DevWalk*)pw; }
   BA(b->d_stamps, (size_t)B * 12 * 2)
@@ -3112,6 +3203,12 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   std::vector<float> q((size_t)B * nq);
   for (int e = 0; e < B; e++) memcpy(&q[(size_t)e * nq], m->qpos0.data(), nq * 4);
   HIPCHK(hipMemcpy(d.qpos, q.data(), q.size() * 4, hipMemcpyHostToDevice));
+  {
+    std::vector<float> f((size_t)B * 3 * nu, 0.f);
+    for (int e = 0; e < B; e++) for (int i = 0; i < nu; i++) f[(size_t)e * 3 * nu + nu + i] = 1.f;      // MR = 1
+    HIPCHK(hipMemcpy(d.fatigue, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+    d.fat_dt = m->dm.timestep; d.reaf_epl = d.reaf_eip = -1;
+  }
   b->task.task = MYO_TASK_NONE; b->task.frame_skip = 1; b->task.obs_dim = 0; b->task.ntarget = 0;
   b->task.jnt_lo = b->d_jlo; b->task.jnt_hi = b->d_jhi; b->task.init_qpos = b->d_init; b->task.target_lo = b->d_tlo; b->task.target_hi = b->d_thi;
   b->task.init_qvel = nullptr;
@@ -3220,6 +3317,8 @@ static int field_info(myo_batch* b, int f, void** p, size_t* pitch, size_t* widt
     case MYO_F_TENLEN: *p = d.tenlen; *pitch = *width = nu; break;
     case MYO_F_ACTFORCE: *p = d.actforce; *pitch = *width = nu; break;
     case MYO_F_ELAPSED: *p = d.elapsed; *pitch = *width = 1; break;
+    case MYO_F_ACTION: *p = b->d_action; *pitch = *width = nu; break;
+    case MYO_F_FATIGUE: *p = d.fatigue; *pitch = *width = 3 * nu; break;
     case MYO_F_SITEXPOS: *p = d.sitexpos; *pitch = *width = b->task.ntip > 0 ? 3 * b->task.ntip : 1; break;
     default: return fail(MYO_E_ARG, "unknown field");
   }
@@ -3381,6 +3480,15 @@ int myo_obs_only(myo_batch* b, void* stream) {
   return launch_obs(b, (hipStream_t)stream, 1);
 }
 
+int myo_batch_set_condition(myo_batch* b, int frame_skip, int epl_actuator, int eip_actuator) {
+  if (!b || frame_skip <= 0) return fail(MYO_E_ARG, "myo_batch_set_condition: bad arguments");
+  const int nu = b->model->dm.nu;
+  if (epl_actuator >= nu || eip_actuator >= nu) return fail(MYO_E_ARG, "myo_batch_set_condition: actuator id out of range");
+  b->db.fat_dt = (float)frame_skip * b->model->dm.timestep;
+  b->db.reaf_epl = epl_actuator; b->db.reaf_eip = eip_actuator;
+  return MYO_OK;
+}
+
 int myo_obs_reset_only(myo_batch* b, void* stream) {
   if (!b) return fail(MYO_E_ARG, "myo_obs_reset_only: null");
   HIPCHK(hipSetDevice(b->model->device));
@@ -3463,6 +3571,65 @@ int myo_bench_rollout(myo_batch* b, int steps, int nsubsteps, uint64_t seed, int
 int myo_bench_last_kernel_ms(myo_batch* b, float* ms_out) {
   if (!b || !ms_out) return fail(MYO_E_ARG, "null");
   *ms_out = b->last_kernel_ms;
+  return MYO_OK;
+}
+
+struct myo_policy {
+  int device = 0;
+  PolicyDev pd{};
+  std::vector<void*> dev_allocs;
+};
+
+int myo_policy_load(int device, int obs_dim, int act_dim, int nlayers, const int* layer_out, const float* obs_mean, const float* obs_std,
+                    const float* const* kernels, const float* const* biases, myo_policy** out) {
+  if (!out || !layer_out || !obs_mean || !obs_std || !kernels || !biases || obs_dim <= 0 || act_dim <= 0 || nlayers <= 0 || nlayers > 8)
+    return fail(MYO_E_ARG, "myo_policy_load: bad arguments");
+  if (layer_out[nlayers - 1] != 2 * act_dim) return fail(MYO_E_ARG, "myo_policy_load: last layer must have 2*act_dim outputs (loc, scale)");
+  for (int l = 0; l < nlayers; l++) if (layer_out[l] <= 0 || layer_out[l] > 512) return fail(MYO_E_UNSUPPORTED, "myo_policy_load: layer width must be in 1..512");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(MYO_E_HIP, "myo_policy_load: no such HIP device");
+  HIPCHK(hipSetDevice(device));
+  myo_policy* p = new myo_policy();
+  p->device = device;
+  PolicyDev& P = p->pd;
+  P.obs_dim = obs_dim; P.act_dim = act_dim; P.nlayers = nlayers;
+  auto up = [&](const float* src, size_t n, const float** dst) -> int {
+    void* d = nullptr;
+    if (hipMalloc(&d, n * 4) != hipSuccess) return fail(MYO_E_NOMEM, "hipMalloc policy");
+    p->dev_allocs.push_back(d);
+    if (hipMemcpy(d, src, n * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(MYO_E_HIP, "hipMemcpy policy");
+    *dst = (const float*)d;
+    return 0;
+  };
+  int rc = 0, nin = obs_dim;
+  if ((rc = up(obs_mean, obs_dim, &P.mean)) || (rc = up(obs_std, obs_dim, &P.std))) { myo_policy_free(p); return rc; }
+  for (int l = 0; l < nlayers; l++) {
+    P.width[l] = layer_out[l];
+    if ((rc = up(kernels[l], (size_t)nin * layer_out[l], &P.W[l])) || (rc = up(biases[l], layer_out[l], &P.b[l]))) { myo_policy_free(p); return rc; }
+    nin = layer_out[l];
+  }
+  *out = p;
+  return MYO_OK;
+}
+
+void myo_policy_free(myo_policy* p) {
+  if (!p) return;
+  for (void* d : p->dev_allocs) (void)hipFree(d);
+  delete p;
+}
+
+int myo_policy_act(myo_policy* p, const float* obs_dev, int B, float* action_dev, int deterministic, uint64_t seed, uint64_t step,
+                   int env_offset, void* stream) {
+  if (!p || !obs_dev || !action_dev || B <= 0) return fail(MYO_E_ARG, "myo_policy_act: bad arguments");
+  HIPCHK(hipSetDevice(p->device));
+  int stride = p->pd.obs_dim > POL_MAXW ? p->pd.obs_dim : POL_MAXW;
+  for (int l = 0; l < p->pd.nlayers; l++) if (p->pd.width[l] > stride) stride = p->pd.width[l];
+  size_t lds = (size_t)2 * POL_ENVS * stride * 4;
+  if (lds > 64 * 1024) return fail(MYO_E_UNSUPPORTED, "myo_policy_act: observation too wide for the LDS tile");
+  hipLaunchKernelGGL(policy_kernel, dim3((B + POL_ENVS - 1) / POL_ENVS), dim3(POL_ENVS * POL_MAXW), lds, (hipStream_t)stream, p->pd, obs_dev, B,
+                     action_dev, deterministic, seed, step, env_offset);
+  HIPCHK(hipGetLastError());
   return MYO_OK;
 }
 

@@ -83,6 +83,13 @@ REGISTRY["myoLegWalk-v0"] = dict(
     model="myolegs", task="walk", max_episode_steps=1000, frame_skip=10, normalize_act=True, reset_type="init",
     min_height=0.8, max_rot=0.8, hip_period=100, target_x_vel=0.0, target_y_vel=1.2, target_rot=None,
     weights=dict(vel_reward=5.0, done=-100.0, cyclic_hip=-10.0, ref_rot=10.0, joint_angle_rew=5.0))
+# muscle-condition variants (register_env_with_variants, envs/myo/myobase/__init__.py:14-48): myoSarc* (sarcopenia), myoFati* (fatigue)
+# for every myo* id, myoReaf* (EIP -> EPL tendon transfer) for the myoHand* ids
+for _id in [k for k in list(REGISTRY) if k.startswith("myo")]:
+    REGISTRY[_id[:3] + "Sarc" + _id[3:]] = dict(REGISTRY[_id], muscle_condition="sarcopenia")
+    REGISTRY[_id[:3] + "Fati" + _id[3:]] = dict(REGISTRY[_id], muscle_condition="fatigue")
+    if _id.startswith("myoHand"):
+        REGISTRY[_id[:3] + "Reaf" + _id[3:]] = dict(REGISTRY[_id], muscle_condition="reafferentation")
 # registered by the reference but not runnable on the HIP path (DESIGN.md "out of scope")
 UNSUPPORTED = {
     "myoLegRoughTerrainWalk-v0": "height-field terrain contacts are not implemented in the HIP kernel",
@@ -132,6 +139,9 @@ class BatchedMyoEnv:
         self.autoreset = autoreset
         self.as_torch = as_torch
         self.mjmodel = _model.load_asset(spec["model"])
+        self.muscle_condition = spec.get("muscle_condition", "")
+        if self.muscle_condition == "sarcopenia":                      # base_v0.py:64-68: a model edit
+            self.mjmodel = self.mjmodel.with_sarcopenia()
         self.model = capi.HipModel(self.mjmodel.blob(), device)       # raises if there is no GPU / no library
         self.batch = capi.HipBatch(self.model, self.num_envs)
         self.batch.set_env_offset(env_offset)
@@ -174,6 +184,13 @@ class BatchedMyoEnv:
                                  far_th=spec["far_th"] * n, near_th=0.0125 * n,
                                  w_reach=w["reach"], w_bonus=w["bonus"], w_act_reg=w["act_reg"], w_penalty=w["penalty"])
             self.obs_dim = 2 * m.nq + 6 * n + m.na
+        self.actmap = capi.ACTMAP_MUSCLE_SIGMOID
+        if self.muscle_condition == "fatigue":                         # base_v0.py:70-74, 100-104
+            self.actmap = capi.ACTMAP_SIGMOID_FATIGUE
+            self.batch.set_condition(self.frame_skip)
+        elif self.muscle_condition == "reafferentation":               # base_v0.py:76-80, 105-109
+            self.actmap = capi.ACTMAP_SIGMOID_REAFFERENTATION
+            self.batch.set_condition(self.frame_skip, m.name2id("actuator", "EPL"), m.name2id("actuator", "EIP"))
         self.act_dim = m.nu
         self.action_space = Box(-1.0, 1.0, (m.nu,))                    # env_base.py:101-113 (normalize_act)
         self.observation_space = Box(-10.0, 10.0, (self.obs_dim,))     # env_base.py:172-176
@@ -216,13 +233,12 @@ class BatchedMyoEnv:
         if self.as_torch:
             a = self._torch.as_tensor(action, dtype=self._torch.float32, device=self._action_buf.device)
             a = self._torch.clamp(a, -1.0, 1.0, out=self._action_buf)      # env_base.py:341 (clip to action space)
-            self.batch.step(a.data_ptr(), capi.ACTMAP_MUSCLE_SIGMOID, self.frame_skip, s)
+            self.batch.step(a.data_ptr(), self.actmap, self.frame_skip, s)
         else:
-            import ctypes
             a = np.clip(np.ascontiguousarray(action, np.float32).reshape(self.num_envs, self.act_dim), -1, 1)
-            # host actions go through the CTRL field: apply the muscle sigmoid here (base_v0.py:87-91)
-            self.batch.write(capi.F_CTRL, 1.0 / (1.0 + np.exp(-5.0 * (a - 0.5))))
-            self.batch.step(None, capi.ACTMAP_NONE, self.frame_skip, s)
+            # host actions are uploaded into the library's action buffer; the action map runs in the step kernel either way
+            self.batch.write(capi.F_ACTION, a)
+            self.batch.step(self.batch.field_ptr(capi.F_ACTION)[0], self.actmap, self.frame_skip, s)
         if self.spec["task"] != "walk":      # the walk task's observation / reward pass is fused into the step kernel
             self.batch.obs(s)
         if self.as_torch:

@@ -298,9 +298,10 @@ def lower(cm):
     act = np.zeros((nu, ACT_FLTS))
     for i in range(nu):
         gp, bp = m.actuator_gainprm[i], m.actuator_biasprm[i]
-        if not np.allclose(gp, bp):
-            raise NotImplementedError("HIP path: muscle gainprm != biasprm")
+        if not np.allclose(np.delete(gp, 2), np.delete(bp, 2)):
+            raise NotImplementedError("HIP path: muscle gainprm != biasprm (other than the peak force)")
         force = gp[2] if gp[2] >= 0 else gp[3] / max(1e-15, m.actuator_acc0[i])
+        bforce = bp[2] if bp[2] >= 0 else bp[3] / max(1e-15, m.actuator_acc0[i])     # sarcopenia halves the gain's force only
         lr = m.actuator_lengthrange[i]
         cr = m.actuator_ctrlrange[i] if m.actuator_ctrllimited[i] else (-1e30, 1e30)
         if m.actuator_forcelimited[i]:
@@ -308,7 +309,7 @@ def lower(cm):
         if m.actuator_dynprm[i, 2] != 0:
             raise NotImplementedError("HIP path: muscle tausmooth")
         act[i] = [gp[0], gp[1], force, gp[4], gp[5], gp[6], gp[7], gp[8], lr[0], lr[1],
-                  m.actuator_dynprm[i, 0], m.actuator_dynprm[i, 1], cr[0], cr[1], m.actuator_gear[i], 0.0]
+                  m.actuator_dynprm[i, 0], m.actuator_dynprm[i, 1], cr[0], cr[1], m.actuator_gear[i], bforce]
     # ---- collision geoms + pair table
     # reach bound: every point of link l stays within reach[l] + |p - anchor_l| of the (static) anchor of its root link,
     # where anchor_l is the link's first joint position; distances between consecutive anchors are pose invariant

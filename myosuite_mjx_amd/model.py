@@ -59,6 +59,18 @@ class Model:
             self._blob = _blob.pack(self.arrays)
         return self._blob
 
+    def with_sarcopenia(self) -> "Model":
+        """Copy of the model with the muscle condition "sarcopenia" applied (BaseV0.initializeConditions,
+        envs/myo/base_v0.py:64-68): the peak force entry of every actuator's gainprm is halved (biasprm is left alone)."""
+        arrays = {k: np.array(v, copy=True) for k, v in self.arrays.items()}
+        gp = arrays["actuator_gainprm"].reshape(self.nu, -1)
+        gp[:, 2] *= 0.5
+        if "hip_act" in arrays:
+            act = arrays["hip_act"].reshape(self.nu, -1)
+            pos = gp[:, 2] >= 0          # a negative entry means "scale / acc0", which the halving does not change
+            act[pos, 2] = gp[pos, 2]
+        return Model(arrays, self.names, self.source)
+
     def save(self, stem):
         with open(stem + ".myob", "wb") as f:
             f.write(self.blob())
