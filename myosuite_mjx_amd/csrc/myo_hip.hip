@@ -2776,66 +2776,68 @@ __global__ void __launch_bounds__(POL_ENVS * POL_MAXW) policy_kernel(PolicyDev P
   }
 }
 
-// auto_max > 0: gym TimeLimit / done auto-reset (reset iff done or elapsed >= auto_max); else mask-driven reset
-__global__ void reset_kernel(DevBatch Bt, TaskDev T, int nq, int nv, int nu, const float* qpos0, const uint8_t* mask, uint64_t seed, int env_offset,
-                             int auto_max) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
+// auto_max > 0: gym TimeLimit / done auto-reset (reset iff done or elapsed >= auto_max); else mask-driven reset.
+// One 64-lane workgroup per env: envs that are not reset leave after one test, the others write their rows coalesced
+// (one thread per env needed ~500 serialised scattered stores per reset: 27 ms for a full reset of 4096 leg envs)
+__global__ void __launch_bounds__(64) reset_kernel(DevBatch Bt, TaskDev T, int nq, int nv, int nu, const float* qpos0, const uint8_t* mask, uint64_t seed,
+                                                  int env_offset, int auto_max) {
+  const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= Bt.B) return;
   if (auto_max > 0) { if (!(Bt.done[e] > 0.f || Bt.elapsed[e] >= auto_max)) return; }
   else if (mask && !mask[e]) return;
-  seed += 0x632BE59BD9B4E019ull * (uint64_t)(Bt.episode[e]++);  // a fresh RNG stream per (env, episode)
-  Bt.elapsed[e] = 0;
-  Bt.done[e] = 0.f;
+  seed += 0x632BE59BD9B4E019ull * (uint64_t)Bt.episode[e];  // a fresh RNG stream per (env, episode)
+  __syncthreads();                                            // every lane has read done / elapsed / episode before lane 0 updates them
+  if (lane == 0) { Bt.episode[e] += 1; Bt.elapsed[e] = 0; Bt.done[e] = 0.f; Bt.time[e] = 0; }
   uint64_t ge = (uint64_t)(e + env_offset);
-  for (int i = 0; i < nq; i++) {
+  for (int i = lane; i < nq; i += 64) {
     float q = T.init_qpos ? T.init_qpos[i] : qpos0[i];
     if (T.reset_random) q = T.jnt_lo[i] + (T.jnt_hi[i] - T.jnt_lo[i]) * u01(seed, ge * 4096 + i, 1);   // nq == nv checked at configure
     Bt.qpos[(size_t)e * nq + i] = q;
   }
-  for (int i = 0; i < nv; i++) {
+  for (int i = lane; i < nv; i += 64) {
     Bt.qvel[(size_t)e * nv + i] = T.init_qvel ? T.init_qvel[i] : 0.f;
     Bt.warm[(size_t)e * nv + i] = 0;
   }
-  for (int i = 0; i < nu; i++) {
+  for (int i = lane; i < nu; i += 64) {
     Bt.act[(size_t)e * nu + i] = 0; Bt.ctrl[(size_t)e * nu + i] = 0;
     // fatigue compartments: all motor units resting (CumulativeFatigue.reset defaults, fatigue.py:130-134)
     Bt.fatigue[(size_t)e * 3 * nu + i] = 0.f; Bt.fatigue[(size_t)e * 3 * nu + nu + i] = 1.f; Bt.fatigue[(size_t)e * 3 * nu + 2 * nu + i] = 0.f;
   }
-  Bt.time[e] = 0;
-  for (int i = 0; i < T.ntarget; i++) {
+  for (int i = lane; i < T.ntarget; i += 64) {
     float lo = T.target_lo[i], hi = T.target_hi[i];
     Bt.target[(size_t)e * T.ntarget + i] = T.target_generate ? lo + (hi - lo) * u01(seed, ge * 4096 + 2048 + i, 2) : lo;
   }
 }
 
-// observation + reward (pose_v0.py:98-138, reach_v0.py:88-144, obs_vec_dict.py:86-98); one lane per env
-__global__ void obs_kernel(DevModel M, DevBatch Bt, TaskDev T, int obs_only) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
+// observation + reward (pose_v0.py:98-138, obs_vec_dict.py:86-98); one 64-lane workgroup per env, rows written coalesced
+__global__ void __launch_bounds__(64) obs_kernel(DevModel M, DevBatch Bt, TaskDev T, int obs_only, int reset_only) {
+  const int e = blockIdx.x, lane = threadIdx.x;
   if (e >= Bt.B) return;
+  if (reset_only && Bt.elapsed[e] != 0) return;    // refresh only the rows of envs an auto-reset just touched
   const int nv = M.nv, nu = M.nu;
   float dt = (float)T.frame_skip * M.timestep;
   float* o = Bt.obs + (size_t)e * T.obs_dim;
   const float* q = Bt.qpos + (size_t)e * nv;
   const float* v = Bt.qvel + (size_t)e * nv;
   const float* a = Bt.act + (size_t)e * nu;
-  float actn = 0;
-  for (int i = 0; i < nu; i++) actn += a[i] * a[i];
-  actn = sqrtf(actn) / (float)(nu > 0 ? nu : 1);
   if (T.task == MYO_TASK_POSE) {
-    float err2 = 0;
-    for (int i = 0; i < nv; i++) {
-      float pe = Bt.target[(size_t)e * T.ntarget + i] - q[i];
-      o[i] = q[i]; o[nv + i] = v[i] * dt; o[2 * nv + i] = pe;
+    float err2 = 0, act2 = 0;
+    for (int i = lane; i < nv; i += 64) {
+      float qi = q[i], pe = Bt.target[(size_t)e * T.ntarget + i] - qi;
+      o[i] = qi; o[nv + i] = v[i] * dt; o[2 * nv + i] = pe;
       err2 += pe * pe;
     }
-    for (int i = 0; i < nu; i++) o[3 * nv + i] = a[i];
+    for (int i = lane; i < nu; i += 64) { float ai = a[i]; o[3 * nv + i] = ai; act2 += ai * ai; }
     if (obs_only) return;
-    float dist = sqrtf(err2);
-    float bonus = (dist < T.pose_thd ? 1.f : 0.f) + (dist < 1.5f * T.pose_thd ? 1.f : 0.f);
-    float pen = dist > T.far_th ? -1.f : 0.f;
-    Bt.reward[e] = T.w_pose * (-dist) + T.w_bonus * bonus + T.w_act_reg * (-actn) + T.w_penalty * pen;
-    Bt.solved[e] = dist < T.pose_thd ? 1.f : 0.f;
-    Bt.done[e] = dist > T.far_th ? 1.f : 0.f;
+    float dist = sqrtf(wave_sum(err2));
+    float actn = sqrtf(wave_sum(act2)) / (float)(nu > 0 ? nu : 1);
+    if (lane == 0) {
+      float bonus = (dist < T.pose_thd ? 1.f : 0.f) + (dist < 1.5f * T.pose_thd ? 1.f : 0.f);
+      float pen = dist > T.far_th ? -1.f : 0.f;
+      Bt.reward[e] = T.w_pose * (-dist) + T.w_bonus * bonus + T.w_act_reg * (-actn) + T.w_penalty * pen;
+      Bt.solved[e] = dist < T.pose_thd ? 1.f : 0.f;
+      Bt.done[e] = dist > T.far_th ? 1.f : 0.f;
+    }
   }
 }
 
@@ -3359,7 +3361,7 @@ int myo_reset(myo_batch* b, const uint8_t* mask_dev, uint64_t seed, void* stream
   const DevModel& dm = b->model->dm;
   HIPCHK(hipSetDevice(b->model->device));
   int B = b->db.B;
-  hipLaunchKernelGGL(reset_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->db, b->task, b->model->nq, dm.nv, dm.nu, dm.qpos0, mask_dev, seed,
+  hipLaunchKernelGGL(reset_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, b->db, b->task, b->model->nq, dm.nv, dm.nu, dm.qpos0, mask_dev, seed,
                      b->env_offset, 0);
   HIPCHK(hipGetLastError());
   return MYO_OK;
@@ -3370,7 +3372,7 @@ int myo_autoreset(myo_batch* b, int max_episode_steps, uint64_t seed, void* stre
   const DevModel& dm = b->model->dm;
   HIPCHK(hipSetDevice(b->model->device));
   int B = b->db.B;
-  hipLaunchKernelGGL(reset_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, b->db, b->task, b->model->nq, dm.nv, dm.nu, dm.qpos0,
+  hipLaunchKernelGGL(reset_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, b->db, b->task, b->model->nq, dm.nv, dm.nu, dm.qpos0,
                      (const uint8_t*)nullptr, seed, b->env_offset, max_episode_steps);
   HIPCHK(hipGetLastError());
   return MYO_OK;
@@ -3457,7 +3459,7 @@ static int launch_obs(myo_batch* b, hipStream_t s, int obs_only = 0, int reset_o
     // the walk observation lives in the step kernel: run it with zero substeps as an observation-only pass
     return launch_step(b, nullptr, MYO_ACTMAP_NONE, 0, s, KF_AUX | (obs_only ? KF_OBS_ONLY : 0) | (reset_only ? KF_RESET_ONLY : 0));
   } else if (b->task.task == MYO_TASK_POSE) {
-    hipLaunchKernelGGL(obs_kernel, dim3((B + 63) / 64), dim3(64), 0, s, m->dm, b->db, b->task, obs_only);
+    hipLaunchKernelGGL(obs_kernel, dim3(B), dim3(64), 0, s, m->dm, b->db, b->task, obs_only, reset_only);
   } else if (b->task.task == MYO_TASK_REACH) {
     const int EPW = 4;
     hipLaunchKernelGGL(reach_obs_kernel<16>, dim3((B + EPW - 1) / EPW), dim3(64), (size_t)EPW * m->env_lds_bytes, s, m->dm, b->db, b->task, obs_only);
