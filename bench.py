@@ -126,7 +126,7 @@ def main():
     # the committed rocprofv3 measurement of the same kernel / batch (profiles/, separate FETCH_SIZE / WRITE_SIZE passes)
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_d_pmc_step_kernel_wave.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r1_f_pmc_step_kernel_hand.json")) as f:
             t = json.load(f)["traffic"]
         if B == B_PER_GPU and env_id == ENV_ID:
             traffic = t["hbm_bytes_per_launch_raw"]

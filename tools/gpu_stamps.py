@@ -19,7 +19,7 @@ for lanes, bal in ((64, 0), (64, 1)):
     ms = env.batch.bench_rollout(10, 10, 0, 0, 0, None) / 10
     nwg = B // (64 // lanes)
     st, ok = capi.read_stamps(env.batch, nwg)
-    tot = st.sum(1)
+    tot = st[:, :10].sum(1)          # columns 10, 11 hold hardware ids, not cycles
     print(f"== lanes/env {lanes} balance {bal}: step kernel {ms:.3f} ms per env-step ({B/ms*1e3:,.0f} env-steps/s); per-WG total cycles mean {tot.mean():,.0f} max {tot.max():,.0f} (10 substeps)")
     for k, n in enumerate(NAMES):
         print(f"   {n:26s} {st[:,k].mean()/10:12,.0f} cycles/substep  {100*st[:,k].mean()/tot.mean():5.1f}%")
