@@ -65,7 +65,8 @@ typedef enum myo_field {
   MYO_F_COUNT
 } myo_field;
 
-enum { MYO_FLAG_BAD_STATE = 1, MYO_FLAG_BAD_QACC = 2, MYO_FLAG_CONTACT_OVERFLOW = 4, MYO_FLAG_CAND_OVERFLOW = 8 };
+enum { MYO_FLAG_BAD_STATE = 1, MYO_FLAG_BAD_QACC = 2, MYO_FLAG_CONTACT_OVERFLOW = 4, MYO_FLAG_CAND_OVERFLOW = 8,
+       MYO_FLAG_SCHED_TIMEOUT = 16 /* opt-in substep scheduler gave up waiting (raised on env 0); the step is incomplete */ };
 
 /* action -> control map applied inside myo_step (base_v0.py:87-91) */
 enum {

@@ -1586,10 +1586,56 @@ __device__ __forceinline__ float straight_w(const DevModel& M, const LayW& Y, fl
   return active ? dist * invdiv : 0.f;
 }
 
-template <int NVT, int KC, int NC, int NTR, int WPE>
+// ------------------------------------------------------------------------------------------------
+// Substep-granular dynamic scheduling (opt-in, MYO_SCHED=1).  With one workgroup per env, a launch of B = 4096 envs fills every
+// wave slot of the chip exactly once and lasts as long as its slowest SIMD (env work varies +-12 %).  Here the waves are
+// persistent instead: the unit of work is ONE substep of one env.  Each XCD owns a FIFO ring of its envs (state stays in that
+// XCD's L2); a wave takes a ticket, waits until the ticket's slot is published, loads the env's state, runs the substep, stores
+// the state and publishes the env's next substep at the tail.  Envs advance in near lock-step, so the imbalance that is left is
+// that of a single substep.  No wave ever waits while it holds work, published work is always held by a running wave, and the
+// ticket count is fixed (envs x substeps), so every wave terminates; spins are capped anyway and a timeout raises a flag.
+template <bool S> __device__ __forceinline__ float ldstate(const float* p) {
+  if (S) return __int_as_float(__hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  return *p;
+}
+template <bool S> __device__ __forceinline__ int ldstatei(const int* p) {
+  if (S) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+struct SchedDev {
+  int* ctl;      // [8][4]: head (next ticket), tail (next publish index), n (envs of this queue), error
+  int* ring;     // [8][stride]: gen << 24 | substep << 20 | env
+  int stride, nsubtot;
+};
+#define SCHED_ENV_MASK 0xFFFFF
+__global__ void __launch_bounds__(1024) sched_init_kernel(const int* __restrict__ diag, int B, SchedDev S) {
+  __shared__ int hist[256], start[256];
+  __shared__ int cmax_s;
+  const int t = threadIdx.x;
+  if (t < 256) hist[t] = 0;
+  if (t == 0) cmax_s = 1;
+  if (t < 8) { int n = (B - t + 7) / 8; S.ctl[4 * t] = 0; S.ctl[4 * t + 1] = n; S.ctl[4 * t + 2] = n; S.ctl[4 * t + 3] = 0; }
+  __syncthreads();
+  int cm = 1;
+  for (int e = t; e < B; e += 1024) cm = max(cm, diag[(size_t)e * 8 + 3]);
+  atomicMax(&cmax_s, cm);
+  __syncthreads();
+  const int cmax = cmax_s;
+  for (int e = t; e < B; e += 1024) atomicAdd(&hist[255 - min(255, (int)(255LL * diag[(size_t)e * 8 + 3] / cmax))], 1);   // bucket 0 = heaviest
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int k = 0; k < 256; k++) { start[k] = acc; acc += hist[k]; } }
+  __syncthreads();
+  for (int e = t; e < B; e += 1024) {
+    int b = 255 - min(255, (int)(255LL * diag[(size_t)e * 8 + 3] / cmax));
+    int r = atomicAdd(&start[b], 1);                  // rank by descending predicted cost: heavy envs are served first
+    S.ring[(r & 7) * S.stride + (r >> 3)] = e;        // generation 0, substep 0
+  }
+}
+
+template <int NVT, int KC, int NC, int NTR, int WPE, bool SCHED>
 __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restrict__ Mp, const DevModelW* __restrict__ Wp, DevBatch Bt,
                                                         const float* __restrict__ action, int actmap, int nsub, long long* stamps,
-                                                        const int* __restrict__ order, const DevWalk* __restrict__ wk, int kflags) {
+                                                        const int* __restrict__ order, const DevWalk* __restrict__ wk, int kflags, SchedDev S) {
   extern __shared__ __align__(16) float E[];
   // the model structs stay in (scalar-cached) global memory: fields are s_load-ed where they are used instead of
   // pinning ~150 SGPRs for the whole kernel
@@ -1599,15 +1645,17 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   const int lane_id = threadIdx.x;
   // workgroup -> env map: a speed-only placement hint (envs sorted by last step's cost, see balance_kernel); results of an
   // env never depend on which workgroup steps it
-  const int oe = order ? order[blockIdx.x] : blockIdx.x;
-  const int env = oe & 0x0FFFFFFF;
+  const int oe = (!SCHED && order) ? order[blockIdx.x] : blockIdx.x;
+  int env = oe & 0x0FFFFFFF;
   // the four waves of a SIMD come from different cost quartiles (balance_kernel); the predicted-heavy ones get a higher issue
   // priority so that the launch's critical path -- its heaviest waves -- is not slowed down by lighter neighbours that have slack
-  switch (oe >> 28) {
-    case 3: __builtin_amdgcn_s_setprio(3); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    default: break;
+  if (!SCHED) {
+    switch (oe >> 28) {
+      case 3: __builtin_amdgcn_s_setprio(3); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      default: break;
+    }
   }
   const int nv = M.nv, nu = M.nu, nq = W.nq;
   constexpr int CDW = (KC + 3) / 4;   // ints per contact holding its KC byte-packed dof ids
@@ -1617,36 +1665,69 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   const bool has_free = FULL && W.has_free;
   const int neq = FULL ? W.neq : 0;
   const bool walk = FULL && wk != nullptr;   // fused observation / reward pass of the walk task after the last substep
-  if (FULL && (kflags & KF_RESET_ONLY) && Bt.elapsed[env] != 0) return;   // wave-uniform: refresh only the envs an auto-reset just touched
+  if (!SCHED && FULL && (kflags & KF_RESET_ONLY) && Bt.elapsed[env] != 0) return;   // wave-uniform: refresh only the envs an auto-reset just touched
 #if MYO_STAMPS
   long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long st_t0 = clock64();
 #endif
-  // ---- state: LDS copies of what other lanes gather; per-dof / per-actuator scalars stay in registers
-  float warm = 0.f, qacc = 0.f, actdot[NTR];
-#pragma unroll
-  for (int r = 0; r < NTR; r++) actdot[r] = 0.f;
-  if (lane_id < nq) E[Y.qpos + lane_id] = Bt.qpos[(size_t)env * nq + lane_id];
-  if (lane_id < nv) {
-    E[Y.qvel + lane_id] = Bt.qvel[(size_t)env * nv + lane_id];
-    warm = Bt.warm[(size_t)env * nv + lane_id];
-  }
-  for (int i = lane_id; i < nu; i += 64) {
-    E[Y.act + i] = Bt.act[(size_t)env * nu + i];
-    float c;
-    if (action) c = action_map(Bt, M.act, action, env, i, nu, actmap);
-    else c = Bt.ctrl[(size_t)env * nu + i];
-    E[Y.ctrl + i] = c;
-  }
-  float time = Bt.time[env];
-  int flags = 0, d_nefc = 0, d_ncon = 0, d_iter = 0, d_cost = 0;
-  int f_cand = 0, f_mpr = 0, f_ncon = 0, f_iter = 0, f_itcon = 0, f_ls = 0, f_fact = 0;   // work features of this env step (placement cost model)
-  bool alive = true;
+  const int nsubtot = nsub + (walk ? 1 : 0);
   const float h = M.timestep;
   const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
   const float damping = lane_id < nv ? M.dof_damping[lane_id] : 0.f;
+  // scheduler state of this wave: the queue of the XCD it runs on
+  const int sq_q = SCHED ? (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7) : 0;
+  int* const sq_ctl = SCHED ? S.ctl + 4 * sq_q : nullptr;
+  int* const sq_ring = SCHED ? S.ring + (size_t)sq_q * S.stride : nullptr;
+  const int sq_n = SCHED ? sq_ctl[2] : 0;
+  int last_cost = 0;
+  for (;;) {   // task loop: one (env, substep) per pass when SCHED, a single pass over all substeps of this workgroup's env otherwise
+  int s0 = 0, s1 = nsubtot;
+  if (SCHED) {
+    int t = 0;
+    if (lane_id == 0) t = atomicAdd(&sq_ctl[0], 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= sq_n * nsubtot) break;                       // every ticket of this queue is taken: this wave is done
+    const int gen = t / sq_n, slot = t - gen * sq_n;
+    int v = 0, spins = 0;
+    for (;;) {                                            // wait until the slot of this ticket has been published
+      v = __hip_atomic_load(&sq_ring[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((v >> 24) == gen || ++spins > (1 << 21)) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    v = __builtin_amdgcn_readfirstlane(v);
+    if ((v >> 24) != gen) { if (lane_id == 0) { atomicOr(&Bt.flags[0], MYO_FLAG_SCHED_TIMEOUT); sq_ctl[3] = 1; } break; }
+    env = v & SCHED_ENV_MASK;
+    s0 = (v >> 20) & 15; s1 = s0 + 1;
+  }
+  // ---- state: LDS copies of what other lanes gather; per-dof / per-actuator scalars stay in registers.  Under the scheduler the
+  // rows were written by another CU of this XCD: agent-scope loads read them from L2 instead of a possibly stale L1 line
+  float warm = 0.f, qacc = 0.f, actdot[NTR];
+#pragma unroll
+  for (int r = 0; r < NTR; r++) actdot[r] = 0.f;
+  if (lane_id < nq) E[Y.qpos + lane_id] = ldstate<SCHED>(Bt.qpos + (size_t)env * nq + lane_id);
+  if (lane_id < nv) {
+    E[Y.qvel + lane_id] = ldstate<SCHED>(Bt.qvel + (size_t)env * nv + lane_id);
+    warm = ldstate<SCHED>(Bt.warm + (size_t)env * nv + lane_id);
+  }
+  for (int i = lane_id; i < nu; i += 64) {
+    E[Y.act + i] = ldstate<SCHED>(Bt.act + (size_t)env * nu + i);
+    float c;
+    if (action && s0 == 0) c = action_map(Bt, M.act, action, env, i, nu, actmap);   // the action map runs once per env step
+    else c = ldstate<SCHED>(Bt.ctrl + (size_t)env * nu + i);
+    E[Y.ctrl + i] = c;
+  }
+  float time = ldstate<SCHED>(Bt.time + env);
+  int flags = 0, d_nefc = 0, d_ncon = 0, d_iter = 0, d_cost = 0;
+  int f_cand = 0, f_mpr = 0, f_ncon = 0, f_iter = 0, f_itcon = 0, f_ls = 0, f_fact = 0;   // work features of this env step (placement cost model)
+  if (SCHED && s0 > 0) {   // accumulators of the earlier substeps of this env step
+    const int* D = Bt.diag + (size_t)env * 8;
+    int a2 = ldstatei<SCHED>(D + 2), a4 = ldstatei<SCHED>(D + 4), a5 = ldstatei<SCHED>(D + 5), a6 = ldstatei<SCHED>(D + 6), a7 = ldstatei<SCHED>(D + 7);
+    d_nefc = ldstatei<SCHED>(D); d_ncon = ldstatei<SCHED>(D + 1);   // the observation pass has no rows of its own: keep the last substep's
+    d_iter = a2; f_cand = a4 & 0xFFFF; f_ncon = a4 >> 16; f_mpr = a5; f_itcon = a6 & 0xFFFF; f_iter = a6 >> 16; f_ls = a7 & 0xFFFF; f_fact = a7 >> 16;
+  }
+  bool alive = true;
   SYNC();
-  for (int step = 0; step < nsub + (walk ? 1 : 0); step++) {
+  for (int step = s0; step < s1; step++) {
     const bool op = walk && step == nsub;   // observation pass: position / velocity stages at the post-step state, then out
     // compiler-only barrier: keeps the (substep-invariant) model-table loads inside the loop body instead of hoisting
     // ~60 values per lane out of it and spilling them to scratch
@@ -2633,7 +2714,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     SYNC();
     STAMP(8);
   }
-  if (FULL && (kflags & KF_AUX)) return;   // observation-only launch: the state arrays are not touched
+  if (!SCHED && FULL && (kflags & KF_AUX)) return;   // observation-only launch: the state arrays are not touched
   if (!alive) {  // a bad env is reset like mj_resetData (mj_sim_scene.py:56-61)
     if (lane_id < nq) E[Y.qpos + lane_id] = M.qpos0[lane_id];
     if (lane_id < nv) { E[Y.qvel + lane_id] = 0; warm = 0; }
@@ -2652,8 +2733,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   }
   if (lane_id == 0) {
     Bt.time[env] = time;
-    Bt.elapsed[env] += 1;
-    Bt.flags[env] |= flags;
+    if (s1 == nsubtot) Bt.elapsed[env] += 1;
+    if (SCHED) { if (flags) atomicOr(&Bt.flags[env], flags); } else Bt.flags[env] |= flags;
     Bt.diag[(size_t)env * 8 + 0] = d_nefc; Bt.diag[(size_t)env * 8 + 1] = d_ncon; Bt.diag[(size_t)env * 8 + 2] = d_iter;
     // predicted work of this env's NEXT step for the placement hint, in units of 1024 single-wave cycles: linear model of this
     // step's work features and the last substep's contact / row counts, fitted on one-wave-per-SIMD runs where a wave's duration is
@@ -2665,10 +2746,21 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     Bt.diag[(size_t)env * 8 + 4] = f_cand | (f_ncon << 16); Bt.diag[(size_t)env * 8 + 5] = f_mpr;
     Bt.diag[(size_t)env * 8 + 6] = f_itcon | (f_iter << 16); Bt.diag[(size_t)env * 8 + 7] = f_ls | (f_fact << 16);
   }
-#if MYO_STAMPS
+  last_cost = d_cost;
   STAMP(9);
+  if (!SCHED) break;
+  // publish this env's next substep: the state rows written above must have reached L2 before the ring entry becomes visible
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (s1 < nsubtot && lane_id == 0) {
+    const int tt = atomicAdd(&sq_ctl[1], 1);
+    const int g2 = tt / sq_n, sl = tt - g2 * sq_n;
+    __hip_atomic_store(&sq_ring[sl], (g2 << 24) | (s1 << 20) | env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  SYNC();   // the next task reuses this wave's LDS slice
+  }  // task loop
+#if MYO_STAMPS
   st_acc[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: wave/simd/cu/sh/se ids (placement census)
-  st_acc[11] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFF) | ((long long)(oe >> 28) << 8) | ((long long)d_cost << 16);   // HW_REG_XCC_ID, issue priority, cost estimate
+  st_acc[11] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFF) | ((long long)(oe >> 28) << 8) | ((long long)last_cost << 16);   // HW_REG_XCC_ID, issue priority, cost estimate
   if (stamps && lane_id == 0) for (int k = 0; k < 12; k++) stamps[(size_t)blockIdx.x * 12 + k] = st_acc[k];
 #endif
 }
@@ -2934,6 +3026,8 @@ struct myo_batch {
   uint64_t bench_step = 0;
   long long* d_stamps = nullptr;
   int* d_order = nullptr;
+  int* d_sched = nullptr;       // substep scheduler: 8 queues x (4 control words + ring)
+  int sched_stride = 0;
   int balance = 1;
   std::vector<hipEvent_t> kev;   // per-launch event pairs around the step kernel (bench only)
   float last_kernel_ms = 0.f;
@@ -3196,6 +3290,8 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   { void* pw = nullptr; if ((rc = balloc(b, &pw, sizeof(DevWalk)))) { myo_batch_free(b); return rc; } b->d_walk = (DevWalk*)pw; }
   BA(b->d_stamps, (size_t)B * 12 * 2)
   BA(b->d_order, B)
+  b->sched_stride = (B + 7) / 8 + 1;
+  BA(b->d_sched, 32 + 8 * b->sched_stride)
 #undef BA
   if (const char* e = getenv("MYO_LANES")) { int g = atoi(e); if (g == 16 || g == 32 || g == 64) g_lanes = g; }
   HIPCHK(hipMemcpy(b->d_jlo, m->jnt_lo.data(), nv * 4, hipMemcpyHostToDevice));
@@ -3418,24 +3514,51 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
   if (G == 64 && m->wave_ok) {
     static bool attr_w = false;
     if (!attr_w) {
-      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       attr_w = true;
     }
     const int* order = nullptr;
     int Bn = b->db.B;
-    if (b->balance && Bn >= 1024 && Bn % 4 == 0 && !kflags) {
+    // substep scheduler: MYO_SCHED=1 forces it, 0 disables it; default (auto) uses it where it was measured to pay: when the launch
+    // holds at least twice as many envs as the chip holds waves of this kernel (MyoLeg: 8 waves per CU; +6 % at 4096 envs).  With as
+    // many waves as envs every wave just re-takes its own env and only the overhead is left (MyoHand at 4096 envs: -15 %)
+    static int sched_mode = -2, n_cu = 0;
+    if (sched_mode == -2) {
+      const char* e = getenv("MYO_SCHED"); sched_mode = e ? atoi(e) : -1;
+      hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, m->device) == hipSuccess) n_cu = prop.multiProcessorCount;
+      if (n_cu <= 0) n_cu = 256;
+    }
+    const int resident = n_cu * (m->wave_cfg == 1 ? 8 : 16);
+    const bool sched_ok = !kflags && Bn >= 64 && Bn <= SCHED_ENV_MASK && nsub + (wk ? 1 : 0) <= 15 && nsub > 0;
+    const bool sched = sched_ok && (sched_mode == 1 || (sched_mode == -1 && m->wave_cfg == 1 && Bn >= 2 * resident));
+    if (b->balance && Bn >= 1024 && Bn % 4 == 0 && !kflags && !sched) {
       static int prio_mode = -1;
       if (prio_mode < 0) { const char* e = getenv("MYO_PRIO"); prio_mode = e ? atoi(e) : 2; }
       hipLaunchKernelGGL(balance_kernel, dim3(1), dim3(1024), 0, s, (const int*)b->db.diag, Bn, b->d_order, Bn / 4, prio_mode);
       order = b->d_order;
     }
-    if (m->wave_cfg == 0)
-      hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
-                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0);
+    SchedDev S{b->d_sched, b->d_sched + 32, b->sched_stride, nsub + (wk ? 1 : 0)};
+    if (sched) {
+      hipLaunchKernelGGL(sched_init_kernel, dim3(1), dim3(1024), 0, s, (const int*)b->db.diag, Bn, S);
+      int grid = Bn < resident ? Bn : resident;    // persistent waves: no more workgroups than the chip holds at once
+      static int grid_override = -1;
+      if (grid_override < 0) { const char* e = getenv("MYO_SCHED_GRID"); grid_override = e ? atoi(e) : 0; }
+      if (grid_override > 0 && grid_override < grid) grid = grid_override;
+      if (m->wave_cfg == 0)
+        hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, true>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+                           (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, (const int*)nullptr, (const DevWalk*)nullptr, 0, S);
+      else
+        hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, true>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+                           (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, (const int*)nullptr, wk, 0, S);
+    } else if (m->wave_cfg == 0)
+      hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, false>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0, S);
     else
-      hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
-                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, wk, kflags);
+      hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, false>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, wk, kflags, S);
     HIPCHK(hipGetLastError());
     return MYO_OK;
   }
