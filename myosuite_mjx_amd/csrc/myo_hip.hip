@@ -1632,7 +1632,18 @@ __global__ void __launch_bounds__(1024) sched_init_kernel(const int* __restrict_
   }
 }
 
-template <int NVT, int KC, int NC, int NTR, int WPE, bool SCHED>
+// table sizes of the compiled config models (after lowering): SPEC = 1 (MyoHand, myohand_pose.xml) and SPEC = 2 (MyoLeg, myolegs.xml)
+// instantiations of the wave kernel take their loop bounds from here; SPEC = 0 reads them from the model at run time
+template <int SPEC> struct Sizes { static constexpr int nq = 0, nv = 0, nu = 0, nl = 0, nlevel = 0, maxnnz = 0, nseg = 0, ncg = 0, npair = 0; };
+template <> struct Sizes<1> { static constexpr int nq = 23, nv = 23, nu = 39, nl = 17, nlevel = 5, maxnnz = 7, nseg = 116, ncg = 27, npair = 289; };
+template <> struct Sizes<2> { static constexpr int nq = 35, nv = 34, nu = 80, nl = 13, nlevel = 6, maxnnz = 11, nseg = 100, ncg = 32, npair = 45; };
+template <int SPEC> static bool sizes_match(int nq, int nv, int nu, int nl, int nlevel, int maxnnz, int ngt, int nseg, int ncg, int npair) {
+  typedef Sizes<SPEC> Z;
+  return nq == Z::nq && nv == Z::nv && nu == Z::nu && nl == Z::nl && nlevel == Z::nlevel && maxnnz == Z::maxnnz && ngt == Z::nu && nseg == Z::nseg &&
+         ncg == Z::ncg && npair == Z::npair;
+}
+
+template <int NVT, int KC, int NC, int NTR, int WPE, bool SCHED, int SPEC>
 __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restrict__ Mp, const DevModelW* __restrict__ Wp, DevBatch Bt,
                                                         const float* __restrict__ action, int actmap, int nsub, long long* stamps,
                                                         const int* __restrict__ order, const DevWalk* __restrict__ wk, int kflags, SchedDev S) {
@@ -1657,7 +1668,12 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       default: break;
     }
   }
-  const int nv = M.nv, nu = M.nu, nq = W.nq;
+  // SPEC != 0: the model has exactly the table sizes of Sizes<SPEC> (checked by myo_model_load): loop bounds become compile-time
+  // constants (+3 % measured on MyoHand); SPEC = 0 reads them from the model
+  typedef Sizes<SPEC> Z;
+  const int nv = SPEC ? Z::nv : M.nv, nu = SPEC ? Z::nu : M.nu, nq = SPEC ? Z::nq : W.nq;
+  const int nl_ = SPEC ? Z::nl : M.nl, nlevel_ = SPEC ? Z::nlevel : M.nlevel, maxnnz_ = SPEC ? Z::maxnnz : M.maxnnz, ngt_ = SPEC ? Z::nu : M.ngt,
+            nseg_ = SPEC ? Z::nseg : M.nseg, ncg_ = SPEC ? Z::ncg : M.ncg, npair_ = SPEC ? Z::npair : M.npair;
   constexpr int CDW = (KC + 3) / 4;   // ints per contact holding its KC byte-packed dof ids
   // the small instantiation (hand / finger class) is compiled without the free-joint, equality, plane-contact and condim-1 code;
   // myo_model_load routes any model that needs one of those to the large instantiation
@@ -1742,7 +1758,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     }
     STAMP(0);
     // ---------------------------------------------------------------- kinematics (lane = link, level by level)
-    for (int L = 0; L < M.nlevel; L++) {
+    for (int L = 0; L < nlevel_; L++) {
       int l = M.level_adr[L] + lane;
       if (l < M.level_adr[L + 1]) {
         float pos[3], R[9];
@@ -1813,9 +1829,9 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     STAMP(1);
     // ---------------------------------------------------------------- tendons: lane = segment
     float tlen_r[NTR], tvel_r[NTR];
-    for (int base = 0; base < M.nseg; base += 64) {
+    for (int base = 0; base < nseg_; base += 64) {
       int idx = base + lane;
-      if (idx < M.nseg) {
+      if (idx < nseg_) {
         int si = W.seg_order[idx];
         const int* S = M.seg + 12 * si;
         float invdiv = 1.0f / M.seg_div[si];
@@ -1856,9 +1872,9 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     for (int rr = 0; rr < NTR; rr++) {  // lane = tendon (NTR rounds of 64): gather its segments, then the muscle
       int gt = lane + 64 * rr;
       tlen_r[rr] = 0.f; tvel_r[rr] = 0.f;
-      if (gt >= M.ngt) continue;
-      float* Jrow = E + Y.tJ + gt * M.maxnnz;
-      for (int k = 0; k < M.maxnnz; k++) Jrow[k] = 0;
+      if (gt >= ngt_) continue;
+      float* Jrow = E + Y.tJ + gt * maxnnz_;
+      for (int k = 0; k < maxnnz_; k++) Jrow[k] = 0;
       float L = M.gt_len0[gt];   // constant same-link segments, folded at lowering time
       for (int si = M.gt_seg_adr[gt]; si < M.gt_seg_adr[gt] + M.gt_seg_num[gt]; si++) L += E[Y.seglen + si];
       int e0 = W.gt_dl[2 * gt], en = W.gt_dl[2 * gt + 1];
@@ -1866,10 +1882,10 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       E[Y.tlen + gt] = L;
       tlen_r[rr] = L;
       float vel = 0;
-      for (int k = 0; k < M.maxnnz; k++) {
-        int d = M.gt_dofs[gt * M.maxnnz + k];
+      for (int k = 0; k < maxnnz_; k++) {
+        int d = M.gt_dofs[gt * maxnnz_ + k];
         if (d >= 0) vel += Jrow[k] * E[Y.qvel + d];
-        if (W.has_tl) E[Y.tJp + gt * M.maxnnz + k] = Jrow[k];
+        if (W.has_tl) E[Y.tJp + gt * maxnnz_ + k] = Jrow[k];
       }
       tvel_r[rr] = vel;
       if (gt < nu) {
@@ -1885,7 +1901,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     if (lane < nv) {
       for (int k = M.col_adr[lane]; k < M.col_adr[lane + 1]; k++) {
         int t = M.col[2 * k], slot = M.col[2 * k + 1];
-        qfa += E[Y.tJ + t * M.maxnnz + slot] * E[Y.tforce + t];
+        qfa += E[Y.tJ + t * maxnnz_ + slot] * E[Y.tforce + t];
       }
     }
     if (step == nsub - 1) {   // diagnostics of the last substep
@@ -1908,7 +1924,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     SYNC();  // region X changes owner: tendon scratch -> spatial dynamics
     STAMP(2);
     // ---------------------------------------------------------------- CRB + RNE (lane = link / dof)
-    if (lane < M.nl) {
+    if (lane < nl_) {
       int l = lane;
       const float* R = E + Y.lmat + 9 * l;
       const float* I = M.link_inertia + 6 * l;
@@ -1946,7 +1962,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     }
     WFOR(i, NVT * (NVT + 1)) E[Y.sq + i] = 0;
     SYNC();
-    for (int L = 0; L < M.nlevel; L++) {
+    for (int L = 0; L < nlevel_; L++) {
       int l = M.level_adr[L] + lane;
       if (l < M.level_adr[L + 1]) {
         int par = M.link_parent[l];
@@ -1991,7 +2007,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       if (lane < nq - 2) o[lane] = E[Y.qpos + 2 + lane];                    // qpos_without_xy
       if (lane < nv) o[nq - 2 + lane] = E[Y.qvel + lane] * wk->dt;          // qvel * dt
       float mc[3] = {0.f, 0.f, 0.f}, ml = 0.f;
-      if (lane < M.nl) {
+      if (lane < nl_) {
         float cw[3];
         matvec(cw, E + Y.lmat + 9 * lane, M.link_com + 3 * lane);
         ml = M.link_mass[lane];
@@ -2003,7 +2019,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       // MuJoCo's cvel is the velocity of the body-fixed point that coincides with the root's subtree COM (COM of the moving bodies)
       const float cm[3] = {sx / mmov, sy / mmov, sz / mmov};
       float mv[2] = {0.f, 0.f};
-      if (lane < M.nl) {
+      if (lane < nl_) {
         const float* cv = E + Y.cvel + 6 * lane;
         float r[3] = {cm[0] - c0[0], cm[1] - c0[1], cm[2] - c0[2]}, wr[3];
         cross3(wr, cv, r);
@@ -2058,7 +2074,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       }
       break;
     }
-    for (int L = M.nlevel - 2; L >= 0; L--) {
+    for (int L = nlevel_ - 2; L >= 0; L--) {
       int l = M.level_adr[L] + lane;
       if (l < M.level_adr[L + 1]) {
         for (int ci = M.child_adr[l]; ci < M.child_adr[l + 1]; ci++) {
@@ -2102,7 +2118,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     if (!M.disable_contact) {
       int ncand = 0;
       int* cand = (int*)(E + Y.cand);
-      if (lane < M.ncg) {   // world centre and long axis (3rd column) of every collision geom
+      if (lane < ncg_) {   // world centre and long axis (3rd column) of every collision geom
         float x[3], R[9];
         geom_world_pos(M, Y, E, lane, x);
         geom_world_mat(M, Y, E, lane, R);
@@ -2110,10 +2126,10 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         E[Y.gax + 3 * lane] = R[2]; E[Y.gax + 3 * lane + 1] = R[5]; E[Y.gax + 3 * lane + 2] = R[8];
       }
       SYNC();
-      for (int base = 0; base < M.npair; base += 64) {
+      for (int base = 0; base < npair_; base += 64) {
         int p = base + lane;
         bool hit = false;
-        if (p < M.npair) {
+        if (p < npair_) {
           const int* P = M.pair_i + 6 * p;
           if (!(M.disable_ellipsoid && P[4] == 0)) {
             int g1 = P[0], g2 = P[1];
@@ -2420,7 +2436,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       const int gt = lane + 64 * rr;
       bool tact = false;
       float t_aref = 0.f, t_D = 0.f, t_sign = 0.f;
-      if (gt < M.ngt && !M.disable_limit) {
+      if (gt < ngt_ && !M.disable_limit) {
         const float* T = W.tl + 12 * gt;
         if (T[0] != 0) {
           float margin = T[3], dlo = tlen_r[rr] - T[1], dhi = T[2] - tlen_r[rr], dist = 0;
@@ -2446,8 +2462,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         int kc = 0;
 #pragma unroll
         for (int k = 0; k < KC; k++) {
-          int d = k < M.maxnnz ? M.gt_dofs[gt * M.maxnnz + k] : -1;
-          float jv = d >= 0 ? t_sign * E[Y.tJp + gt * M.maxnnz + k] : 0.f;
+          int d = k < maxnnz_ ? M.gt_dofs[gt * maxnnz_ + k] : -1;
+          float jv = d >= 0 ? t_sign * E[Y.tJp + gt * maxnnz_ + k] : 0.f;
           if (d >= 0) kc = k + 1; else d = 0;
           cJ[k] = jv; cJ[KC + k] = 0.f; cJ[2 * KC + k] = 0.f;
           dpk[k >> 2] |= (unsigned int)d << (8 * (k & 3));
@@ -3001,6 +3017,7 @@ struct myo_model {
   DevModelW* d_dw = nullptr;
   int env_lds_bytes_w = 0;
   bool wave_ok = false, generic_ok = false;
+  bool hand_sizes = false, leg_sizes = false;   // table sizes equal Sizes<1> / Sizes<2>: the size-specialised instantiations may be used
   int wave_cfg = 0;             // 0: step_kernel_w<24,8,32,1,4> (hand / finger), 1: step_kernel_w<36,20,48,2,2> (legs)
   int nq = 0;
   int has_tl = 0;
@@ -3223,6 +3240,9 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
     if (common && !needs_full && d.nv <= 24 && d.nu <= 64 && d.ngt <= 64 && d.maxkc <= 8) { m->wave_ok = true; m->wave_cfg = 0; build_layout_w(d, w, 24, 8, 32); }
     else if (common && d.nv <= 36 && d.nu <= 128 && d.ngt <= 128 && d.maxkc <= 20) { m->wave_ok = true; m->wave_cfg = 1; build_layout_w(d, w, 36, 20, 32); }
     else { m->wave_ok = false; build_layout_w(d, w, 24, 8, 32); }
+    m->hand_sizes = m->wave_ok && m->wave_cfg == 0 && sizes_match<1>(w.nq, d.nv, d.nu, d.nl, d.nlevel, d.maxnnz, d.ngt, d.nseg, d.ncg, d.npair);
+    m->leg_sizes = m->wave_ok && m->wave_cfg == 1 && sizes_match<2>(w.nq, d.nv, d.nu, d.nl, d.nlevel, d.maxnnz, d.ngt, d.nseg, d.ncg, d.npair);
+    if (const char* e = getenv("MYO_NO_SPEC")) if (atoi(e) == 1) m->hand_sizes = m->leg_sizes = false;   // tests: force the run-time-sized instantiations
     if (!m->wave_ok && !m->generic_ok) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "model exceeds the limits of both step kernels (nv <= 36, nu <= 128, pair dofs <= 20)"); }
     m->env_lds_bytes_w = w.lay.total * 4;
     if (m->wave_ok && m->env_lds_bytes_w > 64 * 1024) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "wave kernel working set exceeds 64 KB of LDS"); }
@@ -3514,10 +3534,13 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
   if (G == 64 && m->wave_ok) {
     static bool attr_w = false;
     if (!attr_w) {
-      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 4, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 4, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 4, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       attr_w = true;
     }
     const int* order = nullptr;
@@ -3548,16 +3571,25 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
       if (grid_override < 0) { const char* e = getenv("MYO_SCHED_GRID"); grid_override = e ? atoi(e) : 0; }
       if (grid_override > 0 && grid_override < grid) grid = grid_override;
       if (m->wave_cfg == 0)
-        hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, true>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+        hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, true, 0>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                            (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, (const int*)nullptr, (const DevWalk*)nullptr, 0, S);
-      else
-        hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, true>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+      else if (m->leg_sizes)
+        hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, true, 2>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                            (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, (const int*)nullptr, wk, 0, S);
-    } else if (m->wave_cfg == 0)
-      hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, false>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+      else
+        hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, true, 0>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+                           (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, (const int*)nullptr, wk, 0, S);
+    } else if (m->wave_cfg == 0 && m->hand_sizes)
+      hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, false, 1>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                          (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0, S);
+    else if (m->wave_cfg == 0)
+      hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, false, 0>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0, S);
+    else if (m->leg_sizes)
+      hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, false, 2>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, wk, kflags, S);
     else
-      hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, false>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+      hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, false, 0>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                          (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, wk, kflags, S);
     HIPCHK(hipGetLastError());
     return MYO_OK;

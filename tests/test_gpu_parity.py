@@ -209,3 +209,36 @@ def test_finger_env_config0():
         obs, rwd, term, trunc, info = env.step(0.01 * torch.rand((1, 5), device="cuda", generator=g))
         assert torch.isfinite(obs).all() and not term.any()
     assert trunc.all() and (env.status() == 0).all()
+
+
+def test_size_specialised_and_generic_instantiations_agree(hand, legs):
+    """The wave kernel has size-specialised instantiations for the config models (loop bounds as compile-time constants) and
+    run-time-sized ones for anything else; MYO_NO_SPEC=1 at model load forces the latter.  Same algorithm; results agree to float32 round-off."""
+    from myosuite_mjx_amd import capi
+    for m, N in ((hand, 256), (legs, 128)):
+        rng = np.random.default_rng(11)
+        if m.nq == m.nv:
+            lo, hi = m.jnt_range[:, 0], m.jnt_range[:, 1]
+            qpos = rng.uniform(lo, hi, (N, m.nq)).astype(np.float32)
+        else:
+            qpos = np.tile(np.asarray(m.key_qpos).reshape(-1, m.nq)[2], (N, 1)).astype(np.float32)
+            qpos[:, 7:] += rng.normal(0, 0.05, (N, m.nq - 7)).astype(np.float32)
+            qpos[:, 2] -= 0.03
+        qvel = rng.normal(0, 0.3, (N, m.nv)).astype(np.float32)
+        act = rng.uniform(0, 1, (N, m.nu)).astype(np.float32)
+        out = []
+        for no_spec in ("0", "1"):
+            os.environ["MYO_NO_SPEC"] = no_spec
+            try:
+                hm = capi.HipModel(m.blob(), 0)
+            finally:
+                os.environ.pop("MYO_NO_SPEC", None)
+            b = capi.HipBatch(hm, N)
+            for f, a in ((capi.F_QPOS, qpos), (capi.F_QVEL, qvel), (capi.F_ACT, act), (capi.F_CTRL, act)):
+                b.write(f, a)
+            b.step(None, capi.ACTMAP_NONE, 10)
+            out.append((b.read(capi.F_QPOS), b.read(capi.F_QVEL), b.read(capi.F_DIAG)[:, :3]))
+        # not bit-identical (unrolling changes fma contraction / summation order): float32 round-off amplified over 10 substeps
+        assert np.abs(out[0][0] - out[1][0]).max() < 1e-4 and np.abs(out[0][1] - out[1][1]).max() < 2e-2
+        assert np.median(np.abs(out[0][0] - out[1][0]).max(axis=1)) < 1e-6
+        assert (out[0][2] == out[1][2]).mean() > 0.97
