@@ -150,7 +150,7 @@ def main():
                        "global_batch": world * B, "parallelism": f"env-shard x{world}", "lanes_per_env": 64,
                        "substeps_per_s": value * env.frame_skip},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "step_kernel_w<24,8,32,1,4,false>" if mm.nv <= 24 else "step_kernel_w<36,20,32,2,2,true>", "kernel_ms": k_ms,
+                         "traffic": traffic, "kernel": "step_kernel_w<24,8,32,1,4,false,1>" if mm.nv <= 24 else "step_kernel_w<36,20,32,2,2,true,2>", "kernel_ms": k_ms,
                          "alg_bytes_per_launch": b_alg * B,
                          "note": "path is FP32-VALU/latency bound, not HBM bound (SURVEY.md 8d); fp32 view alongside",
                          "fp32": {"achieved_tflops_est": F_ALG_EST * B / (k_ms * 1e-3) / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
