@@ -169,3 +169,26 @@ def test_hip_sim_scene_mirrors_the_backend_abc(hand, oracle64):
     assert np.allclose(sim.data.qpos, hand.qpos0) and not sim.data.qvel.any() and not sim.data.time.any()
     sim.advance(1)
     assert np.isfinite(sim.data.qpos).all()
+
+
+def test_every_registered_env_id_resets_steps_and_is_deterministic():
+    """Counterpart of the reference's tests/test_myo.py -> test_envs.py loop over every registered id: construct, seed, reset, one
+    small-action step (a = 0.01 * U like test_envs.py:61-64), shapes and finiteness, and the same seed twice gives the same obs / reward."""
+    import torch
+    from myosuite_mjx_amd import envs
+    ids = sorted(envs.REGISTRY)
+    assert len(ids) >= 40 and "myoLegWalk-v0" in ids and "myoFatiHandReachRandom-v0" in ids
+    for k, env_id in enumerate(ids):
+        outs = []
+        for rep in range(2):
+            env = envs.make(env_id, num_envs=8, seed=1234)
+            obs0 = env.reset(seed=1234).clone()
+            g = torch.Generator(device="cuda").manual_seed(k)
+            a = 0.01 * torch.rand((8, env.act_dim), device="cuda", generator=g)
+            obs, rew, term, trunc, info = env.step(a)
+            torch.cuda.synchronize()
+            assert obs.shape == (8, env.obs_dim) and obs0.shape == obs.shape and rew.shape == (8,), env_id
+            assert torch.isfinite(obs).all() and torch.isfinite(rew).all(), env_id
+            assert (env.status() == 0).all(), env_id
+            outs.append((obs0, obs.clone(), rew.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]), env_id
