@@ -95,12 +95,16 @@ def main():
         if world == 1:
             ms = env.batch.bench_rollout(nsteps, env.frame_skip, 0, mode, env.max_episode_steps, stream)
             return ms, env.batch.last_kernel_ms()
-        ms = kms = 0.0
+        # N > 1: nothing in the loop waits on the host -- each step's launches and its RCCL all-gather are enqueued on the same stream
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         for _ in range(nsteps):
-            ms += env.batch.bench_rollout(1, env.frame_skip, 0, mode, env.max_episode_steps, stream)
-            kms += env.batch.last_kernel_ms()
+            env.batch.bench_rollout_async(1, env.frame_skip, 0, mode, env.max_episode_steps, stream)
             dist.all_gather_into_tensor(gathered, obs)     # cross-GPU observation gather (RCCL over xGMI)
-        return ms, kms
+        e1.record()
+        kms = env.batch.last_kernel_ms()                   # waits for the last step kernel
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1), kms
 
     run(args.warmup)
     torch.cuda.synchronize()

@@ -166,7 +166,10 @@ int myo_read_stamps(myo_batch*, long long* host, int nwg);
  * stream; returns elapsed milliseconds in *ms_out.  mode bits select what runs inside the timed region. */
 enum { MYO_BENCH_OBS = 1, MYO_BENCH_FRESH_ACTIONS = 2, MYO_BENCH_AUTORESET = 4 };
 int myo_bench_rollout(myo_batch*, int steps, int nsubsteps, uint64_t seed, int mode, int max_episode_steps, void* stream, float* ms_out);
-/* HIP-event milliseconds spent inside the step-kernel launches of the last myo_bench_rollout (events recorded on its stream) */
+/* ms_out == NULL makes myo_bench_rollout asynchronous: launches are enqueued on `stream` and nothing waits (a multi-GPU caller puts
+ * its observation all-gather on the same stream between calls).
+ * myo_bench_last_kernel_ms: HIP-event milliseconds spent inside the step-kernel launches of the last synchronous call, or of all
+ * asynchronous calls since the previous collection (waits for them); events are recorded on the launches' own stream */
 int myo_bench_last_kernel_ms(myo_batch*, float* ms_out);
 
 /* ---- policy inference: the network family of the reference's `mjx_brax_policy` artefact (a brax PPO

@@ -259,6 +259,10 @@ class HipBatch:
         _chk(lib().myo_bench_rollout(self.h, steps, nsub, seed, mode, max_episode_steps, stream, C.byref(ms)))
         return ms.value
 
+    def bench_rollout_async(self, steps, nsub, seed=0, mode=BENCH_OBS | BENCH_FRESH_ACTIONS | BENCH_AUTORESET, max_episode_steps=100, stream=None):
+        """Enqueues `steps` env steps on `stream` without waiting; `last_kernel_ms()` later collects the step-kernel time of all of them."""
+        _chk(lib().myo_bench_rollout(self.h, steps, nsub, seed, mode, max_episode_steps, stream, None))
+
 
 def set_lanes(lanes):
     _chk(lib().myo_set_lanes(lanes))

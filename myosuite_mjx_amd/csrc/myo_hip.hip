@@ -3047,6 +3047,7 @@ struct myo_batch {
   int sched_stride = 0;
   int balance = 1;
   std::vector<hipEvent_t> kev;   // per-launch event pairs around the step kernel (bench only)
+  int kev_pending = 0;           // pairs recorded by asynchronous bench calls and not collected yet
   float last_kernel_ms = 0.f;
 };
 
@@ -3696,25 +3697,29 @@ int myo_sync(void* stream) {
 }
 
 int myo_bench_rollout(myo_batch* b, int steps, int nsubsteps, uint64_t seed, int mode, int max_episode_steps, void* stream, float* ms_out) {
-  if (!b || steps <= 0 || !ms_out) return fail(MYO_E_ARG, "myo_bench_rollout: bad arguments");
+  if (!b || steps <= 0) return fail(MYO_E_ARG, "myo_bench_rollout: bad arguments");
   HIPCHK(hipSetDevice(b->model->device));
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (!(mode & MYO_BENCH_FRESH_ACTIONS)) { rc = myo_random_action(b, b->d_action, seed, b->bench_step, b->env_offset, stream); if (rc) return rc; }
-  while ((int)b->kev.size() < 2 * steps) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); b->kev.push_back(e); }
-  HIPCHK(hipEventRecord(b->ev0, s));
+  // ms_out == NULL: asynchronous -- the launches are only enqueued (a multi-GPU caller interleaves its collective on the same stream)
+  // and their kernel event pairs pile up until myo_bench_last_kernel_ms collects them
+  const int base = ms_out ? 0 : b->kev_pending;
+  while ((int)b->kev.size() < 2 * (base + steps)) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); b->kev.push_back(e); }
+  if (ms_out) { b->kev_pending = 0; HIPCHK(hipEventRecord(b->ev0, s)); }
   for (int i = 0; i < steps; i++) {
     if (mode & MYO_BENCH_FRESH_ACTIONS) { rc = myo_random_action(b, b->d_action, seed, b->bench_step++, b->env_offset, stream); if (rc) return rc; }
-    HIPCHK(hipEventRecord(b->kev[2 * i], s));       // brackets the dominant kernel (+ its tiny placement kernel) on its own stream
+    HIPCHK(hipEventRecord(b->kev[2 * (base + i)], s));       // brackets the dominant kernel (+ its tiny placement kernel) on its own stream
     rc = launch_step(b, b->d_action, MYO_ACTMAP_MUSCLE_SIGMOID, nsubsteps, s);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(b->kev[2 * i + 1], s));
+    HIPCHK(hipEventRecord(b->kev[2 * (base + i) + 1], s));
     if ((mode & MYO_BENCH_OBS) && b->task.task != MYO_TASK_NONE && b->task.task != MYO_TASK_WALK) { rc = launch_obs(b, s); if (rc) return rc; }   // walk: fused into the step launch
     if ((mode & MYO_BENCH_AUTORESET) && max_episode_steps > 0) {
       rc = myo_autoreset(b, max_episode_steps, seed, stream); if (rc) return rc;
       if ((mode & MYO_BENCH_OBS) && b->task.task != MYO_TASK_NONE) { rc = launch_obs(b, s, 1, 1); if (rc) return rc; }
     }
   }
+  if (!ms_out) { b->kev_pending = base + steps; return MYO_OK; }
   HIPCHK(hipEventRecord(b->ev1, s));
   HIPCHK(hipEventSynchronize(b->ev1));
   HIPCHK(hipEventElapsedTime(ms_out, b->ev0, b->ev1));
@@ -3724,9 +3729,18 @@ int myo_bench_rollout(myo_batch* b, int steps, int nsubsteps, uint64_t seed, int
   return MYO_OK;
 }
 
-/* total HIP-event milliseconds spent in the step kernel launches of the last myo_bench_rollout call */
+/* total HIP-event milliseconds spent in the step kernel launches of the last synchronous myo_bench_rollout call, or -- after
+ * asynchronous calls (ms_out == NULL) -- of all launches enqueued since the last collection (waits for them) */
 int myo_bench_last_kernel_ms(myo_batch* b, float* ms_out) {
   if (!b || !ms_out) return fail(MYO_E_ARG, "null");
+  if (b->kev_pending > 0) {
+    HIPCHK(hipSetDevice(b->model->device));
+    HIPCHK(hipEventSynchronize(b->kev[2 * b->kev_pending - 1]));
+    float tot = 0.f;
+    for (int i = 0; i < b->kev_pending; i++) { float t; HIPCHK(hipEventElapsedTime(&t, b->kev[2 * i], b->kev[2 * i + 1])); tot += t; }
+    b->last_kernel_ms = tot;
+    b->kev_pending = 0;
+  }
   *ms_out = b->last_kernel_ms;
   return MYO_OK;
 }

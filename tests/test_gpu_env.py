@@ -192,3 +192,28 @@ def test_every_registered_env_id_resets_steps_and_is_deterministic():
             assert (env.status() == 0).all(), env_id
             outs.append((obs0, obs.clone(), rew.clone()))
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]), env_id
+
+
+def test_async_bench_rollout_interleaves_with_stream_work():
+    """bench.py's N > 1 loop: steps are enqueued without host waits and another stream operation (there: the RCCL obs all-gather,
+    here: a device copy of the same buffer) sits between them; kernel times are collected once at the end."""
+    import torch
+    from myosuite_mjx_amd import capi
+    e_sync = _make("myoHandPoseRandom-v0", 512, seed=3)
+    e_async = _make("myoHandPoseRandom-v0", 512, seed=3)
+    e_sync.reset(seed=3); e_async.reset(seed=3)
+    st = torch.cuda.current_stream().cuda_stream
+    mode = capi.BENCH_OBS | capi.BENCH_FRESH_ACTIONS | capi.BENCH_AUTORESET
+    ms = e_sync.batch.bench_rollout(12, 10, 0, mode, 100, st)
+    k_sync = e_sync.batch.last_kernel_ms()
+    obs = e_async.view(capi.F_OBS)
+    sink = torch.empty((2 * 512, e_async.obs_dim), device=obs.device)
+    for _ in range(12):
+        e_async.batch.bench_rollout_async(1, 10, 0, mode, 100, st)
+        sink[512:].copy_(obs, non_blocking=True)
+    k_async = e_async.batch.last_kernel_ms()
+    torch.cuda.synchronize()
+    assert ms > 0 and k_sync > 0 and k_async > 0 and 0.5 < k_async / k_sync < 2.0
+    assert torch.equal(e_sync.view(capi.F_OBS), e_async.view(capi.F_OBS))          # same steps, same results
+    assert torch.equal(sink[512:], obs)
+    assert e_async.batch.last_kernel_ms() == k_async                               # nothing pending: value is kept
