@@ -48,7 +48,10 @@ class WalkConfig(C.Structure):
 
 def build_library(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> libmyo_hip.so next to this file (cross-compiles without a GPU)."""
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= os.path.getmtime(SRC_PATH):
+    csrc = os.path.dirname(SRC_PATH)
+    newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    newest = max(newest, os.path.getmtime(os.path.join(os.path.dirname(os.path.dirname(csrc)), "include", "myo_hip.h")))
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-hip-fp32-correctly-rounded-divide-sqrt",

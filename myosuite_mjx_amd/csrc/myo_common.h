@@ -1,0 +1,202 @@
+// myo_common.h -- shared definitions: limits, device-side model / batch / task structs, small vector math.
+// Part of the single translation unit myo_hip.hip (included there, in this order); not a stand-alone header.
+#ifndef MYO_COMMON_H
+#define MYO_COMMON_H
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/myo_hip.h"
+
+#define MINVALF 1e-15f
+#define MAXVALF 1e10f
+#define MINIMPF 0.0001f
+#define MAXIMPF 0.9999f
+#define NCON 32   // contact slots per env
+#define NCAND 128 // broad-phase survivors per env
+#ifndef LS_FLOOR
+#define LS_FLOOR 1e-6f   // float32 floor of the line-search slope tolerance, relative to the initial slope
+#endif
+#define KCMAX 8   // max dofs in a contact pair's jacobian (checked against the model at load)
+#define GEOM_SPHERE 2
+#define GEOM_CAPSULE 3
+#define GEOM_ELLIPSOID 4
+#define GEOM_CYLINDER 5
+
+// ------------------------------------------------------------------------------------------------
+// device-side model: sizes + device pointers + LDS layout; passed by value as a kernel argument
+struct Lay {
+  int qpos, qvel, act, ctrl, warm;                       // persistent state
+  int lpos, lmat, lquat, axis, anchor;                   // kinematics
+  int tJ, tlen, tforce, actdot;                          // tendons / muscles
+  int cdof, cinert, crb, cvel, cacc, cfrc;               // spatial dynamics
+  int qfa, smooth, qas, qacc, Ma, grad, search, Mv, qfc; // nv-vectors
+  int Mp, Hp;                                            // packed lower-triangular matrices
+  int gpos, gmat, cand;                                  // collision geoms (world), broad-phase list
+  int cdist, cpos, cnrm, cpair, cJ, caref, cD, cjar, cjv, cimp; // contacts and their rows
+  int lsign, laref, lD, ljar, ljv;                       // joint-limit rows
+  int total;                                             // floats per env (padded)
+};
+
+struct DevModel {
+  int nl, nlevel, nv, nu, ngt, nseg, maxnnz, nwg, ncg, npair, maxkc, ns, nM;
+  int iterations, ls_iterations;
+  int disable_contact, disable_limit, disable_ellipsoid;
+  float timestep, grav[3], tolerance, ls_tolerance, meaninertia, c0[3], origin[3];
+  const int *level_adr, *link_parent, *link_dofadr, *link_dofnum, *child_adr, *child, *dof_link, *dof_type, *dof_parent;
+  const int *site_link, *wg_link, *gt_seg_adr, *gt_seg_num, *gt_dofs, *seg, *dl, *col_adr, *col;
+  const int *cg_link, *cg_type, *pair_i, *pair_dl;
+  const float *link_pos, *link_quat, *link_mass, *link_com, *link_inertia, *dof_pos, *dof_axis, *qpos0, *dof_damping,
+      *dof_armature;
+  const float *site_lpos, *wg_lpos, *wg_lmat, *wg_radius, *seg_div, *gt_len0, *act, *cg_lpos, *cg_lmat, *cg_size, *cg_rbound,
+      *pair_f, *jl;
+  Lay lay;
+};
+
+// per-batch device pointers (env-major, pitch = row length)
+struct DevBatch {
+  int B;
+  float *qpos, *qvel, *act, *ctrl, *warm, *time, *target, *obs, *reward, *done, *solved, *qacc, *tenlen, *actforce, *sitexpos;
+  int *flags, *diag, *elapsed, *episode;
+  float* fatigue;          // [B][3][nu]: MA, MR, MF of the 3CC-r fatigue model (muscle condition "fatigue")
+  float fat_dt;            // its time step = frame_skip * timestep
+  int reaf_epl, reaf_eip;  // actuator ids of the EIP -> EPL tendon transfer (muscle condition "reafferentation")
+};
+
+struct TaskDev {
+  int task, frame_skip, reset_random, target_generate, ntarget, ntip, obs_dim;
+  int tip_site[8];
+  float pose_thd, far_th, near_th, w_pose, w_bonus, w_act_reg, w_penalty, w_reach;
+  const float *target_lo, *target_hi, *init_qpos, *jnt_lo, *jnt_hi;
+  const float* init_qvel;   // walk task: reset velocity (NULL = zero)
+};
+
+// walk task (walk_v0.py:WalkEnvV0): its observation needs a forward pass at the post-step state, which the wave kernel
+// runs itself as one extra kinematics / tendon / velocity pass after the last substep (no second kernel, no state re-read)
+struct DevWalk {
+  int obs_dim, hip_period;
+  float dt, min_height, max_rot, target_x_vel, target_y_vel;
+  float target_rot[4];
+  int link_tl, link_tr, link_pel, link_tor;          // links holding talus_l, talus_r, pelvis, torso
+  float lpos_tl[3], lpos_tr[3], lpos_pel[3], lquat_tor[4];
+  int qadr_hfl, qadr_hfr, qadr_ja[4];
+  float w_vel, w_done, w_cyc, w_rot, w_ja;
+  float mass_total, static_mcom[3];
+};
+enum { KF_AUX = 1, KF_OBS_ONLY = 2, KF_RESET_ONLY = 4 };   // step_kernel_w flags: observation pass without stepping / without reward / only for just-reset envs
+
+// ------------------------------------------------------------------------------------------------
+// small device math
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void cross3(float* r, const float* a, const float* b) {
+  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+__device__ __forceinline__ float norm3(const float* a) { return sqrtf(dot3(a, a)); }
+__device__ __forceinline__ float normalize3(float* a) {
+  float n = norm3(a);
+  if (n < MINVALF) { a[0] = 1; a[1] = 0; a[2] = 0; } else { float i = 1.0f / n; a[0] *= i; a[1] *= i; a[2] *= i; }
+  return n;
+}
+__device__ __forceinline__ float clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+__device__ __forceinline__ void quat2mat(float* R, const float* q) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = w * w + x * x - y * y - z * z; R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z); R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = w * w - x * x - y * y + z * z;
+}
+__device__ __forceinline__ void mulquat(float* r, const float* a, const float* b) {
+  float t0 = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  float t1 = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  float t2 = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  float t3 = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = t0; r[1] = t1; r[2] = t2; r[3] = t3;
+}
+__device__ __forceinline__ void matvec(float* r, const float* R, const float* v) {
+  float a = R[0] * v[0] + R[1] * v[1] + R[2] * v[2], b = R[3] * v[0] + R[4] * v[1] + R[5] * v[2],
+        c = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  r[0] = a; r[1] = b; r[2] = c;
+}
+__device__ __forceinline__ void matTvec(float* r, const float* R, const float* v) {
+  float a = R[0] * v[0] + R[3] * v[1] + R[6] * v[2], b = R[1] * v[0] + R[4] * v[1] + R[7] * v[2],
+        c = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+  r[0] = a; r[1] = b; r[2] = c;
+}
+__device__ __forceinline__ void matmul3(float* C, const float* A, const float* B) {
+  float t[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; i++) C[i] = t[i];
+}
+__device__ __forceinline__ int tri(int i, int j) { return (i * (i + 1)) / 2 + j; }  // j <= i
+
+template <int G> __device__ __forceinline__ float grp_sum(float x) {
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) x += __shfl_xor(x, m, G);
+  return x;
+}
+template <int G> __device__ __forceinline__ int grp_sumi(int x) {
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) x += __shfl_xor(x, m, G);
+  return x;
+}
+template <int G> __device__ __forceinline__ int grp_maxi(int x) {
+#pragma unroll
+  for (int m = G / 2; m >= 1; m >>= 1) x = max(x, __shfl_xor(x, m, G));
+  return x;
+}
+#define SYNC() __syncthreads()
+// position of this lane among the set lanes of its G-lane group, and the group's set count
+template <int G> __device__ __forceinline__ void grp_rank(bool pred, int grp, int sub, int* rank, int* count) {
+  unsigned long long bal = __ballot(pred);
+  unsigned long long gmask = (G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull);
+  unsigned long long g = (bal >> (grp * (G & 63))) & gmask;
+  *rank = __popcll(g & ((1ull << sub) - 1ull));
+  *count = __popcll(g);
+}
+#ifndef MYO_STAMPS
+#define MYO_STAMPS 0
+#endif
+#if MYO_STAMPS
+#define STAMP(k) do { long long t1_ = clock64(); st_acc[k] += t1_ - st_t0; st_t0 = t1_; } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+#define GFOR(i, n) for (int i = sub; i < (n); i += G)
+
+// 10-element spatial inertia times a motion vector (ang, lin)
+__device__ __forceinline__ void mul_inert_vec(float* r, const float* i, const float* v) {
+  float a0 = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  float a1 = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  float a2 = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  float a3 = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  float a4 = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  float a5 = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+  r[0] = a0; r[1] = a1; r[2] = a2; r[3] = a3; r[4] = a4; r[5] = a5;
+}
+__device__ __forceinline__ void cross_motion(float* r, const float* vel, const float* v) {
+  float a[3], b[3];
+  cross3(r, vel, v);
+  cross3(a, vel, v + 3);
+  cross3(b, vel + 3, v);
+  r[3] = a[0] + b[0]; r[4] = a[1] + b[1]; r[5] = a[2] + b[2];
+}
+__device__ __forceinline__ void cross_force(float* r, const float* vel, const float* f) {
+  float a[3], b[3];
+  cross3(a, vel, f);
+  cross3(b, vel + 3, f + 3);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2];
+  cross3(r + 3, vel, f + 3);
+}
+
+#endif  // MYO_COMMON_H

@@ -1,0 +1,1350 @@
+// myo_kernel_wave.h -- wave-per-env kernel step_kernel_w (default path), its LDS layout, substep scheduler, size specialisations.
+// Part of the single translation unit myo_hip.hip (included there, in this order); not a stand-alone header.
+#ifndef MYO_KERNEL_WAVE_H
+#define MYO_KERNEL_WAVE_H
+
+// ================================================================================================
+// WAVE-PER-ENV KERNEL (lanes_per_env = 64): one wavefront steps one environment.
+//  * per-dof quantities (qacc, M rows, gradient, search direction, limit rows ...) live in the registers of lane = dof;
+//    contact rows live in lane = contact; dense Cholesky / triangular solves / M*v run on registers with v_readlane
+//    broadcasts -- no barriers, no LDS round trips;
+//  * J^T f and J^T D J are scattered with LDS float atomics (one wave => deterministic order);
+//  * tendons run lane = segment (wrapping segments first, then straight ones) instead of lane = tendon;
+//  * the LDS slice is <= 10 KB so 16 envs (= 16 waves, 4 per SIMD) are resident per CU.
+// ================================================================================================
+#define NCONW 32
+struct LayW {
+  int qpos, qvel, act, ctrl, lpos, lmat, axis, anchor, xv, qfc, sq, X;
+  int tJ, tlen, tforce, seglen, dlval;            // region X, tendon phase
+  int cdof, cinert, crb, cvel, cacc, cfrc;        // region X, dynamics phase
+  int gpos, gax, cand, cdist, cpos, cnrm, cpair, cJ, cdofs;  // region X, collision + solver phase
+  int Mp;                                                     // packed mass matrix, aliases gpos/gax/cand once the contact rows exist
+  int tJp;                                                    // persistent sparse tendon rows (only for models with tendon limits)
+  int total;
+};
+struct DevModelW {
+  LayW lay;
+  const int *seg_order, *seg_tendon, *gt_dl;
+  const float* link_mat0;
+  int nwrapseg, ndl, has_tl;
+  const float* tl;
+  int nq, has_free, neq;          // free-floating root (nq = nv + 1), joint-coupling equalities
+  const int *link_free, *dof_qposadr, *eq_i;
+  const float* eq_f;
+};
+
+__device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ int rdlanei(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 64 lanes, result in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  v = dpp_add<0x140>(v);  // row_mirror  -> every lane of a 16-lane row holds the row sum
+  return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
+}
+#define WFOR(i, n) for (int i = lane; i < (n); i += 64)
+// dof id k (0..KC-1) of contact c from the byte-packed table (CDW = ints per contact, a constexpr of the kernel)
+#define CDOF(E_, Y_, c_, k_) ((int)((((const unsigned int*)((E_) + (Y_).cdofs))[CDW * (c_) + ((k_) >> 2)] >> (8 * ((k_) & 3))) & 255u))
+
+// in: r[k] = H[lane][k] (k <= lane). out: r[k] = L[lane][k], returns 1/L[lane][lane].  All indices are compile-time.
+template <int NVT> __device__ __forceinline__ float chol_rows(float (&r)[NVT], int lane) {
+  float invd = 1.0f;
+#pragma unroll
+  for (int j = 0; j < NVT; j++) {
+    float s = r[j];
+#pragma unroll
+    for (int k = 0; k < j; k++) s -= r[k] * rdlane(r[k], j);
+    float pj = fmaxf(rdlane(s, j), MINVALF);
+    float inv = __builtin_amdgcn_rsqf(pj);   // v_rsq_f32 (1 ulp); pj >= 1e-15, no denormal handling needed
+    float dj = pj * inv;
+    r[j] = (lane == j) ? dj : s * inv;
+    if (lane == j) invd = inv;
+  }
+  return invd;
+}
+// x <- (L L^T)^-1 b ; L rows in registers, L^T columns read from the LDS copy T[j*(NVT+1) + lane]
+template <int NVT> __device__ __forceinline__ float chol_solve_rows(const float (&r)[NVT], float invd, float b, const float* T, int lane) {
+  float y = b;
+#pragma unroll
+  for (int j = 0; j < NVT; j++) {
+    float yj = rdlane(y, j) * rdlane(invd, j);
+    y = (lane == j) ? yj : (lane > j ? y - r[j] * yj : y);
+  }
+  const float* Tc = T + (lane < NVT ? lane : 0);
+#pragma unroll
+  for (int j = NVT - 1; j >= 0; j--) {
+    float xj = rdlane(y, j) * rdlane(invd, j);
+    float cj = Tc[j * (NVT + 1)];
+    y = (lane == j) ? xj : (lane < j ? y - cj * xj : y);
+  }
+  return y;
+}
+// y_lane = sum_k M[lane][k] x_k with M packed lower-triangular in LDS (rows beyond nv read as zero)
+template <int NVT> __device__ __forceinline__ float symv_lds(const float* Mp, float x, int lane, int nv) {
+  float s = 0;
+  const int d = lane < nv ? lane : 0;
+  const int based = (d * (d + 1)) / 2;
+#pragma unroll
+  for (int k = 0; k < NVT; k++) {
+    int kk = k < nv ? k : 0;
+    int adr = (kk <= d) ? based + kk : (kk * (kk + 1)) / 2 + d;
+    float mv = (k < nv && lane < nv) ? Mp[adr] : 0.f;
+    s += mv * rdlane(x, k);
+  }
+  return s;
+}
+
+__device__ __forceinline__ void site_world_w(const DevModel& M, const LayW& Y, const float* E, int s, float* out) {
+  int l = M.site_link[s];
+  const float* lp = M.site_lpos + 3 * s;
+  float a = lp[0], b = lp[1], c = lp[2];
+  if (l < 0) { out[0] = a; out[1] = b; out[2] = c; return; }
+  const float* R = E + Y.lmat + 9 * l;
+  const float* P = E + Y.lpos + 3 * l;
+  out[0] = P[0] + R[0] * a + R[1] * b + R[2] * c;
+  out[1] = P[1] + R[3] * a + R[4] * b + R[5] * c;
+  out[2] = P[2] + R[6] * a + R[7] * b + R[8] * c;
+}
+__device__ __forceinline__ void geom_world_pos(const DevModel& M, const LayW& Y, const float* E, int g, float* out) {
+  int l = M.cg_link[g];
+  const float* lp = M.cg_lpos + 3 * g;
+  float a = lp[0], b = lp[1], c = lp[2];
+  if (l < 0) { out[0] = a; out[1] = b; out[2] = c; return; }
+  const float* R = E + Y.lmat + 9 * l;
+  const float* P = E + Y.lpos + 3 * l;
+  out[0] = P[0] + R[0] * a + R[1] * b + R[2] * c;
+  out[1] = P[1] + R[3] * a + R[4] * b + R[5] * c;
+  out[2] = P[2] + R[6] * a + R[7] * b + R[8] * c;
+}
+__device__ __forceinline__ void geom_world_mat(const DevModel& M, const LayW& Y, const float* E, int g, float* R) {
+  int l = M.cg_link[g];
+  if (l < 0) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = M.cg_lmat[9 * g + k];
+  } else {
+    matmul3(R, E + Y.lmat + 9 * l, M.cg_lmat + 9 * g);
+  }
+}
+// moment-arm entries of one straight tendon piece into dlval[]
+__device__ __forceinline__ float straight_w(const DevModel& M, const LayW& Y, float* E, const float* pa, const float* pb, int adr, int n,
+                                            float invdiv, bool active) {
+  float dif[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+  float dist = norm3(dif);
+  float inv = dist > MINVALF ? 1.0f / dist : 0.f;
+  dif[0] *= inv; dif[1] *= inv; dif[2] *= inv;
+  for (int k = 0; k < n; k++) {
+    const int* e = M.dl + 3 * (adr + k);
+    int d = e[0];
+    const float* ax = E + Y.axis + 3 * d;
+    float col;
+    if (M.dof_type[d] == 3) {
+      const float* an = E + Y.anchor + 3 * d;
+      float r[3] = {pb[0] - an[0], pb[1] - an[1], pb[2] - an[2]}, c[3];
+      cross3(c, ax, r);
+      col = dot3(dif, c);
+    } else col = dot3(dif, ax);
+    E[Y.dlval + adr + k] = active ? (float)e[1] * col * invdiv : 0.f;
+  }
+  return active ? dist * invdiv : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Substep-granular dynamic scheduling (opt-in, MYO_SCHED=1).  With one workgroup per env, a launch of B = 4096 envs fills every
+// wave slot of the chip exactly once and lasts as long as its slowest SIMD (env work varies +-12 %).  Here the waves are
+// persistent instead: the unit of work is ONE substep of one env.  Each XCD owns a FIFO ring of its envs (state stays in that
+// XCD's L2); a wave takes a ticket, waits until the ticket's slot is published, loads the env's state, runs the substep, stores
+// the state and publishes the env's next substep at the tail.  Envs advance in near lock-step, so the imbalance that is left is
+// that of a single substep.  No wave ever waits while it holds work, published work is always held by a running wave, and the
+// ticket count is fixed (envs x substeps), so every wave terminates; spins are capped anyway and a timeout raises a flag.
+template <bool S> __device__ __forceinline__ float ldstate(const float* p) {
+  if (S) return __int_as_float(__hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  return *p;
+}
+template <bool S> __device__ __forceinline__ int ldstatei(const int* p) {
+  if (S) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+struct SchedDev {
+  int* ctl;      // [8][4]: head (next ticket), tail (next publish index), n (envs of this queue), error
+  int* ring;     // [8][stride]: gen << 24 | substep << 20 | env
+  int stride, nsubtot;
+};
+#define SCHED_ENV_MASK 0xFFFFF
+__global__ void __launch_bounds__(1024) sched_init_kernel(const int* __restrict__ diag, int B, SchedDev S) {
+  __shared__ int hist[256], start[256];
+  __shared__ int cmax_s;
+  const int t = threadIdx.x;
+  if (t < 256) hist[t] = 0;
+  if (t == 0) cmax_s = 1;
+  if (t < 8) { int n = (B - t + 7) / 8; S.ctl[4 * t] = 0; S.ctl[4 * t + 1] = n; S.ctl[4 * t + 2] = n; S.ctl[4 * t + 3] = 0; }
+  __syncthreads();
+  int cm = 1;
+  for (int e = t; e < B; e += 1024) cm = max(cm, diag[(size_t)e * 8 + 3]);
+  atomicMax(&cmax_s, cm);
+  __syncthreads();
+  const int cmax = cmax_s;
+  for (int e = t; e < B; e += 1024) atomicAdd(&hist[255 - min(255, (int)(255LL * diag[(size_t)e * 8 + 3] / cmax))], 1);   // bucket 0 = heaviest
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int k = 0; k < 256; k++) { start[k] = acc; acc += hist[k]; } }
+  __syncthreads();
+  for (int e = t; e < B; e += 1024) {
+    int b = 255 - min(255, (int)(255LL * diag[(size_t)e * 8 + 3] / cmax));
+    int r = atomicAdd(&start[b], 1);                  // rank by descending predicted cost: heavy envs are served first
+    S.ring[(r & 7) * S.stride + (r >> 3)] = e;        // generation 0, substep 0
+  }
+}
+
+// table sizes of the compiled config models (after lowering): SPEC = 1 (MyoHand, myohand_pose.xml) and SPEC = 2 (MyoLeg, myolegs.xml)
+// instantiations of the wave kernel take their loop bounds from here; SPEC = 0 reads them from the model at run time
+template <int SPEC> struct Sizes { static constexpr int nq = 0, nv = 0, nu = 0, nl = 0, nlevel = 0, maxnnz = 0, nseg = 0, ncg = 0, npair = 0; };
+template <> struct Sizes<1> { static constexpr int nq = 23, nv = 23, nu = 39, nl = 17, nlevel = 5, maxnnz = 7, nseg = 116, ncg = 27, npair = 289; };
+template <> struct Sizes<2> { static constexpr int nq = 35, nv = 34, nu = 80, nl = 13, nlevel = 6, maxnnz = 11, nseg = 100, ncg = 32, npair = 45; };
+template <int SPEC> static bool sizes_match(int nq, int nv, int nu, int nl, int nlevel, int maxnnz, int ngt, int nseg, int ncg, int npair) {
+  typedef Sizes<SPEC> Z;
+  return nq == Z::nq && nv == Z::nv && nu == Z::nu && nl == Z::nl && nlevel == Z::nlevel && maxnnz == Z::maxnnz && ngt == Z::nu && nseg == Z::nseg &&
+         ncg == Z::ncg && npair == Z::npair;
+}
+
+template <int NVT, int KC, int NC, int NTR, int WPE, bool SCHED, int SPEC>
+__global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restrict__ Mp, const DevModelW* __restrict__ Wp, DevBatch Bt,
+                                                        const float* __restrict__ action, int actmap, int nsub, long long* stamps,
+                                                        const int* __restrict__ order, const DevWalk* __restrict__ wk, int kflags, SchedDev S) {
+  extern __shared__ __align__(16) float E[];
+  // the model structs stay in (scalar-cached) global memory: fields are s_load-ed where they are used instead of
+  // pinning ~150 SGPRs for the whole kernel
+  const DevModel& M = *Mp;
+  const DevModelW& W = *Wp;
+  const LayW& Y = W.lay;
+  const int lane_id = threadIdx.x;
+  // workgroup -> env map: a speed-only placement hint (envs sorted by last step's cost, see balance_kernel); results of an
+  // env never depend on which workgroup steps it
+  const int oe = (!SCHED && order) ? order[blockIdx.x] : blockIdx.x;
+  int env = oe & 0x0FFFFFFF;
+  // the four waves of a SIMD come from different cost quartiles (balance_kernel); the predicted-heavy ones get a higher issue
+  // priority so that the launch's critical path -- its heaviest waves -- is not slowed down by lighter neighbours that have slack
+  if (!SCHED) {
+    switch (oe >> 28) {
+      case 3: __builtin_amdgcn_s_setprio(3); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      default: break;
+    }
+  }
+  // SPEC != 0: the model has exactly the table sizes of Sizes<SPEC> (checked by myo_model_load): loop bounds become compile-time
+  // constants (+3 % measured on MyoHand); SPEC = 0 reads them from the model
+  typedef Sizes<SPEC> Z;
+  const int nv = SPEC ? Z::nv : M.nv, nu = SPEC ? Z::nu : M.nu, nq = SPEC ? Z::nq : W.nq;
+  const int nl_ = SPEC ? Z::nl : M.nl, nlevel_ = SPEC ? Z::nlevel : M.nlevel, maxnnz_ = SPEC ? Z::maxnnz : M.maxnnz, ngt_ = SPEC ? Z::nu : M.ngt,
+            nseg_ = SPEC ? Z::nseg : M.nseg, ncg_ = SPEC ? Z::ncg : M.ncg, npair_ = SPEC ? Z::npair : M.npair;
+  constexpr int CDW = (KC + 3) / 4;   // ints per contact holding its KC byte-packed dof ids
+  // the small instantiation (hand / finger class) is compiled without the free-joint, equality, plane-contact and condim-1 code;
+  // myo_model_load routes any model that needs one of those to the large instantiation
+  constexpr bool FULL = NVT > 24;
+  const bool has_free = FULL && W.has_free;
+  const int neq = FULL ? W.neq : 0;
+  const bool walk = FULL && wk != nullptr;   // fused observation / reward pass of the walk task after the last substep
+  if (!SCHED && FULL && (kflags & KF_RESET_ONLY) && Bt.elapsed[env] != 0) return;   // wave-uniform: refresh only the envs an auto-reset just touched
+#if MYO_STAMPS
+  long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long st_t0 = clock64();
+#endif
+  const int nsubtot = nsub + (walk ? 1 : 0);
+  const float h = M.timestep;
+  const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
+  const float damping = lane_id < nv ? M.dof_damping[lane_id] : 0.f;
+  // scheduler state of this wave: the queue of the XCD it runs on
+  const int sq_q = SCHED ? (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7) : 0;
+  int* const sq_ctl = SCHED ? S.ctl + 4 * sq_q : nullptr;
+  int* const sq_ring = SCHED ? S.ring + (size_t)sq_q * S.stride : nullptr;
+  const int sq_n = SCHED ? sq_ctl[2] : 0;
+  int last_cost = 0;
+  for (;;) {   // task loop: one (env, substep) per pass when SCHED, a single pass over all substeps of this workgroup's env otherwise
+  int s0 = 0, s1 = nsubtot;
+  if (SCHED) {
+    int t = 0;
+    if (lane_id == 0) t = atomicAdd(&sq_ctl[0], 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= sq_n * nsubtot) break;                       // every ticket of this queue is taken: this wave is done
+    const int gen = t / sq_n, slot = t - gen * sq_n;
+    int v = 0, spins = 0;
+    for (;;) {                                            // wait until the slot of this ticket has been published
+      v = __hip_atomic_load(&sq_ring[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((v >> 24) == gen || ++spins > (1 << 21)) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    v = __builtin_amdgcn_readfirstlane(v);
+    if ((v >> 24) != gen) { if (lane_id == 0) { atomicOr(&Bt.flags[0], MYO_FLAG_SCHED_TIMEOUT); sq_ctl[3] = 1; } break; }
+    env = v & SCHED_ENV_MASK;
+    s0 = (v >> 20) & 15; s1 = s0 + 1;
+  }
+  // ---- state: LDS copies of what other lanes gather; per-dof / per-actuator scalars stay in registers.  Under the scheduler the
+  // rows were written by another CU of this XCD: agent-scope loads read them from L2 instead of a possibly stale L1 line
+  float warm = 0.f, qacc = 0.f, actdot[NTR];
+#pragma unroll
+  for (int r = 0; r < NTR; r++) actdot[r] = 0.f;
+  if (lane_id < nq) E[Y.qpos + lane_id] = ldstate<SCHED>(Bt.qpos + (size_t)env * nq + lane_id);
+  if (lane_id < nv) {
+    E[Y.qvel + lane_id] = ldstate<SCHED>(Bt.qvel + (size_t)env * nv + lane_id);
+    warm = ldstate<SCHED>(Bt.warm + (size_t)env * nv + lane_id);
+  }
+  for (int i = lane_id; i < nu; i += 64) {
+    E[Y.act + i] = ldstate<SCHED>(Bt.act + (size_t)env * nu + i);
+    float c;
+    if (action && s0 == 0) c = action_map(Bt, M.act, action, env, i, nu, actmap);   // the action map runs once per env step
+    else c = ldstate<SCHED>(Bt.ctrl + (size_t)env * nu + i);
+    E[Y.ctrl + i] = c;
+  }
+  float time = ldstate<SCHED>(Bt.time + env);
+  int flags = 0, d_nefc = 0, d_ncon = 0, d_iter = 0, d_cost = 0;
+  int f_cand = 0, f_mpr = 0, f_ncon = 0, f_iter = 0, f_itcon = 0, f_ls = 0, f_fact = 0;   // work features of this env step (placement cost model)
+  if (SCHED && s0 > 0) {   // accumulators of the earlier substeps of this env step
+    const int* D = Bt.diag + (size_t)env * 8;
+    int a2 = ldstatei<SCHED>(D + 2), a4 = ldstatei<SCHED>(D + 4), a5 = ldstatei<SCHED>(D + 5), a6 = ldstatei<SCHED>(D + 6), a7 = ldstatei<SCHED>(D + 7);
+    d_nefc = ldstatei<SCHED>(D); d_ncon = ldstatei<SCHED>(D + 1);   // the observation pass has no rows of its own: keep the last substep's
+    d_iter = a2; f_cand = a4 & 0xFFFF; f_ncon = a4 >> 16; f_mpr = a5; f_itcon = a6 & 0xFFFF; f_iter = a6 >> 16; f_ls = a7 & 0xFFFF; f_fact = a7 >> 16;
+  }
+  bool alive = true;
+  SYNC();
+  for (int step = s0; step < s1; step++) {
+    const bool op = walk && step == nsub;   // observation pass: position / velocity stages at the post-step state, then out
+    // compiler-only barrier: keeps the (substep-invariant) model-table loads inside the loop body instead of hoisting
+    // ~60 values per lane out of it and spilling them to scratch
+    asm volatile("" ::: "memory");
+    int lane;   // opaque per-iteration copy of the lane id: address arithmetic derived from it cannot be hoisted (and spilled)
+    asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane_id));
+    {  // mj_checkPos / mj_checkVel
+      bool bad = false;
+      if (lane < nq) { float a = E[Y.qpos + lane]; bad = !(a == a) || fabsf(a) > MAXVALF; }
+      if (lane < nv) { float b = E[Y.qvel + lane]; bad = bad || !(b == b) || fabsf(b) > MAXVALF; }
+      if (__any(bad) && alive && !op) { flags |= MYO_FLAG_BAD_STATE; alive = false; }
+    }
+    STAMP(0);
+    // ---------------------------------------------------------------- kinematics (lane = link, level by level)
+    for (int L = 0; L < nlevel_; L++) {
+      int l = M.level_adr[L] + lane;
+      if (l < M.level_adr[L + 1]) {
+        float pos[3], R[9];
+        int par = M.link_parent[l];
+        const float* lp = M.link_pos + 3 * l;
+        if (par < 0) {
+          pos[0] = lp[0]; pos[1] = lp[1]; pos[2] = lp[2];
+#pragma unroll
+          for (int k = 0; k < 9; k++) R[k] = W.link_mat0[9 * l + k];
+        } else {
+          float v[3];
+          matvec(v, E + Y.lmat + 9 * par, lp);
+          pos[0] = E[Y.lpos + 3 * par] + v[0]; pos[1] = E[Y.lpos + 3 * par + 1] + v[1]; pos[2] = E[Y.lpos + 3 * par + 2] + v[2];
+          matmul3(R, E + Y.lmat + 9 * par, W.link_mat0 + 9 * l);
+        }
+        int da = M.link_dofadr[l], dn = M.link_dofnum[l];
+        if (has_free && W.link_free[l]) {
+          // free joint: pose straight from qpos (position + unit quaternion); its 3 translational dofs act like slides along
+          // the world axes and its 3 rotational dofs like hinges about the body axes through the body origin
+          int qa = W.dof_qposadr[da];
+          pos[0] = E[Y.qpos + qa]; pos[1] = E[Y.qpos + qa + 1]; pos[2] = E[Y.qpos + qa + 2];
+          float q[4] = {E[Y.qpos + qa + 3], E[Y.qpos + qa + 4], E[Y.qpos + qa + 5], E[Y.qpos + qa + 6]};
+          float qn = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+          q[0] *= qn; q[1] *= qn; q[2] *= qn; q[3] *= qn;
+          quat2mat(R, q);
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            E[Y.axis + 3 * (da + k)] = k == 0 ? 1.f : 0.f; E[Y.axis + 3 * (da + k) + 1] = k == 1 ? 1.f : 0.f; E[Y.axis + 3 * (da + k) + 2] = k == 2 ? 1.f : 0.f;
+            E[Y.axis + 3 * (da + 3 + k)] = R[k]; E[Y.axis + 3 * (da + 3 + k) + 1] = R[3 + k]; E[Y.axis + 3 * (da + 3 + k) + 2] = R[6 + k];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { E[Y.anchor + 3 * (da + k) + c] = pos[c]; E[Y.anchor + 3 * (da + 3 + k) + c] = pos[c]; }
+          }
+          dn = 0;
+        }
+        for (int k = 0; k < dn; k++) {
+          int d = da + k;
+          const float* al = M.dof_axis + 3 * d;
+          float ax[3], an[3];
+          matvec(ax, R, al);
+          matvec(an, R, M.dof_pos + 3 * d);
+          an[0] += pos[0]; an[1] += pos[1]; an[2] += pos[2];
+          E[Y.axis + 3 * d] = ax[0]; E[Y.axis + 3 * d + 1] = ax[1]; E[Y.axis + 3 * d + 2] = ax[2];
+          E[Y.anchor + 3 * d] = an[0]; E[Y.anchor + 3 * d + 1] = an[1]; E[Y.anchor + 3 * d + 2] = an[2];
+          float ang = E[Y.qpos + W.dof_qposadr[d]] - M.qpos0[W.dof_qposadr[d]];
+          if (M.dof_type[d] == 3) {
+            float sn, cs;
+            sincosf(ang, &sn, &cs);
+            float oc = 1 - cs, x = al[0], y = al[1], z = al[2];
+            float Rj[9] = {cs + oc * x * x, oc * x * y - sn * z, oc * x * z + sn * y, oc * x * y + sn * z, cs + oc * y * y, oc * y * z - sn * x,
+                           oc * x * z - sn * y, oc * y * z + sn * x, cs + oc * z * z};
+            matmul3(R, R, Rj);
+            float v[3];
+            matvec(v, R, M.dof_pos + 3 * d);
+            pos[0] = an[0] - v[0]; pos[1] = an[1] - v[1]; pos[2] = an[2] - v[2];
+          } else {
+            pos[0] += ax[0] * ang; pos[1] += ax[1] * ang; pos[2] += ax[2] * ang;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) E[Y.lpos + 3 * l + k] = pos[k];
+#pragma unroll
+        for (int k = 0; k < 9; k++) E[Y.lmat + 9 * l + k] = R[k];
+      }
+      SYNC();
+    }
+    // reference point of the spatial (6-D) quantities: fixed for fixed-base models, the root link's origin for free-floating ones
+    const float c0[3] = {has_free ? E[Y.lpos] : M.c0[0], has_free ? E[Y.lpos + 1] : M.c0[1], has_free ? E[Y.lpos + 2] : M.c0[2]};
+    STAMP(1);
+    // ---------------------------------------------------------------- tendons: lane = segment
+    float tlen_r[NTR], tvel_r[NTR];
+    for (int base = 0; base < nseg_; base += 64) {
+      int idx = base + lane;
+      if (idx < nseg_) {
+        int si = W.seg_order[idx];
+        const int* S = M.seg + 12 * si;
+        float invdiv = 1.0f / M.seg_div[si];
+        float p0[3], p1[3];
+        site_world_w(M, Y, E, S[0], p0);
+        site_world_w(M, Y, E, S[1], p1);
+        float wlen = -1, wp[6];
+        if (S[2] >= 0) {
+          int g = S[2], gl = M.wg_link[g];
+          float gpos[3], gmat[9], side[3] = {0, 0, 0};
+          if (gl < 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) gpos[k] = M.wg_lpos[3 * g + k];
+#pragma unroll
+            for (int k = 0; k < 9; k++) gmat[k] = M.wg_lmat[9 * g + k];
+          } else {
+            float v[3];
+            matvec(v, E + Y.lmat + 9 * gl, M.wg_lpos + 3 * g);
+#pragma unroll
+            for (int k = 0; k < 3; k++) gpos[k] = E[Y.lpos + 3 * gl + k] + v[k];
+            matmul3(gmat, E + Y.lmat + 9 * gl, M.wg_lmat + 9 * g);
+          }
+          if (S[3] >= 0) site_world_w(M, Y, E, S[3], side);
+          wlen = wrap_geom(wp, p0, p1, gpos, gmat, M.wg_radius[g], S[10] != 0, side, S[3] >= 0);
+        }
+        bool wr = wlen >= 0;
+        float L = straight_w(M, Y, E, p0, p1, S[4], S[5], invdiv, !wr);
+        if (S[2] >= 0) {
+          L += straight_w(M, Y, E, p0, wp, S[6], S[7], invdiv, wr);
+          L += straight_w(M, Y, E, wp + 3, p1, S[8], S[9], invdiv, wr);
+          if (wr) L += wlen * invdiv;
+        }
+        E[Y.seglen + si] = L;
+      }
+    }
+    SYNC();
+#pragma unroll
+    for (int rr = 0; rr < NTR; rr++) {  // lane = tendon (NTR rounds of 64): gather its segments, then the muscle
+      int gt = lane + 64 * rr;
+      tlen_r[rr] = 0.f; tvel_r[rr] = 0.f;
+      if (gt >= ngt_) continue;
+      float* Jrow = E + Y.tJ + gt * maxnnz_;
+      for (int k = 0; k < maxnnz_; k++) Jrow[k] = 0;
+      float L = M.gt_len0[gt];   // constant same-link segments, folded at lowering time
+      for (int si = M.gt_seg_adr[gt]; si < M.gt_seg_adr[gt] + M.gt_seg_num[gt]; si++) L += E[Y.seglen + si];
+      int e0 = W.gt_dl[2 * gt], en = W.gt_dl[2 * gt + 1];
+      for (int e = e0; e < e0 + en; e++) Jrow[M.dl[3 * e + 2]] += E[Y.dlval + e];
+      E[Y.tlen + gt] = L;
+      tlen_r[rr] = L;
+      float vel = 0;
+      for (int k = 0; k < maxnnz_; k++) {
+        int d = M.gt_dofs[gt * maxnnz_ + k];
+        if (d >= 0) vel += Jrow[k] * E[Y.qvel + d];
+        if (W.has_tl) E[Y.tJp + gt * maxnnz_ + k] = Jrow[k];
+      }
+      tvel_r[rr] = vel;
+      if (gt < nu) {
+        const float* A = M.act + 16 * gt;
+        float f, ad;
+        muscle(A, A[14] * L, A[14] * vel, E[Y.act + gt], E[Y.ctrl + gt], &f, &ad);
+        actdot[rr] = ad;
+        E[Y.tforce + gt] = f * A[14];
+      }
+    }
+    SYNC();
+    float qfa = 0.f;
+    if (lane < nv) {
+      for (int k = M.col_adr[lane]; k < M.col_adr[lane + 1]; k++) {
+        int t = M.col[2 * k], slot = M.col[2 * k + 1];
+        qfa += E[Y.tJ + t * maxnnz_ + slot] * E[Y.tforce + t];
+      }
+    }
+    if (step == nsub - 1) {   // diagnostics of the last substep
+      for (int i = lane; i < nu; i += 64) { Bt.tenlen[(size_t)env * nu + i] = E[Y.tlen + i]; Bt.actforce[(size_t)env * nu + i] = E[Y.tforce + i]; }
+    }
+    if (FULL && op) {   // walk observation, muscle block (walk_v0.py:283-285,354-361): length, clipped velocity, clipped force / 1000, then act
+      float* o = Bt.obs + (size_t)env * wk->obs_dim + (nq - 2 + nv + 16);
+#pragma unroll
+      for (int rr = 0; rr < NTR; rr++) {
+        int gt = lane + 64 * rr;
+        if (gt < nu) {
+          float g = M.act[16 * gt + 14];
+          o[gt] = g * tlen_r[rr];
+          o[nu + gt] = clipf(g * tvel_r[rr], -100.f, 100.f);
+          o[2 * nu + gt] = clipf(E[Y.tforce + gt] / (g != 0.f ? g : 1.f) * 1e-3f, -100.f, 100.f);
+          o[3 * nu + gt] = E[Y.act + gt];
+        }
+      }
+    }
+    SYNC();  // region X changes owner: tendon scratch -> spatial dynamics
+    STAMP(2);
+    // ---------------------------------------------------------------- CRB + RNE (lane = link / dof)
+    if (lane < nl_) {
+      int l = lane;
+      const float* R = E + Y.lmat + 9 * l;
+      const float* I = M.link_inertia + 6 * l;
+      float Il[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}, T[9], Iw[9], com[3];
+      matmul3(T, R, Il);
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Iw[3 * i + j] = T[3 * i] * R[3 * j] + T[3 * i + 1] * R[3 * j + 1] + T[3 * i + 2] * R[3 * j + 2];
+      matvec(com, R, M.link_com + 3 * l);
+      float mass = M.link_mass[l];
+      float dif[3] = {E[Y.lpos + 3 * l] + com[0] - c0[0], E[Y.lpos + 3 * l + 1] + com[1] - c0[1], E[Y.lpos + 3 * l + 2] + com[2] - c0[2]};
+      float ci[10];
+      ci[0] = Iw[0] + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
+      ci[1] = Iw[4] + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
+      ci[2] = Iw[8] + mass * (dif[0] * dif[0] + dif[1] * dif[1]);
+      ci[3] = Iw[1] - mass * dif[0] * dif[1];
+      ci[4] = Iw[2] - mass * dif[0] * dif[2];
+      ci[5] = Iw[5] - mass * dif[1] * dif[2];
+      ci[6] = mass * dif[0]; ci[7] = mass * dif[1]; ci[8] = mass * dif[2]; ci[9] = mass;
+#pragma unroll
+      for (int k = 0; k < 10; k++) { E[Y.cinert + 10 * l + k] = ci[k]; E[Y.crb + 10 * l + k] = ci[k]; }
+    }
+    if (lane < nv) {
+      int d = lane;
+      const float* ax = E + Y.axis + 3 * d;
+      float c[6];
+      if (M.dof_type[d] == 3) {
+        float off[3] = {c0[0] - E[Y.anchor + 3 * d], c0[1] - E[Y.anchor + 3 * d + 1], c0[2] - E[Y.anchor + 3 * d + 2]};
+        c[0] = ax[0]; c[1] = ax[1]; c[2] = ax[2];
+        cross3(c + 3, ax, off);
+      } else { c[0] = c[1] = c[2] = 0; c[3] = ax[0]; c[4] = ax[1]; c[5] = ax[2]; }
+#pragma unroll
+      for (int k = 0; k < 6; k++) E[Y.cdof + 6 * d + k] = c[k];
+    }
+    WFOR(i, NVT * (NVT + 1)) E[Y.sq + i] = 0;
+    SYNC();
+    for (int L = 0; L < nlevel_; L++) {
+      int l = M.level_adr[L] + lane;
+      if (l < M.level_adr[L + 1]) {
+        int par = M.link_parent[l];
+        float cvel[6], cacc[6];
+        if (par < 0) {
+          cvel[0] = cvel[1] = cvel[2] = cvel[3] = cvel[4] = cvel[5] = 0;
+          cacc[0] = cacc[1] = cacc[2] = 0; cacc[3] = -M.grav[0]; cacc[4] = -M.grav[1]; cacc[5] = -M.grav[2];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 6; k++) { cvel[k] = E[Y.cvel + 6 * par + k]; cacc[k] = E[Y.cacc + 6 * par + k]; }
+        }
+        int da = M.link_dofadr[l], dn = M.link_dofnum[l];
+        const bool isfree = has_free && W.link_free[l];
+        float cvel_rot[6];
+        for (int j = 0; j < dn; j++) {
+          int d = da + j;
+          float cd[6], cdd[6], qv = E[Y.qvel + d];
+#pragma unroll
+          for (int k = 0; k < 6; k++) cd[k] = E[Y.cdof + 6 * d + k];
+          if (isfree && j == 3) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) cvel_rot[k] = cvel[k];   // velocity after the translations, before any of the 3 rotations
+          }
+          cross_motion(cdd, (isfree && j >= 3) ? cvel_rot : cvel, cd);
+#pragma unroll
+          for (int k = 0; k < 6; k++) { cacc[k] += cdd[k] * qv; cvel[k] += cd[k] * qv; }
+        }
+        float ci[10], f[6], t[6], t1[6];
+#pragma unroll
+        for (int k = 0; k < 10; k++) ci[k] = E[Y.cinert + 10 * l + k];
+        mul_inert_vec(f, ci, cacc);
+        mul_inert_vec(t, ci, cvel);
+        cross_force(t1, cvel, t);
+#pragma unroll
+        for (int k = 0; k < 6; k++) { E[Y.cvel + 6 * l + k] = cvel[k]; E[Y.cacc + 6 * l + k] = cacc[k]; E[Y.cfrc + 6 * l + k] = f[k] + t1[k]; }
+      }
+      SYNC();
+    }
+    if (FULL && op) {
+      // ---- walk observation / reward (walk_v0.py:268-316, 363-470) from link frames and link velocities of this pass
+      float* o = Bt.obs + (size_t)env * wk->obs_dim;
+      if (lane < nq - 2) o[lane] = E[Y.qpos + 2 + lane];                    // qpos_without_xy
+      if (lane < nv) o[nq - 2 + lane] = E[Y.qvel + lane] * wk->dt;          // qvel * dt
+      float mc[3] = {0.f, 0.f, 0.f}, ml = 0.f;
+      if (lane < nl_) {
+        float cw[3];
+        matvec(cw, E + Y.lmat + 9 * lane, M.link_com + 3 * lane);
+        ml = M.link_mass[lane];
+#pragma unroll
+        for (int k = 0; k < 3; k++) mc[k] = ml * (E[Y.lpos + 3 * lane + k] + cw[k]);
+      }
+      const float mmov = wave_sum(ml);
+      const float sx = wave_sum(mc[0]), sy = wave_sum(mc[1]), sz = wave_sum(mc[2]);
+      // MuJoCo's cvel is the velocity of the body-fixed point that coincides with the root's subtree COM (COM of the moving bodies)
+      const float cm[3] = {sx / mmov, sy / mmov, sz / mmov};
+      float mv[2] = {0.f, 0.f};
+      if (lane < nl_) {
+        const float* cv = E + Y.cvel + 6 * lane;
+        float r[3] = {cm[0] - c0[0], cm[1] - c0[1], cm[2] - c0[2]}, wr[3];
+        cross3(wr, cv, r);
+        mv[0] = ml * (cv[3] + wr[0]); mv[1] = ml * (cv[4] + wr[1]);
+      }
+      const float cvx = -wave_sum(mv[0]) / wk->mass_total, cvy = -wave_sum(mv[1]) / wk->mass_total;   // walk_v0.py:438-444 (note the minus)
+      const float height = (sz + wk->static_mcom[2]) / wk->mass_total;                                  // walk_v0.py:446-450,465-470
+      if (lane == 0) {
+        const int sb = nq - 2 + nv;
+        o[sb] = cvx; o[sb + 1] = cvy;
+        float q[4] = {E[Y.qpos + 3], E[Y.qpos + 4], E[Y.qpos + 5], E[Y.qpos + 6]};
+        float qn = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        float u[4] = {q[0] * qn, q[1] * qn, q[2] * qn, q[3] * qn};
+        const float* t = wk->lquat_tor;
+        float tq[4] = {u[0] * t[0] - u[1] * t[1] - u[2] * t[2] - u[3] * t[3], u[0] * t[1] + u[1] * t[0] + u[2] * t[3] - u[3] * t[2],
+                       u[0] * t[2] - u[1] * t[3] + u[2] * t[0] + u[3] * t[1], u[0] * t[3] + u[1] * t[2] - u[2] * t[1] + u[3] * t[0]};
+        float tn = 1.0f / sqrtf(tq[0] * tq[0] + tq[1] * tq[1] + tq[2] * tq[2] + tq[3] * tq[3]);
+        o[sb + 2] = tq[0] * tn; o[sb + 3] = tq[1] * tn; o[sb + 4] = tq[2] * tn; o[sb + 5] = tq[3] * tn;   // torso xquat
+        float pl[3], pr[3], pp[3], v[3];
+        matvec(v, E + Y.lmat + 9 * wk->link_tl, wk->lpos_tl);
+#pragma unroll
+        for (int k = 0; k < 3; k++) pl[k] = E[Y.lpos + 3 * wk->link_tl + k] + v[k];
+        matvec(v, E + Y.lmat + 9 * wk->link_tr, wk->lpos_tr);
+#pragma unroll
+        for (int k = 0; k < 3; k++) pr[k] = E[Y.lpos + 3 * wk->link_tr + k] + v[k];
+        matvec(v, E + Y.lmat + 9 * wk->link_pel, wk->lpos_pel);
+#pragma unroll
+        for (int k = 0; k < 3; k++) pp[k] = E[Y.lpos + 3 * wk->link_pel + k] + v[k];
+        o[sb + 6] = pl[2]; o[sb + 7] = pr[2];                                    // feet heights (talus_l, talus_r)
+        o[sb + 8] = height;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { o[sb + 9 + k] = pl[k] - pp[k]; o[sb + 12 + k] = pr[k] - pp[k]; }   // feet relative to the pelvis
+        const float phase = fmodf((float)Bt.elapsed[env] / (float)wk->hip_period, 1.0f);
+        o[sb + 15] = phase;
+        if (!(kflags & KF_OBS_ONLY)) {
+          float dvy = wk->target_y_vel - cvy, dvx = wk->target_x_vel - cvx;
+          float vel_reward = expf(-dvy * dvy) + expf(-dvx * dvx);
+          float d0 = 0.8f * cosf(phase * 6.283185307179586f + 3.141592653589793f) - E[Y.qpos + wk->qadr_hfl];
+          float d1 = 0.8f * cosf(phase * 6.283185307179586f) - E[Y.qpos + wk->qadr_hfr];
+          float cyclic = sqrtf(d0 * d0 + d1 * d1);
+          float dq[4] = {q[0] - wk->target_rot[0], q[1] - wk->target_rot[1], q[2] - wk->target_rot[2], q[3] - wk->target_rot[3]};
+          float ref_rot = expf(-5.0f * sqrtf(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]));
+          float mag = 0.25f * (fabsf(E[Y.qpos + wk->qadr_ja[0]]) + fabsf(E[Y.qpos + wk->qadr_ja[1]]) + fabsf(E[Y.qpos + wk->qadr_ja[2]]) +
+                               fabsf(E[Y.qpos + wk->qadr_ja[3]]));
+          float ja = expf(-5.0f * mag);
+          float r00 = 1.0f - 2.0f * (q[2] * q[2] + q[3] * q[3]) / (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+          float done = (height < wk->min_height || fabsf(r00) > wk->max_rot) ? 1.f : 0.f;
+          Bt.reward[env] = wk->w_vel * vel_reward + wk->w_done * done + wk->w_cyc * cyclic + wk->w_rot * ref_rot + wk->w_ja * ja;
+          Bt.done[env] = done;
+          Bt.solved[env] = vel_reward >= 1.0f ? 1.f : 0.f;
+        }
+      }
+      break;
+    }
+    for (int L = nlevel_ - 2; L >= 0; L--) {
+      int l = M.level_adr[L] + lane;
+      if (l < M.level_adr[L + 1]) {
+        for (int ci = M.child_adr[l]; ci < M.child_adr[l + 1]; ci++) {
+          int c = M.child[ci];
+#pragma unroll
+          for (int k = 0; k < 6; k++) E[Y.cfrc + 6 * l + k] += E[Y.cfrc + 6 * c + k];
+#pragma unroll
+          for (int k = 0; k < 10; k++) E[Y.crb + 10 * l + k] += E[Y.crb + 10 * c + k];
+        }
+      }
+      SYNC();
+    }
+    float smooth = 0.f;
+    if (lane < nv) {
+      int d = lane, l = M.dof_link[d];
+      float cd[6], buf[6], crb[10];
+#pragma unroll
+      for (int k = 0; k < 6; k++) cd[k] = E[Y.cdof + 6 * d + k];
+#pragma unroll
+      for (int k = 0; k < 10; k++) crb[k] = E[Y.crb + 10 * l + k];
+      float bias = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) bias += cd[k] * E[Y.cfrc + 6 * l + k];
+      mul_inert_vec(buf, crb, cd);
+      int a = d;
+      while (a >= 0) {
+        float sdot = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) sdot += E[Y.cdof + 6 * a + k] * buf[k];
+        if (a == d) sdot += M.dof_armature[d];
+        E[Y.sq + d * (NVT + 1) + a] = sdot;   // full symmetric copy: (d,a) and (a,d)
+        E[Y.sq + a * (NVT + 1) + d] = sdot;
+        a = M.dof_parent[a];
+      }
+      smooth = -damping * E[Y.qvel + d] - bias + qfa;
+    }
+    SYNC();  // region X changes owner: dynamics scratch -> collision / contact rows
+    STAMP(3);
+    // ---------------------------------------------------------------- collision (geom frames computed on the fly)
+    int ncon = 0;
+    if (!M.disable_contact) {
+      int ncand = 0;
+      int* cand = (int*)(E + Y.cand);
+      if (lane < ncg_) {   // world centre and long axis (3rd column) of every collision geom
+        float x[3], R[9];
+        geom_world_pos(M, Y, E, lane, x);
+        geom_world_mat(M, Y, E, lane, R);
+        E[Y.gpos + 3 * lane] = x[0]; E[Y.gpos + 3 * lane + 1] = x[1]; E[Y.gpos + 3 * lane + 2] = x[2];
+        E[Y.gax + 3 * lane] = R[2]; E[Y.gax + 3 * lane + 1] = R[5]; E[Y.gax + 3 * lane + 2] = R[8];
+      }
+      SYNC();
+      for (int base = 0; base < npair_; base += 64) {
+        int p = base + lane;
+        bool hit = false;
+        if (p < npair_) {
+          const int* P = M.pair_i + 6 * p;
+          if (!(M.disable_ellipsoid && P[4] == 0)) {
+            int g1 = P[0], g2 = P[1];
+            const float *x1 = E + Y.gpos + 3 * g1, *x2 = E + Y.gpos + 3 * g2;
+            float dif[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
+            float bound = M.cg_rbound[g1] + M.cg_rbound[g2] + M.pair_f[12 * p];
+            if (FULL && P[4] >= 2) hit = dot3(dif, E + Y.gax + 3 * g1) <= M.cg_rbound[g2] + M.pair_f[12 * p];   // plane: signed distance of the bounding sphere
+            else hit = dot3(dif, dif) <= bound * bound;
+            if (hit && !P[4]) {
+              // conservative refinement before the expensive MPR: replace a capsule's bounding sphere by the distance
+              // from the other geom's centre to the capsule's SEGMENT (a bound on the true distance, never excludes a contact)
+              float b1 = M.cg_rbound[g1], b2 = M.cg_rbound[g2];
+              float c1[3] = {x1[0], x1[1], x1[2]}, c2[3] = {x2[0], x2[1], x2[2]};
+              if (M.cg_type[g1] == GEOM_CAPSULE) {
+                const float* a = E + Y.gax + 3 * g1;
+                float hh = M.cg_size[3 * g1 + 1], t = clipf(dot3(dif, a), -hh, hh);
+                c1[0] += t * a[0]; c1[1] += t * a[1]; c1[2] += t * a[2];
+                b1 = M.cg_size[3 * g1];
+              }
+              if (M.cg_type[g2] == GEOM_CAPSULE) {
+                const float* a = E + Y.gax + 3 * g2;
+                float nd[3] = {c1[0] - x2[0], c1[1] - x2[1], c1[2] - x2[2]};
+                float hh = M.cg_size[3 * g2 + 1], t = clipf(dot3(nd, a), -hh, hh);
+                c2[0] += t * a[0]; c2[1] += t * a[1]; c2[2] += t * a[2];
+                b2 = M.cg_size[3 * g2];
+              }
+              float d2[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
+              float bb = b1 + b2 + M.pair_f[12 * p];
+              hit = dot3(d2, d2) <= bb * bb;
+              if (hit) {
+                // separating-axis test along the centre line: the two (margin-inflated) convex shapes cannot touch if their
+                // support widths along that axis do not reach across the centre distance.  MPR would report "no contact" for
+                // exactly these pairs, after a dozen support evaluations; this costs one support width per shape
+                float dn = norm3(dif);
+                if (dn > MINVALF) {
+                  float inv = 1.0f / dn, ax[3] = {dif[0] * inv, dif[1] * inv, dif[2] * inv}, wsum = M.pair_f[12 * p];
+#pragma unroll
+                  for (int side = 0; side < 2; side++) {
+                    const int g = side ? g2 : g1;
+                    const float* sz = M.cg_size + 3 * g;
+                    const int ty = M.cg_type[g];
+                    if (ty == GEOM_CAPSULE) wsum += sz[0] + sz[1] * fabsf(dot3(E + Y.gax + 3 * g, ax));
+                    else if (ty == GEOM_SPHERE) wsum += sz[0];
+                    else {
+                      float R[9], dl[3];
+                      geom_world_mat(M, Y, E, g, R);
+                      matTvec(dl, R, ax);
+                      if (ty == GEOM_ELLIPSOID) { float sv[3] = {sz[0] * dl[0], sz[1] * dl[1], sz[2] * dl[2]}; wsum += norm3(sv); }
+                      else wsum += sz[0] * sqrtf(dl[0] * dl[0] + dl[1] * dl[1]) + sz[1] * fabsf(dl[2]);   // cylinder
+                    }
+                  }
+                  hit = dn <= wsum * 1.0001f + 1e-6f;   // conservative: never excludes a touching pair
+                }
+              }
+            }
+          }
+        }
+        unsigned long long bal = __ballot(hit);
+        int pos = ncand + __popcll(bal & ((1ull << lane) - 1ull));
+        if (hit && pos < NCAND) cand[pos] = p;
+        ncand += __popcll(bal);
+      }
+      if (ncand > NCAND) { flags |= MYO_FLAG_CAND_OVERFLOW; ncand = NCAND; }
+      f_cand += ncand;
+      SYNC();
+      STAMP(6);
+      for (int base = 0; base < ncand; base += 64) {
+        int ci = base + lane;
+        int nsup = -8;                    // support evaluations of this lane's MPR refinement (-8: not an MPR pair)
+        bool hit = false, hit2 = false;   // a plane-capsule pair can give two contacts (one per end sphere)
+        float dist = 0, dist2 = 0, cpos[3] = {0, 0, 0}, cpos2[3] = {0, 0, 0}, nrm[3] = {1, 0, 0};
+        int p = -1;
+        if (ci < ncand) {
+          p = cand[ci];
+          const int* P = M.pair_i + 6 * p;
+          int g1 = P[0], g2 = P[1];
+          float margin = M.pair_f[12 * p];
+          const float *x1 = E + Y.gpos + 3 * g1, *x2 = E + Y.gpos + 3 * g2;
+          const float *sz1 = M.cg_size + 3 * g1, *sz2 = M.cg_size + 3 * g2;
+          if (P[4] == 1) {
+            const float *a1 = E + Y.gax + 3 * g1, *a2 = E + Y.gax + 3 * g2;
+            float dif[3] = {x1[0] - x2[0], x1[1] - x2[1], x1[2] - x2[2]};
+            float mb = -dot3(a1, a2), u = -dot3(a1, dif), v = dot3(a2, dif), det = 1 - mb * mb, xa, xb;
+            if (fabsf(det) >= MINVALF) {
+              xa = (u - mb * v) / det;
+              xb = (v - mb * u) / det;
+              if (xa > sz1[1]) { xa = sz1[1]; xb = v - mb * sz1[1]; }
+              else if (xa < -sz1[1]) { xa = -sz1[1]; xb = v + mb * sz1[1]; }
+              if (xb > sz2[1]) { xb = sz2[1]; xa = clipf(u - mb * sz2[1], -sz1[1], sz1[1]); }
+              else if (xb < -sz2[1]) { xb = -sz2[1]; xa = clipf(u + mb * sz2[1], -sz1[1], sz1[1]); }
+            } else {
+              xa = clipf(u, -sz1[1], sz1[1]);
+              xb = clipf(v - mb * xa, -sz2[1], sz2[1]);
+              xa = clipf(u - mb * xb, -sz1[1], sz1[1]);
+            }
+            float v1[3] = {x1[0] + a1[0] * xa, x1[1] + a1[1] * xa, x1[2] + a1[2] * xa};
+            float v2[3] = {x2[0] + a2[0] * xb, x2[1] + a2[1] * xb, x2[2] + a2[2] * xb};
+            float dd[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
+            float cd = norm3(dd);
+            if (cd <= margin + sz1[0] + sz2[0]) {
+              if (cd < MINVALF) { dd[0] = 1; dd[1] = 0; dd[2] = 0; } else { float inv = 1.0f / cd; dd[0] *= inv; dd[1] *= inv; dd[2] *= inv; }
+              dist = cd - sz1[0] - sz2[0];
+#pragma unroll
+              for (int k = 0; k < 3; k++) { cpos[k] = v1[k] + dd[k] * (sz1[0] + 0.5f * dist); nrm[k] = dd[k]; }
+              hit = true;
+            }
+          } else if (FULL && P[4] == 2) {   // plane - capsule (mjc_PlaneCapsule): the two end spheres against the plane
+            const float *n = E + Y.gax + 3 * g1, *ax = E + Y.gax + 3 * g2;
+            float r = sz2[0], hh = sz2[1];
+#pragma unroll
+            for (int k = 0; k < 3; k++) nrm[k] = n[k];
+            float eA[3] = {x2[0] - hh * ax[0] - x1[0], x2[1] - hh * ax[1] - x1[1], x2[2] - hh * ax[2] - x1[2]};
+            float eB[3] = {x2[0] + hh * ax[0] - x1[0], x2[1] + hh * ax[1] - x1[1], x2[2] + hh * ax[2] - x1[2]};
+            float dA = dot3(eA, n) - r, dB = dot3(eB, n) - r;
+            if (dA <= margin) {
+              hit = true; dist = dA;
+#pragma unroll
+              for (int k = 0; k < 3; k++) cpos[k] = eA[k] + x1[k] - n[k] * (r + 0.5f * dA);
+            }
+            if (dB <= margin) {
+              hit2 = true; dist2 = dB;
+#pragma unroll
+              for (int k = 0; k < 3; k++) cpos2[k] = eB[k] + x1[k] - n[k] * (r + 0.5f * dB);
+            }
+          } else if (FULL && P[4] == 3) {   // plane - ellipsoid (mjc_PlaneConvex): deepest support point along -normal
+            const float* n = E + Y.gax + 3 * g1;
+            float R2[9], nl[3], sp[3], pw[3];
+            geom_world_mat(M, Y, E, g2, R2);
+            matTvec(nl, R2, n);
+            float sv[3] = {sz2[0] * nl[0], sz2[1] * nl[1], sz2[2] * nl[2]};
+            float nn = norm3(sv), inv = nn > MINVALF ? -1.0f / nn : 0.f;
+            sp[0] = sz2[0] * sv[0] * inv; sp[1] = sz2[1] * sv[1] * inv; sp[2] = sz2[2] * sv[2] * inv;
+            matvec(pw, R2, sp);
+            float rel[3] = {x2[0] - x1[0] + pw[0], x2[1] - x1[1] + pw[1], x2[2] - x1[2] + pw[2]};
+            float d = dot3(rel, n);
+#pragma unroll
+            for (int k = 0; k < 3; k++) nrm[k] = n[k];
+            if (d <= margin) {
+              hit = true; dist = d;
+#pragma unroll
+              for (int k = 0; k < 3; k++) cpos[k] = x2[k] + pw[k] - n[k] * 0.5f * d;
+            }
+          } else {
+            const float zero3[3] = {0.f, 0.f, 0.f};
+            nsup = 0;
+            // MPR in geom1's own frame: obj1 needs no rotation / translation at all (identity frame), obj2 carries the
+            // relative pose R1^T R2, R1^T (x2 - x1); normal and position are rotated back afterwards
+            float R1[9];
+            geom_world_mat(M, Y, E, g1, R1);
+            CObj o1, o2;
+            {
+              float R2[9], rel[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
+              geom_world_mat(M, Y, E, g2, R2);
+#pragma unroll
+              for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) o2.mat[3 * i + j] = R1[i] * R2[j] + R1[3 + i] * R2[3 + j] + R1[6 + i] * R2[6 + j];
+              matTvec(o2.pos, R1, rel);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) o1.mat[k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { o1.pos[k] = 0.f; o1.size[k] = sz1[k]; o2.size[k] = sz2[k]; }
+            o1.type = M.cg_type[g1]; o2.type = M.cg_type[g2]; o1.margin = o2.margin = 0.5f * margin;
+            float depth, dir[3], pos[3];
+            if (mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup)) {
+              dist = margin - depth;
+              normalize3(dir);
+              float dw[3], pw[3];
+              matvec(dw, R1, dir);
+              matvec(pw, R1, pos);
+#pragma unroll
+              for (int k = 0; k < 3; k++) { cpos[k] = pw[k] + x1[k]; nrm[k] = dw[k]; }
+              hit = true;
+            }
+          }
+          if (hit && !(dist < margin - M.pair_f[12 * p + 1])) hit = false;
+          if (hit2 && !(dist2 < margin - M.pair_f[12 * p + 1])) hit2 = false;
+        }
+        {  // slowest lane of this round: MPR lanes cost ~8 + refinement steps, analytic pairs ~1
+          int w = nsup + 8;
+          w = max(w, __builtin_amdgcn_update_dpp(0, w, 0xB1, 0xf, 0xf, true));
+          w = max(w, __builtin_amdgcn_update_dpp(0, w, 0x4E, 0xf, 0xf, true));
+          w = max(w, __builtin_amdgcn_update_dpp(0, w, 0x141, 0xf, 0xf, true));
+          w = max(w, __builtin_amdgcn_update_dpp(0, w, 0x140, 0xf, 0xf, true));
+          f_mpr += max(max(rdlanei(w, 0), rdlanei(w, 16)), max(rdlanei(w, 32), rdlanei(w, 48)));
+        }
+        unsigned long long bal = __ballot(hit);
+        int pos = ncon + __popcll(bal & ((1ull << lane) - 1ull));
+        if (hit && pos < NC) {
+          E[Y.cdist + pos] = dist;
+#pragma unroll
+          for (int k = 0; k < 3; k++) { E[Y.cpos + 3 * pos + k] = cpos[k]; E[Y.cnrm + 3 * pos + k] = nrm[k]; }
+          ((int*)(E + Y.cpair))[pos] = p;
+        }
+        ncon += __popcll(bal);
+        bal = FULL ? __ballot(hit2) : 0ull;
+        if (bal) {
+          pos = ncon + __popcll(bal & ((1ull << lane) - 1ull));
+          if (hit2 && pos < NC) {
+            E[Y.cdist + pos] = dist2;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { E[Y.cpos + 3 * pos + k] = cpos2[k]; E[Y.cnrm + 3 * pos + k] = nrm[k]; }
+            ((int*)(E + Y.cpair))[pos] = p;
+          }
+          ncon += __popcll(bal);
+        }
+      }
+      if (ncon > NC) { flags |= MYO_FLAG_CONTACT_OVERFLOW; ncon = NC; }
+      SYNC();
+    }
+    STAMP(4);
+    // ---------------------------------------------------------------- constraint rows (registers: lane = dof / lane = contact)
+    float lsign = 0.f, laref = 0.f, lD = 0.f;
+    if (lane < nv && !M.disable_limit) {
+      const float* J = M.jl + 12 * lane;
+      if (J[0] != 0) {
+        float q = E[Y.qpos + W.dof_qposadr[lane]], margin = J[3];
+        float dlo = q - J[1], dhi = J[2] - q, dist = 0;
+        if (dlo < margin && dlo <= dhi) { lsign = 1; dist = dlo; }
+        else if (dhi < margin) { lsign = -1; dist = dhi; }
+        if (lsign != 0) {
+          float imp = impedance(J + 6, dist, margin), K, B;
+          float R = fmaxf(MINVALF, (1 - imp) / imp * J[11]);
+          kbi(J[4], J[5], J[7], M.timestep, &K, &B);
+          laref = -B * (lsign * E[Y.qvel + lane]) - K * imp * (dist - margin);
+          lD = 1.0f / R;
+        }
+      }
+    }
+    float caref[4] = {0, 0, 0, 0}, cD = 0.f, cmu = 0.f;
+    int ckc = 0;
+    if (lane < ncon) {
+      int c = lane;
+      int p = ((const int*)(E + Y.cpair))[c];
+      const int* P = M.pair_i + 6 * p;
+      const float* F = M.pair_f + 12 * p;
+      float n[3] = {E[Y.cnrm + 3 * c], E[Y.cnrm + 3 * c + 1], E[Y.cnrm + 3 * c + 2]}, t1[3], t2[3];
+      float cp[3] = {E[Y.cpos + 3 * c], E[Y.cpos + 3 * c + 1], E[Y.cpos + 3 * c + 2]};
+      make_frame(n, t1, t2);
+      if (FULL && P[4] == 2) {   // plane - capsule: first tangent along the capsule axis (MuJoCo's frame for this pair type)
+        const float* ax = E + Y.gax + 3 * P[1];
+        float t = dot3(ax, n), y[3] = {ax[0] - t * n[0], ax[1] - t * n[1], ax[2] - t * n[2]};
+        float yn = norm3(y);
+        if (yn >= 0.5f) {
+          float inv = 1.0f / yn;
+          t1[0] = y[0] * inv; t1[1] = y[1] * inv; t1[2] = y[2] * inv;
+          cross3(t2, n, t1);
+        }
+      }
+      float vn = 0, vt1 = 0, vt2 = 0;
+      float* cJ = E + Y.cJ + c * 3 * KC;
+      unsigned int dpk[CDW];
+#pragma unroll
+      for (int k = 0; k < CDW; k++) dpk[k] = 0;
+      ckc = P[3];
+#pragma unroll
+      for (int k = 0; k < KC; k++) {
+        float jn = 0, j1 = 0, j2 = 0;
+        int d = 0;
+        if (k < ckc) {
+          d = M.pair_dl[2 * (P[2] + k)];
+          float sg = (float)M.pair_dl[2 * (P[2] + k) + 1];
+          const float* ax = E + Y.axis + 3 * d;
+          float col[3];
+          if (M.dof_type[d] == 3) {
+            float r[3] = {cp[0] - E[Y.anchor + 3 * d], cp[1] - E[Y.anchor + 3 * d + 1], cp[2] - E[Y.anchor + 3 * d + 2]};
+            cross3(col, ax, r);
+          } else { col[0] = ax[0]; col[1] = ax[1]; col[2] = ax[2]; }
+          jn = sg * dot3(n, col); j1 = sg * dot3(t1, col); j2 = sg * dot3(t2, col);
+          float qv = E[Y.qvel + d];
+          vn += jn * qv; vt1 += j1 * qv; vt2 += j2 * qv;
+        }
+        cJ[k] = jn; cJ[KC + k] = j1; cJ[2 * KC + k] = j2;
+        dpk[k >> 2] |= (unsigned int)d << (8 * (k & 3));   // padded entries: zero jacobian, dof 0
+      }
+#pragma unroll
+      for (int k = 0; k < CDW; k++) ((unsigned int*)(E + Y.cdofs))[CDW * c + k] = dpk[k];
+      float dist = E[Y.cdist + c], incl = F[0] - F[1];
+      cmu = F[2];
+      float imp = impedance(F + 6, dist, incl), K, B;
+      kbi(F[4], F[5], F[7], M.timestep, &K, &B);
+      if (FULL && P[5] == 1) {
+        // condim 1 (explicit <pair>): one frictionless row = four identical "pyramid" rows with mu = 0 and D/4 each
+        cmu = 0.f;
+        cD = 0.25f / fmaxf(MINVALF, (1 - imp) / imp * F[3]);
+      } else {
+        float R0 = fmaxf(MINVALF, (1 - imp) / imp * F[3] * (1 + cmu * cmu));
+        cD = 1.0f / fmaxf(MINVALF, 2 * cmu * cmu * R0);
+      }
+      float pos = -K * imp * (dist - incl);
+      caref[0] = -B * (vn + cmu * vt1) + pos; caref[1] = -B * (vn - cmu * vt1) + pos;
+      caref[2] = -B * (vn + cmu * vt2) + pos; caref[3] = -B * (vn - cmu * vt2) + pos;
+    }
+    // efc row count as MuJoCo reports it: 4 pyramid rows per condim-3 contact, 1 per frictionless (condim-1) contact
+    int nefc = __popcll(__ballot(lsign != 0.f)) + 4 * ncon - 3 * __popcll(__ballot(lane < ncon && cmu == 0.f));
+    const int ncon_real = ncon;
+    if (W.has_tl) {
+      // an active tendon limit becomes a frictionless pseudo-contact: jacobian = +-(sparse tendon row), mu = 0 and D/4 on each
+      // of the four identical "pyramid" rows, which together act exactly like the single MuJoCo limit row
+      int nt = ncon;
+#pragma unroll
+      for (int rr = 0; rr < NTR; rr++) {
+      const int gt = lane + 64 * rr;
+      bool tact = false;
+      float t_aref = 0.f, t_D = 0.f, t_sign = 0.f;
+      if (gt < ngt_ && !M.disable_limit) {
+        const float* T = W.tl + 12 * gt;
+        if (T[0] != 0) {
+          float margin = T[3], dlo = tlen_r[rr] - T[1], dhi = T[2] - tlen_r[rr], dist = 0;
+          if (dlo < margin && dlo <= dhi) { t_sign = 1; dist = dlo; }
+          else if (dhi < margin) { t_sign = -1; dist = dhi; }
+          if (t_sign != 0) {
+            float imp = impedance(T + 6, dist, margin), K, B;
+            float R = fmaxf(MINVALF, (1 - imp) / imp * T[11]);
+            kbi(T[4], T[5], T[7], M.timestep, &K, &B);
+            t_aref = -B * (t_sign * tvel_r[rr]) - K * imp * (dist - margin);
+            t_D = 1.0f / R;
+            tact = true;
+          }
+        }
+      }
+      unsigned long long bal = __ballot(tact);
+      int slot = nt + __popcll(bal & ((1ull << lane) - 1ull));
+      if (tact && slot < NC) {
+        float* cJ = E + Y.cJ + slot * 3 * KC;
+        unsigned int dpk[CDW];
+#pragma unroll
+        for (int k = 0; k < CDW; k++) dpk[k] = 0;
+        int kc = 0;
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+          int d = k < maxnnz_ ? M.gt_dofs[gt * maxnnz_ + k] : -1;
+          float jv = d >= 0 ? t_sign * E[Y.tJp + gt * maxnnz_ + k] : 0.f;
+          if (d >= 0) kc = k + 1; else d = 0;
+          cJ[k] = jv; cJ[KC + k] = 0.f; cJ[2 * KC + k] = 0.f;
+          dpk[k >> 2] |= (unsigned int)d << (8 * (k & 3));
+        }
+#pragma unroll
+        for (int k = 0; k < CDW; k++) ((unsigned int*)(E + Y.cdofs))[CDW * slot + k] = dpk[k];
+        E[Y.cdist + slot] = t_aref; E[Y.cpos + 3 * slot] = t_D; E[Y.cpos + 3 * slot + 1] = (float)kc;
+      }
+      nt += __popcll(bal);
+      }
+      if (nt > NC) { flags |= MYO_FLAG_CONTACT_OVERFLOW; nt = NC; }
+      SYNC();
+      if (lane >= ncon && lane < nt) {
+        float a = E[Y.cdist + lane];
+        caref[0] = caref[1] = caref[2] = caref[3] = a;
+        cD = 0.25f * E[Y.cpos + 3 * lane]; cmu = 0.f; ckc = (int)E[Y.cpos + 3 * lane + 1];
+      }
+      nefc += nt - ncon;
+      ncon = nt;
+    }
+    // joint-coupling equalities q1 - q1_0 = poly(q2 - q2_0) (mj_instantiateEquality, mjEQ_JOINT): lane = equality, two
+    // jacobian entries (+1 at dof 1, -poly' at dof 2), always active (quadratic cost on both sides)
+    float eJ2 = 0.f, eD = 0.f, earef = 0.f, ejar = 0.f, ejv = 0.f;
+    int ed1 = 0, ed2 = 0;
+    const bool eact = lane < neq;
+    if (eact) {
+      const int* Q = W.eq_i + 4 * lane;
+      const float* F = W.eq_f + 16 * lane;
+      ed1 = Q[0]; ed2 = Q[1];
+      float x = E[Y.qpos + Q[3]] - F[6];
+      float pos = E[Y.qpos + Q[2]] - F[5] - (F[0] + x * (F[1] + x * (F[2] + x * (F[3] + x * F[4]))));
+      eJ2 = -(F[1] + x * (2 * F[2] + x * (3 * F[3] + x * 4 * F[4])));
+      float vel = E[Y.qvel + ed1] + eJ2 * E[Y.qvel + ed2];
+      float imp = impedance(F + 9, pos, 0.f), K, B;
+      kbi(F[7], F[8], F[10], M.timestep, &K, &B);
+      earef = -B * vel - K * imp * pos;
+      eD = 1.0f / fmaxf(MINVALF, (1 - imp) / imp * F[14]);
+    }
+    nefc += neq;
+    SYNC();
+    // the mass matrix moves from the square buffer (about to be reused for the Hessian) to a packed copy that
+    // aliases the now dead broad-phase scratch
+    if (lane < nv) {
+      const int based = (lane * (lane + 1)) / 2;
+#pragma unroll
+      for (int k = 0; k < NVT; k++) if (k <= lane) E[Y.Mp + based + k] = E[Y.sq + lane * (NVT + 1) + k];
+    }
+    const float* Mp = E + Y.Mp;
+    SYNC();
+    STAMP(5);
+    // ---------------------------------------------------------------- solver: Newton iterations, then the Euler solve, sharing ONE
+    // instance of the unrolled register Cholesky.  phase 0 = Newton, 1 = unconstrained (nefc == 0), 2 = Euler (implicit damping)
+    float Ma = 0.f, grad = 0.f, qfc = 0.f, ljar = 0.f, ljv = 0.f, cost = 0.f, qaccE = 0.f;
+    float cjar[4] = {0, 0, 0, 0}, cjv[4] = {0, 0, 0, 0};
+    int phase = nefc > 0 ? 0 : 1, iters = 0;
+    if (phase == 0) {  // start from the warm start (MuJoCo also tries qacc_smooth; the minimiser is the same)
+      qacc = warm;
+      Ma = symv_lds<NVT>(Mp, qacc, lane, nv);
+      ljar = lsign * qacc - laref;
+      if (lane < nv) E[Y.xv + lane] = qacc;
+      SYNC();
+      if (lane < ncon) {
+        const float* cJ = E + Y.cJ + lane * 3 * KC;
+        float an = 0, a1 = 0, a2 = 0;
+#pragma unroll
+        for (int k = 0; k < KC; k++) { float xv = E[Y.xv + CDOF(E, Y, lane, k)]; an += cJ[k] * xv; a1 += cJ[KC + k] * xv; a2 += cJ[2 * KC + k] * xv; }
+        cjar[0] = an + cmu * a1 - caref[0]; cjar[1] = an - cmu * a1 - caref[1]; cjar[2] = an + cmu * a2 - caref[2]; cjar[3] = an - cmu * a2 - caref[3];
+      }
+      if (eact) ejar = E[Y.xv + ed1] + eJ2 * E[Y.xv + ed2] - earef;
+    }
+    bool first = true;
+    int sig_prev = -1;
+    const int lane_s = lane;
+    while (true) {
+      int lane;   // opaque copy again: keeps the 24 per-lane symv addresses from being hoisted out of the loop and spilled
+      asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane_s));
+      float r[NVT], rhs, invd;
+      bool refactor = true;
+      if (phase == 0) {
+        // forces of the active rows, J^T f (LDS atomics), cost, gradient; convergence test; then, only if the iteration goes on and
+        // the active set differs from the one whose Hessian was factorised last, the Hessian blocks (LDS atomics)
+        bool lact = lsign != 0.f && ljar < 0;
+        float w0 = cjar[0] < 0 ? cD : 0.f, w1 = cjar[1] < 0 ? cD : 0.f, w2 = cjar[2] < 0 ? cD : 0.f, w3 = cjar[3] < 0 ? cD : 0.f;
+        float f0 = -w0 * cjar[0], f1 = -w1 * cjar[1], f2 = -w2 * cjar[2], f3 = -w3 * cjar[3];
+        if (lane < nv) E[Y.qfc + lane] = lact ? -lsign * lD * ljar : 0.f;
+        SYNC();
+        if (lane < ncon) {
+          const float* cJ = E + Y.cJ + lane * 3 * KC;
+          float Fn = f0 + f1 + f2 + f3, Ft1 = cmu * (f0 - f1), Ft2 = cmu * (f2 - f3);
+          for (int k = 0; k < ckc; k++) atomicAdd(&E[Y.qfc + CDOF(E, Y, lane, k)], Fn * cJ[k] + Ft1 * cJ[KC + k] + Ft2 * cJ[2 * KC + k]);
+        }
+        if (eact) { float f = -eD * ejar; atomicAdd(&E[Y.qfc + ed1], f); atomicAdd(&E[Y.qfc + ed2], eJ2 * f); }
+        SYNC();
+        qfc = lane < nv ? E[Y.qfc + lane] : 0.f;
+        float cst = lact ? 0.5f * lD * ljar * ljar : 0.f;
+        cst += 0.5f * eD * ejar * ejar;
+        cst += 0.5f * (w0 * cjar[0] * cjar[0] + w1 * cjar[1] * cjar[1] + w2 * cjar[2] * cjar[2] + w3 * cjar[3] * cjar[3]);
+        cst += 0.5f * qacc * Ma - qacc * smooth;          // Gauss term up to a constant
+        float newcost = wave_sum(cst);
+        grad = Ma - smooth - qfc;
+        if (!first) {
+          float improvement = scale * (cost - newcost);
+          float gn = scale * sqrtf(wave_sum(grad * grad));
+          iters++;
+          f_itcon += ncon;
+          if (improvement < fmaxf(M.tolerance, 1e-6f * scale * fabsf(newcost)) || gn < M.tolerance || iters >= M.iterations) phase = 2;
+        }
+        cost = newcost;
+        if (phase == 0) {
+          // H = M + J^T D J depends on the state only through the set of active rows: same set as last time -> same factor
+          const int sig = (lact ? 1 : 0) | (w0 != 0.f ? 2 : 0) | (w1 != 0.f ? 4 : 0) | (w2 != 0.f ? 8 : 0) | (w3 != 0.f ? 16 : 0);
+          refactor = first || __any(sig != sig_prev);
+          sig_prev = sig;
+          if (refactor) {
+            f_fact++;
+            WFOR(i, NVT * (NVT + 1)) E[Y.sq + i] = 0;
+            SYNC();
+            if (lane < nv && lact) E[Y.sq + lane * (NVT + 1) + lane] = lD;
+            float Wn = w0 + w1 + w2 + w3, A1 = cmu * (w0 - w1), A2 = cmu * (w2 - w3), B1 = cmu * cmu * (w0 + w1), B2 = cmu * cmu * (w2 + w3);
+            SYNC();
+            for (int c = 0; c < ncon; c++) {   // one contact per step, lanes = entries of its kc x kc block
+              int kc = rdlanei(ckc, c);
+              float sW = rdlane(Wn, c), sA1 = rdlane(A1, c), sA2 = rdlane(A2, c), sB1 = rdlane(B1, c), sB2 = rdlane(B2, c);
+              if (sW == 0.f) continue;
+              for (int t = lane; t < kc * kc; t += 64) {
+                int a = t / kc, b = t - a * kc;
+                const float* cJ = E + Y.cJ + c * 3 * KC;
+                int da = CDOF(E, Y, c, a), db = CDOF(E, Y, c, b);
+                if (da >= db) {
+                  float na = cJ[a], nb = cJ[b], ta = cJ[KC + a], tb = cJ[KC + b], ua = cJ[2 * KC + a], ub = cJ[2 * KC + b];
+                  atomicAdd(&E[Y.sq + da * (NVT + 1) + db], sW * na * nb + sA1 * (na * tb + ta * nb) + sA2 * (na * ub + ua * nb) + sB1 * ta * tb + sB2 * ua * ub);
+                }
+              }
+            }
+            if (eact) {
+              atomicAdd(&E[Y.sq + ed1 * (NVT + 1) + ed1], eD);
+              atomicAdd(&E[Y.sq + ed2 * (NVT + 1) + ed2], eD * eJ2 * eJ2);
+              atomicAdd(&E[Y.sq + max(ed1, ed2) * (NVT + 1) + min(ed1, ed2)], eD * eJ2);
+            }
+            SYNC();
+          }
+        }
+        first = false;
+      }
+      rhs = phase == 0 ? -grad : (phase == 1 ? smooth : smooth + qfc);
+      if (refactor) {
+        const int dd = lane < nv ? lane : 0;
+        const int based = (dd * (dd + 1)) / 2;
+        const float diag_add = phase == 2 ? h * damping : 0.f;
+#pragma unroll
+        for (int k = 0; k < NVT; k++) {
+          float mv = (lane < nv && k <= lane) ? Mp[based + (k <= dd ? k : 0)] : 0.f;                 // lower row of M
+          float hv = (phase == 0 && lane < nv) ? E[Y.sq + lane * (NVT + 1) + k] : 0.f;              // J^T D J (active rows)
+          r[k] = (lane < nv) ? mv + hv + (k == lane ? diag_add : 0.f) : (k == lane ? 1.f : 0.f);
+        }
+        SYNC();
+        invd = chol_rows<NVT>(r, lane);
+        if (lane < NVT) {
+#pragma unroll
+          for (int k = 0; k < NVT; k++) E[Y.sq + lane * (NVT + 1) + k] = r[k];
+        }
+        SYNC();
+      } else {
+        // the factor of the previous iteration is still in LDS (row-major L): reload this lane's row
+        const int ll = lane < NVT ? lane : 0;
+#pragma unroll
+        for (int k = 0; k < NVT; k++) r[k] = E[Y.sq + ll * (NVT + 1) + k];
+        invd = 1.0f / E[Y.sq + ll * (NVT + 1) + ll];
+      }
+      float x = chol_solve_rows<NVT>(r, invd, rhs, E + Y.sq, lane);
+      if (phase == 1) { qacc = x; qfc = 0.f; phase = 2; continue; }
+      if (phase == 2) { qaccE = x; break; }
+      // ---- Newton: exact line search along x
+      float search = lane < nv ? x : 0.f;
+      float Mv = symv_lds<NVT>(Mp, search, lane, nv);
+      ljv = lsign * search;
+      if (lane < nv) E[Y.xv + lane] = search;
+      SYNC();
+      if (lane < ncon) {
+        const float* cJ = E + Y.cJ + lane * 3 * KC;
+        float an = 0, a1 = 0, a2 = 0;
+#pragma unroll
+        for (int k = 0; k < KC; k++) { float xv = E[Y.xv + CDOF(E, Y, lane, k)]; an += cJ[k] * xv; a1 += cJ[KC + k] * xv; a2 += cJ[2 * KC + k] * xv; }
+        cjv[0] = an + cmu * a1; cjv[1] = an - cmu * a1; cjv[2] = an + cmu * a2; cjv[3] = an - cmu * a2;
+      }
+      if (eact) ejv = E[Y.xv + ed1] + eJ2 * E[Y.xv + ed2];
+      float g1 = wave_sum(search * (Ma - smooth)), g2 = wave_sum(0.5f * search * Mv), sn = sqrtf(wave_sum(search * search));
+      float alpha = 0, lo = 0, hi = -1, dlo = 0, d2lo = 0, dhi = 0, d2hi = 0, d1init = 0;
+      bool ls_on = sn >= MINVALF;
+      for (int lsit = -1; lsit < M.ls_iterations && ls_on; lsit++) {
+        float a = (lsit < 0) ? 0.f : alpha;
+        float p1 = 0, p2 = 0;
+        if (lsign != 0.f) { float xx = ljar + a * ljv; if (xx < 0) { p1 += lD * xx * ljv; p2 += lD * ljv * ljv; } }
+        p1 += eD * (ejar + a * ejv) * ejv; p2 += eD * ejv * ejv;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { float xx = cjar[k] + a * cjv[k]; if (xx < 0) { p1 += cD * xx * cjv[k]; p2 += cD * cjv[k] * cjv[k]; } }
+        float d1 = wave_sum(p1) + g1 + 2 * a * g2;
+        float d2 = wave_sum(p2) + 2 * g2;
+        if (lsit < 0) {
+          if (d1 >= 0 || d2 <= 0) { ls_on = false; alpha = 0; break; }
+          dlo = d1; d2lo = d2; d1init = fabsf(d1);
+          alpha = -d1 / d2;
+          continue;
+        }
+        f_ls++;
+        float gtol = fmaxf(M.tolerance * M.ls_tolerance * sn / scale, LS_FLOOR * d1init);
+        if (fabsf(d1) < gtol) break;
+        if (d1 < 0) { lo = alpha; dlo = d1; d2lo = d2; } else { hi = alpha; dhi = d1; d2hi = d2; }
+        float cand = alpha - d1 / d2;
+        if (hi < 0) {
+          if (!(cand > lo)) break;
+          alpha = cand;
+        } else {
+          if (!(cand > lo && cand < hi)) {
+            float c2 = d1 < 0 ? hi - dhi / d2hi : lo - dlo / d2lo;
+            cand = (c2 > lo && c2 < hi) ? c2 : 0.5f * (lo + hi);
+          }
+          if (cand == alpha || hi - lo <= 1e-7f * hi) break;
+          alpha = cand;
+        }
+      }
+      if (!(alpha > 0)) { phase = 2; continue; }   // no descent left: keep qacc / qfc of this iterate
+      qacc += alpha * search; Ma += alpha * Mv; ljar += alpha * ljv; ejar += alpha * ejv;
+#pragma unroll
+      for (int k = 0; k < 4; k++) cjar[k] += alpha * cjv[k];
+    }
+    STAMP(7);
+    d_nefc = nefc; d_ncon = ncon_real; d_iter = max(d_iter, iters);
+    f_ncon += ncon; f_iter += iters;
+    {  // mj_checkAcc
+      bool bad = lane < nv && (!(qacc == qacc) || fabsf(qacc) > MAXVALF);
+      if (__any(bad) && alive) { flags |= MYO_FLAG_BAD_QACC; alive = false; }
+    }
+    warm = qacc;
+    if (alive) {
+#pragma unroll
+      for (int rr = 0; rr < NTR; rr++) if (lane + 64 * rr < nu) E[Y.act + lane + 64 * rr] += h * actdot[rr];
+      if (lane < nv) {
+        float v = E[Y.qvel + lane] + h * qaccE;
+        E[Y.qvel + lane] = v;
+        if (!(has_free && lane >= 3 && lane < 6)) E[Y.qpos + W.dof_qposadr[lane]] += h * v;
+      }
+      if (has_free) {   // root free joint: quaternion integrated with the body-frame angular velocity (mju_quatIntegrate)
+        SYNC();
+        if (lane == 3) {
+          float w[3] = {E[Y.qvel + 3], E[Y.qvel + 4], E[Y.qvel + 5]};
+          float wn = norm3(w), ang = h * wn;
+          float q[4] = {E[Y.qpos + 3], E[Y.qpos + 4], E[Y.qpos + 5], E[Y.qpos + 6]};
+          if (wn >= MINVALF) {
+            float sn, cs;
+            sincosf(0.5f * ang, &sn, &cs);
+            float inv = sn / wn, r[4] = {cs, w[0] * inv, w[1] * inv, w[2] * inv}, o[4];
+            o[0] = q[0] * r[0] - q[1] * r[1] - q[2] * r[2] - q[3] * r[3];
+            o[1] = q[0] * r[1] + q[1] * r[0] + q[2] * r[3] - q[3] * r[2];
+            o[2] = q[0] * r[2] - q[1] * r[3] + q[2] * r[0] + q[3] * r[1];
+            o[3] = q[0] * r[3] + q[1] * r[2] - q[2] * r[1] + q[3] * r[0];
+            float on = 1.0f / sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+            E[Y.qpos + 3] = o[0] * on; E[Y.qpos + 4] = o[1] * on; E[Y.qpos + 5] = o[2] * on; E[Y.qpos + 6] = o[3] * on;
+          }
+        }
+      }
+      time += h;
+    }
+    SYNC();
+    STAMP(8);
+  }
+  if (!SCHED && FULL && (kflags & KF_AUX)) return;   // observation-only launch: the state arrays are not touched
+  if (!alive) {  // a bad env is reset like mj_resetData (mj_sim_scene.py:56-61)
+    if (lane_id < nq) E[Y.qpos + lane_id] = M.qpos0[lane_id];
+    if (lane_id < nv) { E[Y.qvel + lane_id] = 0; warm = 0; }
+    for (int i = lane_id; i < nu; i += 64) { E[Y.act + i] = 0; E[Y.ctrl + i] = 0; }
+    time = 0;
+  }
+  if (lane_id < nq) Bt.qpos[(size_t)env * nq + lane_id] = E[Y.qpos + lane_id];
+  if (lane_id < nv) {
+    Bt.qvel[(size_t)env * nv + lane_id] = E[Y.qvel + lane_id];
+    Bt.warm[(size_t)env * nv + lane_id] = warm;
+    Bt.qacc[(size_t)env * nv + lane_id] = qacc;
+  }
+  for (int i = lane_id; i < nu; i += 64) {
+    Bt.act[(size_t)env * nu + i] = E[Y.act + i];
+    Bt.ctrl[(size_t)env * nu + i] = E[Y.ctrl + i];
+  }
+  if (lane_id == 0) {
+    Bt.time[env] = time;
+    if (s1 == nsubtot) Bt.elapsed[env] += 1;
+    if (SCHED) { if (flags) atomicOr(&Bt.flags[env], flags); } else Bt.flags[env] |= flags;
+    Bt.diag[(size_t)env * 8 + 0] = d_nefc; Bt.diag[(size_t)env * 8 + 1] = d_ncon; Bt.diag[(size_t)env * 8 + 2] = d_iter;
+    // predicted work of this env's NEXT step for the placement hint, in units of 1024 single-wave cycles: linear model of this
+    // step's work features and the last substep's contact / row counts, fitted on one-wave-per-SIMD runs where a wave's duration is
+    // its own work (tools/gpu_cost_fit2.py; correlation with the next step's measured duration 0.92 hand / 0.90 legs)
+    d_cost = FULL ? 1909 + ((7436 * f_cand - 28892 * f_ncon + 1362 * f_mpr + 25014 * f_iter + 2046 * f_itcon - 1413 * f_ls + 13292 * d_nefc + 343707 * d_ncon) >> 10)
+                  : 2236 + ((-141 * f_cand - 3413 * f_ncon + 2188 * f_mpr + 8971 * f_iter - 107 * f_itcon - 122 * f_ls - 518 * d_nefc + 74475 * d_ncon) >> 10);
+    d_cost = max(d_cost, 1);
+    Bt.diag[(size_t)env * 8 + 3] = d_cost;
+    Bt.diag[(size_t)env * 8 + 4] = f_cand | (f_ncon << 16); Bt.diag[(size_t)env * 8 + 5] = f_mpr;
+    Bt.diag[(size_t)env * 8 + 6] = f_itcon | (f_iter << 16); Bt.diag[(size_t)env * 8 + 7] = f_ls | (f_fact << 16);
+  }
+  last_cost = d_cost;
+  STAMP(9);
+  if (!SCHED) break;
+  // publish this env's next substep: the state rows written above must have reached L2 before the ring entry becomes visible
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  if (s1 < nsubtot && lane_id == 0) {
+    const int tt = atomicAdd(&sq_ctl[1], 1);
+    const int g2 = tt / sq_n, sl = tt - g2 * sq_n;
+    __hip_atomic_store(&sq_ring[sl], (g2 << 24) | (s1 << 20) | env, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  SYNC();   // the next task reuses this wave's LDS slice
+  }  // task loop
+#if MYO_STAMPS
+  st_acc[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID: wave/simd/cu/sh/se ids (placement census)
+  st_acc[11] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFF) | ((long long)(oe >> 28) << 8) | ((long long)last_cost << 16);   // HW_REG_XCC_ID, issue priority, cost estimate
+  if (stamps && lane_id == 0) for (int k = 0; k < 12; k++) stamps[(size_t)blockIdx.x * 12 + k] = st_acc[k];
+#endif
+}
+
+#endif  // MYO_KERNEL_WAVE_H

@@ -1,0 +1,224 @@
+// myo_kernels_aux.h -- small kernels: RNG, placement hint, random actions, policy inference, reset, observations.
+// Part of the single translation unit myo_hip.hip (included there, in this order); not a stand-alone header.
+#ifndef MYO_KERNELS_AUX_H
+#define MYO_KERNELS_AUX_H
+
+// ------------------------------------------------------------------------------------------------
+// counter-based RNG (splitmix64 of (seed, stream, counter)) -> U[0,1)
+__device__ __host__ inline float u01(uint64_t seed, uint64_t a, uint64_t b) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (a + 1) + 0xBF58476D1CE4E5B9ull * (b + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// Placement hint for the wave-per-env kernel.  All B envs are co-resident (4 waves per SIMD), so a launch ends when the
+// slowest SIMD ends; envs differ ~2x in work (contacts, Newton iterations) and that work is strongly correlated from one
+// env step to the next.  Sort envs by last step's cost (counting sort, one workgroup) and deal them out so that the waves
+// that land on one SIMD come from different cost quartiles (snake order over `nslot` = B/4 slots).  Dispatch order is not
+// a contract: this only ever changes speed.
+__global__ void __launch_bounds__(1024) balance_kernel(const int* __restrict__ diag, int B, int* __restrict__ order, int nslot, int prio_mode) {
+  __shared__ int hist[256], start[256];
+  __shared__ int cmax_s;
+  const int t = threadIdx.x;
+  if (t < 256) hist[t] = 0;
+  if (t == 0) cmax_s = 1;
+  __syncthreads();
+  int cm = 1;
+  for (int e = t; e < B; e += 1024) cm = max(cm, diag[(size_t)e * 8 + 3]);
+  atomicMax(&cmax_s, cm);
+  __syncthreads();
+  const int cmax = cmax_s;
+  for (int e = t; e < B; e += 1024) atomicAdd(&hist[255 - min(255, (int)(255LL * diag[(size_t)e * 8 + 3] / cmax))], 1);   // bucket 0 = heaviest
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int k = 0; k < 256; k++) { start[k] = acc; acc += hist[k]; } }
+  __syncthreads();
+  for (int e = t; e < B; e += 1024) {
+    int b = 255 - min(255, (int)(255LL * diag[(size_t)e * 8 + 3] / cmax));
+    int r = atomicAdd(&start[b], 1);                       // rank by descending cost (ties in arbitrary order)
+    int q = r / nslot, i = r - q * nslot;
+    int wg = q * nslot + ((q & 1) ? nslot - 1 - i : i);    // snake: slot i gets ranks i, 2*nslot-1-i, 2*nslot+i, ...
+    int pr = prio_mode == 2 ? (q < 3 ? 3 - q : 0) : (prio_mode == 1 ? (q == 0 ? 1 : 0) : (prio_mode == 3 ? (q < 2 ? 1 : 0) : 0));
+    order[wg < B ? wg : r] = e | (pr << 28);   // env id + issue priority of its cost quartile
+  }
+}
+
+__global__ void random_action_kernel(float* action, int B, int nu, uint64_t seed, uint64_t step, int env_offset) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * nu) return;
+  size_t e = i / nu, k = i % nu;
+  action[i] = 2.0f * u01(seed, (uint64_t)(e + env_offset) * 1024 + k, step) - 1.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// policy inference (brax PPO network family): 8 envs per 256-thread workgroup, thread = (env, hidden unit); activations ping-pong
+// through LDS, weights are read coalesced across units and shared by the 8 envs through the cache.  ~13 kMAC per env for
+// the hand observation: negligible next to the physics step, so plain FMAs (no MFMA)
+#define POL_ENVS 8
+#define POL_MAXW 64
+struct PolicyDev {
+  int obs_dim, act_dim, nlayers;
+  int width[8];               // output width of each layer
+  const float* W[8];
+  const float* b[8];
+  const float *mean, *std;
+};
+__global__ void __launch_bounds__(POL_ENVS * POL_MAXW) policy_kernel(PolicyDev P, const float* __restrict__ obs, int B, float* __restrict__ action,
+                                                                     int deterministic, uint64_t seed, uint64_t step, int env_offset) {
+  extern __shared__ float sh[];                       // [POL_ENVS][max(obs_dim, POL_MAXW)] x 2
+  const int j = threadIdx.x % POL_MAXW, le = threadIdx.x / POL_MAXW;
+  const int e = blockIdx.x * POL_ENVS + le;
+  int stride = max(P.obs_dim, POL_MAXW);
+  for (int l = 0; l < P.nlayers; l++) stride = max(stride, P.width[l]);
+  float* xin = sh + le * stride;
+  float* xout = sh + (POL_ENVS + le) * stride;
+  if (e < B)
+    for (int i = j; i < P.obs_dim; i += POL_MAXW) xin[i] = (obs[(size_t)e * P.obs_dim + i] - P.mean[i]) / P.std[i];
+  __syncthreads();
+  int nin = P.obs_dim;
+  for (int l = 0; l < P.nlayers; l++) {
+    const int nout = P.width[l];
+    if (e < B) {
+      const float* Wl = P.W[l];
+      for (int jj = j; jj < nout; jj += POL_MAXW) {
+        float acc = P.b[l][jj];
+        for (int i = 0; i < nin; i++) acc += xin[i] * Wl[(size_t)i * nout + jj];
+        xout[jj] = (l + 1 < P.nlayers) ? acc / (1.0f + expf(-acc)) : acc;     // swish on hidden layers, linear head
+      }
+    }
+    __syncthreads();
+    float* t = xin; xin = xout; xout = t;
+    nin = nout;
+  }
+  if (e < B) {
+    for (int jj = j; jj < P.act_dim; jj += POL_MAXW) {
+      float loc = xin[jj], a = loc;
+      if (!deterministic) {
+        float raw = xin[P.act_dim + jj];
+        float scale = (raw > 20.f ? raw : log1pf(expf(raw))) + 0.001f;
+        uint64_t ge = (uint64_t)(e + env_offset);
+        float u1 = fmaxf(u01(seed ^ 0x5851F42D4C957F2Dull, ge * 1024 + jj, step), 1e-7f), u2 = u01(seed ^ 0x14057B7EF767814Full, ge * 1024 + jj, step);
+        a = loc + scale * sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);   // Box-Muller
+      }
+      action[(size_t)e * P.act_dim + jj] = tanhf(a);
+    }
+  }
+}
+
+// auto_max > 0: gym TimeLimit / done auto-reset (reset iff done or elapsed >= auto_max); else mask-driven reset.
+// One 64-lane workgroup per env: envs that are not reset leave after one test, the others write their rows coalesced
+// (one thread per env needed ~500 serialised scattered stores per reset: 27 ms for a full reset of 4096 leg envs)
+__global__ void __launch_bounds__(64) reset_kernel(DevBatch Bt, TaskDev T, int nq, int nv, int nu, const float* qpos0, const uint8_t* mask, uint64_t seed,
+                                                  int env_offset, int auto_max) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= Bt.B) return;
+  if (auto_max > 0) { if (!(Bt.done[e] > 0.f || Bt.elapsed[e] >= auto_max)) return; }
+  else if (mask && !mask[e]) return;
+  seed += 0x632BE59BD9B4E019ull * (uint64_t)Bt.episode[e];  // a fresh RNG stream per (env, episode)
+  __syncthreads();                                            // every lane has read done / elapsed / episode before lane 0 updates them
+  if (lane == 0) { Bt.episode[e] += 1; Bt.elapsed[e] = 0; Bt.done[e] = 0.f; Bt.time[e] = 0; }
+  uint64_t ge = (uint64_t)(e + env_offset);
+  for (int i = lane; i < nq; i += 64) {
+    float q = T.init_qpos ? T.init_qpos[i] : qpos0[i];
+    if (T.reset_random) q = T.jnt_lo[i] + (T.jnt_hi[i] - T.jnt_lo[i]) * u01(seed, ge * 4096 + i, 1);   // nq == nv checked at configure
+    Bt.qpos[(size_t)e * nq + i] = q;
+  }
+  for (int i = lane; i < nv; i += 64) {
+    Bt.qvel[(size_t)e * nv + i] = T.init_qvel ? T.init_qvel[i] : 0.f;
+    Bt.warm[(size_t)e * nv + i] = 0;
+  }
+  for (int i = lane; i < nu; i += 64) {
+    Bt.act[(size_t)e * nu + i] = 0; Bt.ctrl[(size_t)e * nu + i] = 0;
+    // fatigue compartments: all motor units resting (CumulativeFatigue.reset defaults, fatigue.py:130-134)
+    Bt.fatigue[(size_t)e * 3 * nu + i] = 0.f; Bt.fatigue[(size_t)e * 3 * nu + nu + i] = 1.f; Bt.fatigue[(size_t)e * 3 * nu + 2 * nu + i] = 0.f;
+  }
+  for (int i = lane; i < T.ntarget; i += 64) {
+    float lo = T.target_lo[i], hi = T.target_hi[i];
+    Bt.target[(size_t)e * T.ntarget + i] = T.target_generate ? lo + (hi - lo) * u01(seed, ge * 4096 + 2048 + i, 2) : lo;
+  }
+}
+
+// observation + reward (pose_v0.py:98-138, obs_vec_dict.py:86-98); one 64-lane workgroup per env, rows written coalesced
+__global__ void __launch_bounds__(64) obs_kernel(DevModel M, DevBatch Bt, TaskDev T, int obs_only, int reset_only) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= Bt.B) return;
+  if (reset_only && Bt.elapsed[e] != 0) return;    // refresh only the rows of envs an auto-reset just touched
+  const int nv = M.nv, nu = M.nu;
+  float dt = (float)T.frame_skip * M.timestep;
+  float* o = Bt.obs + (size_t)e * T.obs_dim;
+  const float* q = Bt.qpos + (size_t)e * nv;
+  const float* v = Bt.qvel + (size_t)e * nv;
+  const float* a = Bt.act + (size_t)e * nu;
+  if (T.task == MYO_TASK_POSE) {
+    float err2 = 0, act2 = 0;
+    for (int i = lane; i < nv; i += 64) {
+      float qi = q[i], pe = Bt.target[(size_t)e * T.ntarget + i] - qi;
+      o[i] = qi; o[nv + i] = v[i] * dt; o[2 * nv + i] = pe;
+      err2 += pe * pe;
+    }
+    for (int i = lane; i < nu; i += 64) { float ai = a[i]; o[3 * nv + i] = ai; act2 += ai * ai; }
+    if (obs_only) return;
+    float dist = sqrtf(wave_sum(err2));
+    float actn = sqrtf(wave_sum(act2)) / (float)(nu > 0 ? nu : 1);
+    if (lane == 0) {
+      float bonus = (dist < T.pose_thd ? 1.f : 0.f) + (dist < 1.5f * T.pose_thd ? 1.f : 0.f);
+      float pen = dist > T.far_th ? -1.f : 0.f;
+      Bt.reward[e] = T.w_pose * (-dist) + T.w_bonus * bonus + T.w_act_reg * (-actn) + T.w_penalty * pen;
+      Bt.solved[e] = dist < T.pose_thd ? 1.f : 0.f;
+      Bt.done[e] = dist > T.far_th ? 1.f : 0.f;
+    }
+  }
+}
+
+// reach task needs tip positions: per-env group kernel reusing the kinematics stage
+template <int G>
+__global__ void __launch_bounds__(64) reach_obs_kernel(DevModel M, DevBatch Bt, TaskDev T, int obs_only) {
+  extern __shared__ __align__(16) float smem[];
+  const Lay& Y = M.lay;
+  const int lane = threadIdx.x, grp = lane / G, sub = lane % G;
+  int env = blockIdx.x * (64 / G) + grp;
+  const bool valid = env < Bt.B;
+  if (!valid) env = Bt.B - 1;
+  float* E = smem + grp * Y.total;
+  const int nv = M.nv, nu = M.nu;
+  GFOR(i, nv) E[Y.qpos + i] = Bt.qpos[(size_t)env * nv + i];
+  SYNC();
+  stage_kinematics<G>(M, E, sub);
+  float dt = (float)T.frame_skip * M.timestep;
+  float* o = Bt.obs + (size_t)env * T.obs_dim;
+  float err2 = 0;
+  GFOR(i, T.ntip) {
+    float p[3];
+    site_world(M, E, T.tip_site[i], p);
+    for (int k = 0; k < 3; k++) {
+      p[k] += M.origin[k];  // kernels work relative to the lowered origin; observations are world coordinates
+      float tg = Bt.target[(size_t)env * T.ntarget + 3 * i + k];
+      float re = tg - p[k];
+      err2 += re * re;
+      if (valid) {
+        o[2 * nv + 3 * i + k] = p[k];
+        o[2 * nv + 3 * T.ntip + 3 * i + k] = re;
+        Bt.sitexpos[(size_t)env * 3 * T.ntip + 3 * i + k] = p[k];
+      }
+    }
+  }
+  err2 = grp_sum<G>(err2);
+  float actn = 0;
+  GFOR(i, nu) { float a = Bt.act[(size_t)env * nu + i]; actn += a * a; if (valid) o[2 * nv + 6 * T.ntip + i] = a; }
+  actn = sqrtf(grp_sum<G>(actn)) / (float)(nu > 0 ? nu : 1);
+  if (valid) {
+    GFOR(i, nv) { o[i] = E[Y.qpos + i]; o[nv + i] = Bt.qvel[(size_t)env * nv + i] * dt; }
+    if (sub == 0 && !obs_only) {
+      float dist = sqrtf(err2);
+      float near_th = T.near_th, far_th = Bt.time[env] > 2 * dt ? T.far_th : 1e30f;
+      float bonus = (dist < 2 * near_th ? 1.f : 0.f) + (dist < near_th ? 1.f : 0.f);
+      float pen = dist > far_th ? -1.f : 0.f;
+      Bt.reward[env] = T.w_reach * (-dist) + T.w_bonus * bonus + T.w_act_reg * (-actn) + T.w_penalty * pen;
+      Bt.solved[env] = dist < near_th ? 1.f : 0.f;
+      Bt.done[env] = dist > far_th ? 1.f : 0.f;
+    }
+  }
+}
+
+#endif  // MYO_KERNELS_AUX_H

@@ -1,0 +1,408 @@
+// myo_physics.h -- model pieces shared by both step kernels: tendon wrapping, muscle model, action map, impedance, frames, MPR.
+// Part of the single translation unit myo_hip.hip (included there, in this order); not a stand-alone header.
+#ifndef MYO_PHYSICS_H
+#define MYO_PHYSICS_H
+
+// ------------------------------------------------------------------------------------------------
+// tendon wrapping (2-D circle wrap, inside wrap, sphere / cylinder lifting) -- float twin of the oracle
+__device__ __forceinline__ bool is_intersect(const float* p1, const float* p2, const float* p3, const float* p4) {
+  float det = (p4[1] - p3[1]) * (p2[0] - p1[0]) - (p4[0] - p3[0]) * (p2[1] - p1[1]);
+  if (fabsf(det) < MINVALF) return false;
+  float a = ((p4[0] - p3[0]) * (p1[1] - p3[1]) - (p4[1] - p3[1]) * (p1[0] - p3[0])) / det;
+  float b = ((p2[0] - p1[0]) * (p1[1] - p3[1]) - (p2[1] - p1[1]) * (p1[0] - p3[0])) / det;
+  return a >= 0 && a <= 1 && b >= 0 && b <= 1;
+}
+
+__device__ float wrap_circle(float* pnt, const float* d, const float* sd, bool has_side, float rad) {
+  float sq0 = d[0] * d[0] + d[1] * d[1], sq1 = d[2] * d[2] + d[3] * d[3], sqr = rad * rad;
+  if (sq0 < sqr || sq1 < sqr || rad < MINVALF) return -1;
+  float dif[2] = {d[2] - d[0], d[3] - d[1]};
+  float dd = dif[0] * dif[0] + dif[1] * dif[1];
+  if (dd < MINVALF) return -1;
+  float a = clipf(-(dif[0] * d[0] + dif[1] * d[1]) / dd, 0.f, 1.f);
+  float tmp[2] = {a * dif[0] + d[0], a * dif[1] + d[1]};
+  if (tmp[0] * tmp[0] + tmp[1] * tmp[1] > sqr && (!has_side || sd[0] * tmp[0] + sd[1] * tmp[1] >= 0)) return -1;
+  float s0 = sqrtf(sq0 - sqr), s1 = sqrtf(sq1 - sqr);
+  float sol[2][4], good[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    float sgn = i == 0 ? 1.f : -1.f;
+    sol[i][0] = (d[0] * sqr + sgn * rad * d[1] * s0) / sq0;
+    sol[i][1] = (d[1] * sqr - sgn * rad * d[0] * s0) / sq0;
+    sol[i][2] = (d[2] * sqr - sgn * rad * d[3] * s1) / sq1;
+    sol[i][3] = (d[3] * sqr + sgn * rad * d[2] * s1) / sq1;
+    if (has_side) {
+      float t0 = sol[i][0] + sol[i][2], t1 = sol[i][1] + sol[i][3];
+      float n = sqrtf(t0 * t0 + t1 * t1);
+      if (n > MINVALF) { t0 /= n; t1 /= n; }
+      good[i] = t0 * sd[0] + t1 * sd[1];
+    } else {
+      float t0 = sol[i][0] - sol[i][2], t1 = sol[i][1] - sol[i][3];
+      good[i] = -(t0 * t0 + t1 * t1);
+    }
+    // a grazing solution (tangent points closer than 1e-3 rad) makes the segment-intersection test
+    // meaningless in float; skip it there (changes the length by O(r*1e-9), see DESIGN.md "float safeguards")
+    float gz0 = sol[i][0] - sol[i][2], gz1 = sol[i][1] - sol[i][3];
+    bool grazing = gz0 * gz0 + gz1 * gz1 < 1e-6f * sqr;
+    if (!grazing && is_intersect(d, sol[i], d + 2, sol[i] + 2)) good[i] = -10000.f;
+  }
+  int i = good[0] > good[1] ? 0 : 1;
+#pragma unroll
+  for (int k = 0; k < 4; k++) pnt[k] = i == 0 ? sol[0][k] : sol[1][k];
+  bool grazing = (pnt[0] - pnt[2]) * (pnt[0] - pnt[2]) + (pnt[1] - pnt[3]) * (pnt[1] - pnt[3]) < 1e-6f * sqr;
+  if (!grazing && is_intersect(d, pnt, d + 2, pnt + 2)) return -1;
+  return rad * acosf(clipf((pnt[0] * pnt[2] + pnt[1] * pnt[3]) / sqr, -1.f, 1.f));
+}
+
+__device__ float wrap_inside(float* pnt, const float* d, float rad) {
+  const float zinit = 1.f - 1e-7f, tolerance = 1e-6f;
+  float len0 = sqrtf(d[0] * d[0] + d[1] * d[1]), len1 = sqrtf(d[2] * d[2] + d[3] * d[3]);
+  float dif[2] = {d[2] - d[0], d[3] - d[1]};
+  float dd = dif[0] * dif[0] + dif[1] * dif[1];
+  if (len0 <= rad || len1 <= rad || rad < MINVALF || len0 < MINVALF || len1 < MINVALF) return -1;
+  if (dd > MINVALF) {
+    float a = -(dif[0] * d[0] + dif[1] * d[1]) / dd;
+    if (a > 0 && a < 1) {
+      float t0 = a * dif[0] + d[0], t1 = a * dif[1] + d[1];
+      if (sqrtf(t0 * t0 + t1 * t1) <= rad) return -1;
+    }
+  }
+  pnt[0] = 0.5f * (d[0] + d[2]); pnt[1] = 0.5f * (d[1] + d[3]);
+  float n = sqrtf(pnt[0] * pnt[0] + pnt[1] * pnt[1]);
+  if (n > MINVALF) { pnt[0] *= rad / n; pnt[1] *= rad / n; }
+  pnt[2] = pnt[0]; pnt[3] = pnt[1];
+  float A = rad / len0, B = rad / len1;
+  float cosG = (len0 * len0 + len1 * len1 - dd) / (2 * len0 * len1);
+  if (cosG < -1 + MINVALF) return -1;
+  if (cosG > 1 - MINVALF) return 0;
+  float Gang = acosf(cosG);
+  // Newton on theta = asin(z): same root as MuJoCo's iteration in z, but well conditioned in float near z -> 1
+  (void)zinit;
+  float th = 1.57079632679f - 4.4721360e-4f;
+  float sn = sinf(th), f = asinf(A * sn) + asinf(B * sn) - 2 * th + Gang;
+  if (f > 0) return 0;
+  for (int iter = 0; iter < 20 && fabsf(f) > tolerance; iter++) {
+    float cs = cosf(th);
+    float df = A * cs / fmaxf(MINVALF, sqrtf(1 - A * A * sn * sn)) + B * cs / fmaxf(MINVALF, sqrtf(1 - B * B * sn * sn)) - 2;
+    th = clipf(th - f / df, 1e-6f, 1.57079632679f);
+    sn = sinf(th);
+    f = asinf(A * sn) + asinf(B * sn) - 2 * th + Gang;
+  }
+  float vec[2], ang;
+  if (d[0] * d[3] - d[1] * d[2] > 0) { vec[0] = d[0] / len0; vec[1] = d[1] / len0; ang = th - asinf(A * sn); }
+  else { vec[0] = d[2] / len1; vec[1] = d[3] / len1; ang = th - asinf(B * sn); }
+  float sa, ca;
+  sincosf(ang, &sa, &ca);
+  pnt[0] = rad * (ca * vec[0] - sa * vec[1]);
+  pnt[1] = rad * (sa * vec[0] + ca * vec[1]);
+  pnt[2] = pnt[0]; pnt[3] = pnt[1];
+  return 0;
+}
+
+// returns wrap length (<0: no wrap); wpnt = two world points
+__device__ float wrap_geom(float* wpnt, const float* x0, const float* x1, const float* xpos, const float* xmat, float radius,
+                           bool cylinder, const float* side, bool has_side) {
+  float p[6], s[3] = {0, 0, 0}, tmp[3], axis[6], d[4], sd[2] = {0, 0}, pnt[4], res[6];
+  tmp[0] = x0[0] - xpos[0]; tmp[1] = x0[1] - xpos[1]; tmp[2] = x0[2] - xpos[2];
+  matTvec(p, xmat, tmp);
+  tmp[0] = x1[0] - xpos[0]; tmp[1] = x1[1] - xpos[1]; tmp[2] = x1[2] - xpos[2];
+  matTvec(p + 3, xmat, tmp);
+  if (norm3(p) < MINVALF || norm3(p + 3) < MINVALF) return -1;
+  if (has_side) {
+    tmp[0] = side[0] - xpos[0]; tmp[1] = side[1] - xpos[1]; tmp[2] = side[2] - xpos[2];
+    matTvec(s, xmat, tmp);
+  }
+  if (!cylinder) {
+    axis[0] = p[0]; axis[1] = p[1]; axis[2] = p[2];
+    normalize3(axis);
+    float nrmv[3];
+    cross3(nrmv, p, p + 3);
+    float nrm = norm3(nrmv);
+    if (nrm < MINVALF) {
+      int i = 0;
+      if (fabsf(axis[1]) > fabsf(axis[0]) && fabsf(axis[1]) > fabsf(axis[2])) i = 1;
+      if (fabsf(axis[2]) > fabsf(axis[0]) && fabsf(axis[2]) > fabsf(axis[1])) i = 2;
+      float t[3] = {i == 0 ? 0.f : 1.f, i == 1 ? 0.f : 1.f, i == 2 ? 0.f : 1.f};
+      cross3(nrmv, axis, t);
+      nrm = norm3(nrmv);
+    }
+    float inv = 1.0f / nrm;
+    nrmv[0] *= inv; nrmv[1] *= inv; nrmv[2] *= inv;
+    cross3(axis + 3, nrmv, axis);
+    normalize3(axis + 3);
+    d[0] = dot3(p, axis); d[1] = dot3(p, axis + 3); d[2] = dot3(p + 3, axis); d[3] = dot3(p + 3, axis + 3);
+    if (has_side) { sd[0] = dot3(s, axis); sd[1] = dot3(s, axis + 3); }
+  } else {
+    d[0] = p[0]; d[1] = p[1]; d[2] = p[3]; d[3] = p[4];
+    if (has_side) { sd[0] = s[0]; sd[1] = s[1]; }
+  }
+  float wlen;
+  float sdn = sqrtf(sd[0] * sd[0] + sd[1] * sd[1]);
+  if (has_side && sdn < radius) {
+    wlen = wrap_inside(pnt, d, radius);
+  } else {
+    if (has_side && sdn > MINVALF) { sd[0] /= sdn; sd[1] /= sdn; }
+    wlen = wrap_circle(pnt, d, sd, has_side, radius);
+  }
+  if (wlen < 0) return -1;
+  if (!cylinder) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      res[k] = axis[k] * pnt[0] + axis[3 + k] * pnt[1];
+      res[3 + k] = axis[k] * pnt[2] + axis[3 + k] * pnt[3];
+    }
+  } else {
+    float L0 = sqrtf((p[0] - pnt[0]) * (p[0] - pnt[0]) + (p[1] - pnt[1]) * (p[1] - pnt[1]));
+    float L1 = sqrtf((p[3] - pnt[2]) * (p[3] - pnt[2]) + (p[4] - pnt[3]) * (p[4] - pnt[3]));
+    float tot = L0 + wlen + L1;
+    res[0] = pnt[0]; res[1] = pnt[1]; res[3] = pnt[2]; res[4] = pnt[3];
+    res[2] = p[2] + (p[5] - p[2]) * L0 / tot;
+    res[5] = p[2] + (p[5] - p[2]) * (L0 + wlen) / tot;
+    float h = res[5] - res[2];
+    wlen = sqrtf(wlen * wlen + h * h);
+  }
+  matvec(wpnt, xmat, res);
+  matvec(wpnt + 3, xmat, res + 3);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { wpnt[k] += xpos[k]; wpnt[3 + k] += xpos[k]; }
+  return wlen;
+}
+
+// ------------------------------------------------------------------------------------------------
+// muscle model (MuJoCo mju_muscleGain / Bias / Dynamics) on an actuator record (lowering.ACT_FLTS)
+__device__ __forceinline__ float muscle_fl(float L, float lmin, float lmax) {
+  if (lmin <= L && L <= lmax) {
+    float a = 0.5f * (lmin + 1), b = 0.5f * (1 + lmax), x;
+    if (L <= a) { x = (L - lmin) / fmaxf(MINVALF, a - lmin); return 0.5f * x * x; }
+    else if (L <= 1) { x = (1 - L) / fmaxf(MINVALF, 1 - a); return 1 - 0.5f * x * x; }
+    else if (L <= b) { x = (L - 1) / fmaxf(MINVALF, b - 1); return 1 - 0.5f * x * x; }
+    else { x = (lmax - L) / fmaxf(MINVALF, lmax - b); return 0.5f * x * x; }
+  }
+  return 0;
+}
+__device__ __forceinline__ void muscle(const float* A, float len, float vel, float act, float ctrl, float* force, float* actdot) {
+  float r0 = A[0], r1 = A[1], F0 = A[2], lmin = A[3], lmax = A[4], vmax = A[5], fpmax = A[6], fvmax = A[7], lr0 = A[8], lr1 = A[9];
+  float L0 = (lr1 - lr0) / fmaxf(MINVALF, r1 - r0);
+  float L = r0 + (len - lr0) / fmaxf(MINVALF, L0);
+  float V = vel / fmaxf(MINVALF, L0 * vmax);
+  float FL = muscle_fl(L, lmin, lmax), FV, y = fvmax - 1;
+  if (V <= -1) FV = 0;
+  else if (V <= 0) FV = (V + 1) * (V + 1);
+  else if (V <= y) FV = fvmax - (y - V) * (y - V) / fmaxf(MINVALF, y);
+  else FV = fvmax;
+  float gain = -F0 * FL * FV;
+  float b = 0.5f * (1 + lmax), bias, x;
+  if (L <= 1) bias = 0;
+  else if (L <= b) { x = (L - 1) / fmaxf(MINVALF, b - 1); bias = -A[15] * fpmax * 0.5f * x * x; }   // A[15]: peak force of biasprm
+  else { x = (L - b) / fmaxf(MINVALF, b - 1); bias = -A[15] * fpmax * (0.5f + x); }
+  *force = gain * act + bias;
+  float cc = clipf(clipf(ctrl, A[12], A[13]), 0.f, 1.f), ac = clipf(act, 0.f, 1.f);
+  float tau_act = A[10] * (0.5f + 1.5f * ac), tau_deact = A[11] / (0.5f + 1.5f * ac);
+  float dctrl = cc - act;
+  *actdot = dctrl / fmaxf(MINVALF, dctrl > 0 ? tau_act : tau_deact);
+}
+
+// normalised action -> muscle excitation (BaseV0.step, envs/myo/base_v0.py:83-109), one actuator of one env:
+//   sigmoid re-projection (:87-91); muscle condition "fatigue": the excitation becomes the 3CC-r model's active compartment MA after
+//   one update with the target load TL = sigmoid(a) (envs/myo/fatigue.py:61-108; F, R, r of :10-18); "reafferentation": EPL is driven
+//   by EIP's command and EIP is silenced (:105-109)
+__device__ __forceinline__ float action_map(const DevBatch& Bt, const float* __restrict__ actprm, const float* __restrict__ action, int env,
+                                            int i, int nu, int actmap) {
+  int src = i;
+  if (actmap == MYO_ACTMAP_SIGMOID_REAFFERENTATION) { if (i == Bt.reaf_epl) src = Bt.reaf_eip; else if (i == Bt.reaf_eip) return 0.f; }
+  float c = action[(size_t)env * nu + src];
+  if (actmap == MYO_ACTMAP_NONE) return c;
+  c = 1.0f / (1.0f + expf(-5.0f * (c - 0.5f)));
+  if (actmap == MYO_ACTMAP_SIGMOID_FATIGUE) {
+    float* S = Bt.fatigue + (size_t)env * 3 * nu;
+    float MA = S[i], MR = S[nu + i], MF = S[2 * nu + i];
+    const float F = 0.00912f, R = 0.1f * 0.00094f, rr = 10.f * 15.f, dt = Bt.fat_dt, TL = c;
+    float LD = (0.5f + 1.5f * MA) / actprm[16 * i + 10], LR = (0.5f + 1.5f * MA) / actprm[16 * i + 11];
+    float C, rR;
+    if (MA < TL) { C = (MR > TL - MA) ? LD * (TL - MA) : LD * MR; rR = R; }
+    else { C = LR * (TL - MA); rR = rr * R; }
+    float lo = fmaxf(-MA / dt + F * MA, (MR - 1) / dt + rR * MF), hi = fminf((1 - MA) / dt + F * MA, MR / dt + rR * MF);
+    C = fminf(fmaxf(C, lo), hi);                    // np.clip(C, lo, hi)
+    S[i] = MA + (C - F * MA) * dt;
+    S[nu + i] = MR + (-C + rR * MF) * dt;
+    S[2 * nu + i] = MF + (F * MA - rR * MF) * dt;
+    c = S[i];
+  }
+  return c;
+}
+
+__device__ __forceinline__ float impedance(const float* solimp, float pos, float margin) {
+  float dmin = clipf(solimp[0], MINIMPF, MAXIMPF), dmax = clipf(solimp[1], MINIMPF, MAXIMPF);
+  float width = fmaxf(MINVALF, solimp[2]), mid = clipf(solimp[3], MINIMPF, MAXIMPF), power = fmaxf(1.f, solimp[4]);
+  if (dmin == dmax || width <= MINVALF) return 0.5f * (dmin + dmax);
+  float x = fabsf((pos - margin) / width);
+  if (x >= 1) return dmax;
+  if (x == 0) return dmin;
+  float y;
+  if (power == 1) y = x;
+  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1);
+  else y = 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
+  return dmin + y * (dmax - dmin);
+}
+__device__ __forceinline__ void kbi(float solref0, float solref1, float dmax_in, float timestep, float* K, float* B) {
+  float dmax = clipf(dmax_in, MINIMPF, MAXIMPF);
+  if (solref0 > 0) {
+    float tc = fmaxf(solref0, 2 * timestep);
+    *K = 1.0f / fmaxf(MINVALF, dmax * dmax * tc * tc * solref1 * solref1);
+    *B = 2.0f / fmaxf(MINVALF, dmax * tc);
+  } else {
+    *K = -solref0 / fmaxf(MINVALF, dmax * dmax);
+    *B = -solref1 / fmaxf(MINVALF, dmax);
+  }
+}
+
+__device__ __forceinline__ void make_frame(const float* n, float* t1, float* t2) {  // mju_makeFrame
+  t1[0] = 0; t1[1] = 0; t1[2] = 0;
+  if (n[1] < 0.5f && n[1] > -0.5f) t1[1] = 1; else t1[2] = 1;
+  float t = dot3(n, t1);
+  t1[0] -= t * n[0]; t1[1] -= t * n[1]; t1[2] -= t * n[2];
+  normalize3(t1);
+  cross3(t2, n, t1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// convex collision for ellipsoid pads: margin-inflated MPR (float twin of the oracle's mpr_penetration)
+struct CObj { float pos[3], mat[9], size[3]; int type; float margin; };  // by value: keeps everything in registers
+// support point of the un-inflated shape in its own frame, for a direction given in that frame
+__device__ __forceinline__ void support_local(int type, const float* size, const float* dl, float* pl) {
+  if (type == GEOM_ELLIPSOID) {
+    float s[3] = {size[0] * dl[0], size[1] * dl[1], size[2] * dl[2]};
+    float n = norm3(s);
+    float inv = n > MINVALF ? 1.0f / n : 0.f;
+    pl[0] = size[0] * s[0] * inv; pl[1] = size[1] * s[1] * inv; pl[2] = size[2] * s[2] * inv;
+  } else if (type == GEOM_CYLINDER) {
+    float n = sqrtf(dl[0] * dl[0] + dl[1] * dl[1]);
+    float inv = n > MINVALF ? size[0] / n : 0.f;
+    pl[0] = dl[0] * inv; pl[1] = dl[1] * inv; pl[2] = dl[2] >= 0 ? size[1] : -size[1];
+  } else {  // sphere / capsule
+    float n = norm3(dl);
+    float inv = n > MINVALF ? size[0] / n : 0.f;
+    pl[0] = dl[0] * inv; pl[1] = dl[1] * inv; pl[2] = dl[2] * inv;
+    if (type == GEOM_CAPSULE) pl[2] += dl[2] >= 0 ? size[1] : -size[1];
+  }
+}
+struct Sup { float v[3], v1[3]; };  // Minkowski point and its witness on obj1 (the witness on obj2 is v1 - v)
+// Minkowski-difference support of the two margin-inflated shapes.  Contract of the wave kernel's caller: obj `a` sits in the
+// identity frame at the origin (the pair is expressed in geom 1's frame) and `dir` is a unit vector, so a's support needs no
+// rotation and the spherical inflation is just +-margin * dir (no norm, no division).
+__device__ void mink_support(const CObj& a, const CObj& b, const float* dir, Sup& s) {
+  float nd[3] = {-dir[0], -dir[1], -dir[2]}, dl[3], pl[3], w2[3];
+  support_local(a.type, a.size, dir, s.v1);
+  matTvec(dl, b.mat, nd);
+  support_local(b.type, b.size, dl, pl);
+  matvec(w2, b.mat, pl);
+  const float m2 = a.margin + b.margin;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    s.v1[k] += a.margin * dir[k];
+    s.v[k] = s.v1[k] - (w2[k] + b.pos[k]) + b.margin * dir[k];
+  }
+  (void)m2;
+}
+__device__ __forceinline__ void portal_dir(const Sup* p, float* dir) {
+  float a[3] = {p[2].v[0] - p[1].v[0], p[2].v[1] - p[1].v[1], p[2].v[2] - p[1].v[2]};
+  float b[3] = {p[3].v[0] - p[1].v[0], p[3].v[1] - p[1].v[1], p[3].v[2] - p[1].v[2]};
+  cross3(dir, a, b);
+  normalize3(dir);
+}
+__device__ __forceinline__ void expand_portal(Sup* p, const Sup& v4) {
+  float va[3];
+  cross3(va, v4.v, p[0].v);
+  if (dot3(p[1].v, va) > 0) { if (dot3(p[2].v, va) > 0) p[1] = v4; else p[3] = v4; }
+  else { if (dot3(p[3].v, va) > 0) p[2] = v4; else p[1] = v4; }
+}
+__device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup = nullptr) {
+  Sup p[4];
+  float dir[3], va[3], vb[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { p[0].v1[k] = o1.pos[k]; p[0].v[k] = o1.pos[k] - o2.pos[k]; }
+  if (norm3(p[0].v) < MINVALF) p[0].v[0] += 1e-5f;
+  dir[0] = -p[0].v[0]; dir[1] = -p[0].v[1]; dir[2] = -p[0].v[2];
+  normalize3(dir);
+  mink_support(o1, o2, dir, p[1]);
+  if (dot3(p[1].v, dir) < 0) return false;
+  cross3(dir, p[0].v, p[1].v);
+  if (norm3(dir) < 1e-12f) {
+    *depth = norm3(p[1].v);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { dirout[k] = p[1].v[k]; posout[k] = p[1].v1[k] - 0.5f * p[1].v[k]; }
+    normalize3(dirout);
+    return true;
+  }
+  normalize3(dir);
+  mink_support(o1, o2, dir, p[2]);
+  if (dot3(p[2].v, dir) < 0) return false;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { va[k] = p[1].v[k] - p[0].v[k]; vb[k] = p[2].v[k] - p[0].v[k]; }
+  cross3(dir, va, vb);
+  normalize3(dir);
+  if (dot3(dir, p[0].v) > 0) { Sup t = p[1]; p[1] = p[2]; p[2] = t; dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
+  for (int it = 0;; it++) {
+    if (it > maxit) return false;
+    mink_support(o1, o2, dir, p[3]);
+    if (dot3(p[3].v, dir) < 0) return false;
+    bool cont = false;
+    cross3(va, p[1].v, p[3].v);
+    if (dot3(va, p[0].v) < -MINVALF) { p[2] = p[3]; cont = true; }
+    if (!cont) {
+      cross3(va, p[3].v, p[2].v);
+      if (dot3(va, p[0].v) < -MINVALF) { p[1] = p[3]; cont = true; }
+    }
+    if (!cont) break;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { va[k] = p[1].v[k] - p[0].v[k]; vb[k] = p[2].v[k] - p[0].v[k]; }
+    cross3(dir, va, vb);
+    normalize3(dir);
+  }
+  for (int it = 0;; it++) {
+    if (it > maxit) return false;
+    portal_dir(p, dir);
+    if (dot3(dir, p[1].v) >= 0) break;
+    Sup v4;
+    mink_support(o1, o2, dir, v4);
+    float dv4 = dot3(v4.v, dir);
+    float dmin = fminf(fminf(dv4 - dot3(p[1].v, dir), dv4 - dot3(p[2].v, dir)), dv4 - dot3(p[3].v, dir));
+    if (dv4 < 0 || dmin <= tol) return false;
+    expand_portal(p, v4);
+  }
+  Sup v4;
+  for (int it = 0;; it++) {
+    portal_dir(p, dir);
+    mink_support(o1, o2, dir, v4);
+    float dv4 = dot3(v4.v, dir);
+    float dmin = fminf(fminf(dv4 - dot3(p[1].v, dir), dv4 - dot3(p[2].v, dir)), dv4 - dot3(p[3].v, dir));
+    if (dmin <= tol || it > maxit) { if (nsup) *nsup = it; break; }
+    expand_portal(p, v4);
+  }
+  // output from the final support plane (see the oracle's mpr_penetration for the rationale)
+  *depth = dot3(v4.v, dir);
+  // contact position: barycentric coordinates of the origin in the tetrahedron (v0, portal) (libccd findPos)
+  float bw[4], cr[3];
+  cross3(cr, p[1].v, p[2].v); bw[0] = dot3(cr, p[3].v);
+  cross3(cr, p[3].v, p[2].v); bw[1] = dot3(cr, p[0].v);
+  cross3(cr, p[0].v, p[1].v); bw[2] = dot3(cr, p[3].v);
+  cross3(cr, p[2].v, p[1].v); bw[3] = dot3(cr, p[0].v);
+  float sum = bw[0] + bw[1] + bw[2] + bw[3];
+  if (sum <= 0) {
+    bw[0] = 0;
+    cross3(cr, p[2].v, p[3].v); bw[1] = dot3(cr, dir);
+    cross3(cr, p[3].v, p[1].v); bw[2] = dot3(cr, dir);
+    cross3(cr, p[1].v, p[2].v); bw[3] = dot3(cr, dir);
+    sum = bw[1] + bw[2] + bw[3];
+  }
+  float inv = 1.0f / sum;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    dirout[k] = dir[k];
+    posout[k] = inv * (bw[0] * (p[0].v1[k] - 0.5f * p[0].v[k]) + bw[1] * (p[1].v1[k] - 0.5f * p[1].v[k]) +
+                       bw[2] * (p[2].v1[k] - 0.5f * p[2].v[k]) + bw[3] * (p[3].v1[k] - 0.5f * p[3].v[k]));
+  }
+  return true;
+}
+
+#endif  // MYO_PHYSICS_H
