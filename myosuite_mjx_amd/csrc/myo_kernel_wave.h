@@ -858,8 +858,9 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
 #pragma unroll
             for (int k = 0; k < 9; k++) o1.mat[k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
 #pragma unroll
-            for (int k = 0; k < 3; k++) { o1.pos[k] = 0.f; o1.size[k] = sz1[k]; o2.size[k] = sz2[k]; }
-            o1.type = M.cg_type[g1]; o2.type = M.cg_type[g2]; o1.margin = o2.margin = 0.5f * margin;
+            for (int k = 0; k < 3; k++) o1.pos[k] = 0.f;
+            cobj_shape(o1, M.cg_type[g1], sz1); cobj_shape(o2, M.cg_type[g2], sz2);
+            o1.margin = o2.margin = 0.5f * margin;
             float depth, dir[3], pos[3];
             if (mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup)) {
               dist = margin - depth;

@@ -267,24 +267,22 @@ __device__ __forceinline__ void make_frame(const float* n, float* t1, float* t2)
 
 // ------------------------------------------------------------------------------------------------
 // convex collision for ellipsoid pads: margin-inflated MPR (float twin of the oracle's mpr_penetration)
-struct CObj { float pos[3], mat[9], size[3]; int type; float margin; };  // by value: keeps everything in registers
+// Every convex shape of the config models is "scaled sphere (+) axial segment": support(d) = S^2 d / |S d| + h sign(d_z) e_z with
+//   ellipsoid S = semi-axes, h = 0 | sphere S = (r,r,r), h = 0 | capsule S = (r,r,r), h = half length | cylinder S = (r,r,0), h = half length.
+// One branch-free formula instead of a per-type switch: in a wave that mixes pad / capsule pairs every lane used to walk through all
+// the type branches of both shapes at each of the ~23 support evaluations of an MPR call.
+struct CObj { float pos[3], mat[9], S[3], h, margin; };  // by value: keeps everything in registers
+__device__ __forceinline__ void cobj_shape(CObj& o, int type, const float* size) {
+  if (type == GEOM_ELLIPSOID) { o.S[0] = size[0]; o.S[1] = size[1]; o.S[2] = size[2]; o.h = 0.f; }
+  else if (type == GEOM_CYLINDER) { o.S[0] = size[0]; o.S[1] = size[0]; o.S[2] = 0.f; o.h = size[1]; }
+  else { o.S[0] = o.S[1] = o.S[2] = size[0]; o.h = type == GEOM_CAPSULE ? size[1] : 0.f; }
+}
 // support point of the un-inflated shape in its own frame, for a direction given in that frame
-__device__ __forceinline__ void support_local(int type, const float* size, const float* dl, float* pl) {
-  if (type == GEOM_ELLIPSOID) {
-    float s[3] = {size[0] * dl[0], size[1] * dl[1], size[2] * dl[2]};
-    float n = norm3(s);
-    float inv = n > MINVALF ? 1.0f / n : 0.f;
-    pl[0] = size[0] * s[0] * inv; pl[1] = size[1] * s[1] * inv; pl[2] = size[2] * s[2] * inv;
-  } else if (type == GEOM_CYLINDER) {
-    float n = sqrtf(dl[0] * dl[0] + dl[1] * dl[1]);
-    float inv = n > MINVALF ? size[0] / n : 0.f;
-    pl[0] = dl[0] * inv; pl[1] = dl[1] * inv; pl[2] = dl[2] >= 0 ? size[1] : -size[1];
-  } else {  // sphere / capsule
-    float n = norm3(dl);
-    float inv = n > MINVALF ? size[0] / n : 0.f;
-    pl[0] = dl[0] * inv; pl[1] = dl[1] * inv; pl[2] = dl[2] * inv;
-    if (type == GEOM_CAPSULE) pl[2] += dl[2] >= 0 ? size[1] : -size[1];
-  }
+__device__ __forceinline__ void support_local(const float* S, float h, const float* dl, float* pl) {
+  float s[3] = {S[0] * dl[0], S[1] * dl[1], S[2] * dl[2]};
+  float n = norm3(s);
+  float inv = n > MINVALF ? 1.0f / n : 0.f;
+  pl[0] = S[0] * s[0] * inv; pl[1] = S[1] * s[1] * inv; pl[2] = S[2] * s[2] * inv + (dl[2] >= 0 ? h : -h);
 }
 struct Sup { float v[3], v1[3]; };  // Minkowski point and its witness on obj1 (the witness on obj2 is v1 - v)
 // Minkowski-difference support of the two margin-inflated shapes.  Contract of the wave kernel's caller: obj `a` sits in the
@@ -292,9 +290,9 @@ struct Sup { float v[3], v1[3]; };  // Minkowski point and its witness on obj1 (
 // rotation and the spherical inflation is just +-margin * dir (no norm, no division).
 __device__ void mink_support(const CObj& a, const CObj& b, const float* dir, Sup& s) {
   float nd[3] = {-dir[0], -dir[1], -dir[2]}, dl[3], pl[3], w2[3];
-  support_local(a.type, a.size, dir, s.v1);
+  support_local(a.S, a.h, dir, s.v1);
   matTvec(dl, b.mat, nd);
-  support_local(b.type, b.size, dl, pl);
+  support_local(b.S, b.h, dl, pl);
   matvec(w2, b.mat, pl);
   const float m2 = a.margin + b.margin;
 #pragma unroll
