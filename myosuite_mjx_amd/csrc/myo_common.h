@@ -24,6 +24,9 @@
 #ifndef LS_FLOOR
 #define LS_FLOOR 1e-6f   // float32 floor of the line-search slope tolerance, relative to the initial slope
 #endif
+#ifndef LS_NOISE
+#define LS_NOISE 1e-6f   // line-search slope below this fraction of its own cancelling terms = float32 round-off
+#endif
 #define KCMAX 8   // max dofs in a contact pair's jacobian (checked against the model at load)
 #define GEOM_SPHERE 2
 #define GEOM_CAPSULE 3

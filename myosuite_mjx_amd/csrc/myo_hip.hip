@@ -332,7 +332,7 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   BA(d.fatigue, (size_t)B * 3 * nu)
   BA(b->d_initv, nv)
   { void* pw = nullptr; if ((rc = balloc(b, &pw, sizeof(DevWalk)))) { myo_batch_free(b); return rc; } b->d_walk = (DevWalk*)pw; }
-  BA(b->d_stamps, (size_t)B * 12 * 2)
+  BA(b->d_stamps, (size_t)B * 12 * 2 * 2)      // 2 x 12 long long per workgroup (diagnostic build)
   BA(b->d_order, B)
   b->sched_stride = (B + 7) / 8 + 1;
   BA(b->d_sched, 32 + 8 * b->sched_stride)

@@ -1570,14 +1570,24 @@ static real constraint_update(const Model* m, Data* d, const real* jar, int set_
   return cost;
 }
 
+/* developer statistics (not thread safe; single-threaded probes only): evaluations per exact line search */
+#ifndef MYOO_LS_NOISE
+#define MYOO_LS_NOISE 0
+#endif
+static long g_ls_hist[64];
+static int g_ls_last;
+void myoo_ls_hist(long* out, int reset) { for (int k = 0; k < 64; k++) { out[k] = g_ls_hist[k]; if (reset) g_ls_hist[k] = 0; } }
+
 typedef struct { real g1, g2; const real *jar, *jv, *D; const int* type; int nefc; } LSctx;
+static real g_ls_mag;   /* magnitude of the terms that cancel in d1 at the last evaluation (round-off scale of the float build) */
 static void ls_eval(const LSctx* c, real alpha, real* d1, real* d2) {
-  real a = c->g1 + 2 * alpha * c->g2, b = 2 * c->g2;
+  real a = c->g1 + 2 * alpha * c->g2, b = 2 * c->g2, p = 0;
   for (int i = 0; i < c->nefc; i++) {
     real x = c->jar[i] + alpha * c->jv[i];
-    if (c->type[i] == CT_EQUALITY || x < 0) { a += c->D[i] * x * c->jv[i]; b += c->D[i] * c->jv[i] * c->jv[i]; }
+    if (c->type[i] == CT_EQUALITY || x < 0) { p += c->D[i] * x * c->jv[i]; b += c->D[i] * c->jv[i] * c->jv[i]; }
   }
-  *d1 = a; *d2 = b;
+  g_ls_mag = fabs(c->g1) + fabs(2 * alpha * c->g2) + fabs(p);
+  *d1 = a + p; *d2 = b;
 }
 
 static int cholesky(real* H, int n) { /* in place lower Cholesky, row-major; returns 0 on success */
@@ -1681,9 +1691,15 @@ static void fwd_constraint(const Model* m, Data* d) { /* mj_fwdConstraint + mj_s
     ls_eval(&ls, 0, &dlo, &d2lo);
     if (dlo >= 0 || d2lo <= 0) break; /* not a descent direction: converged to round-off */
     alpha = -dlo / d2lo;
+    g_ls_last = 0;
     for (int lsit = 0; lsit < m->ls_iterations; lsit++) {
       ls_eval(&ls, alpha, &d1, &d2);
+      g_ls_last = lsit + 1;
+#ifdef MYOO_FLOAT
+      if (fabs(d1) < gtol || fabs(d1) < MYOO_LS_NOISE * g_ls_mag) break;   /* slope below the float round-off of its own terms */
+#else
       if (fabs(d1) < gtol) break;
+#endif
       if (d1 < 0) { lo = alpha; dlo = d1; d2lo = d2; } else { hi = alpha; dhi = d1; d2hi = d2; }
       real cand = alpha - d1 / d2;
       if (hi < 0) { /* not bracketed yet: keep doing one-sided Newton steps to the right */
@@ -1698,6 +1714,7 @@ static void fwd_constraint(const Model* m, Data* d) { /* mj_fwdConstraint + mj_s
         alpha = cand;
       }
     }
+    g_ls_hist[g_ls_last < 63 ? g_ls_last : 63]++;
     if (alpha <= 0) break;
     for (int k = 0; k < nv; k++) { d->qacc[k] += alpha * search[k]; Ma[k] += alpha * Mv[k]; }
     for (int i = 0; i < nefc; i++) jar[i] += alpha * jv[i];

@@ -21,9 +21,9 @@ def build(force=False):
 
 
 class Oracle:
-    def __init__(self, blob: bytes, f32=False):
+    def __init__(self, blob: bytes, f32=False, lib_path=None):
         build()
-        self.lib = C.CDLL(os.path.join(_HERE, "libmyo_oracle_f32.so" if f32 else "libmyo_oracle.so"))
+        self.lib = C.CDLL(lib_path or os.path.join(_HERE, "libmyo_oracle_f32.so" if f32 else "libmyo_oracle.so"))
         L = self.lib
         L.myoo_load.restype = C.c_void_p
         L.myoo_load.argtypes = [C.c_char_p, C.c_size_t]
