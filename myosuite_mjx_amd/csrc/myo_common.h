@@ -27,6 +27,9 @@
 #ifndef LS_NOISE
 #define LS_NOISE 1e-6f   // line-search slope below this fraction of its own cancelling terms = float32 round-off
 #endif
+#ifndef NEWTON_NOISE
+#define NEWTON_NOISE 1e-6f   // Newton stops when the cost improvement is below this fraction of the cost itself (float32 round-off of the cost)
+#endif
 #define KCMAX 8   // max dofs in a contact pair's jacobian (checked against the model at load)
 #define GEOM_SPHERE 2
 #define GEOM_CAPSULE 3

@@ -1149,7 +1149,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           float gn = scale * sqrtf(wave_sum(grad * grad));
           iters++;
           f_itcon += ncon;
-          if (improvement < fmaxf(M.tolerance, 1e-6f * scale * fabsf(newcost)) || gn < M.tolerance || iters >= M.iterations) phase = 2;
+          if (improvement < fmaxf(M.tolerance, NEWTON_NOISE * scale * fabsf(newcost)) || gn < M.tolerance || iters >= M.iterations) phase = 2;
         }
         cost = newcost;
         SUB(0);

@@ -1574,6 +1574,9 @@ static real constraint_update(const Model* m, Data* d, const real* jar, int set_
 #ifndef MYOO_LS_NOISE
 #define MYOO_LS_NOISE 0
 #endif
+#ifndef MYOO_NEWTON_NOISE
+#define MYOO_NEWTON_NOISE 0
+#endif
 static long g_ls_hist[64];
 static int g_ls_last;
 void myoo_ls_hist(long* out, int reset) { for (int k = 0; k < 64; k++) { out[k] = g_ls_hist[k]; if (reset) g_ls_hist[k] = 0; } }
@@ -1726,7 +1729,11 @@ static void fwd_constraint(const Model* m, Data* d) { /* mj_fwdConstraint + mj_s
     d->solver_improvement = scale * (oldcost - cost);
     d->solver_gradient = scale * sqrt(gn);
     iter++;
+#ifdef MYOO_FLOAT
+    if (d->solver_improvement < maxr(m->tolerance, MYOO_NEWTON_NOISE * scale * fabs(cost)) || d->solver_gradient < m->tolerance) break;
+#else
     if (d->solver_improvement < m->tolerance || d->solver_gradient < m->tolerance) break;
+#endif
   }
   (void)tmpv;
   d->solver_iter = iter;
