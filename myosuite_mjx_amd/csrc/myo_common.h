@@ -30,6 +30,9 @@
 #ifndef NEWTON_NOISE
 #define NEWTON_NOISE 1e-6f   // Newton stops when the cost improvement is below this fraction of the cost itself (float32 round-off of the cost)
 #endif
+#ifndef GRAD_NOISE
+#define GRAD_NOISE 2e-7f   // Newton stops when the gradient norm is below this fraction of the norm of its cancelling terms
+#endif
 #define KCMAX 8   // max dofs in a contact pair's jacobian (checked against the model at load)
 #define GEOM_SPHERE 2
 #define GEOM_CAPSULE 3

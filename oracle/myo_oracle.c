@@ -1577,6 +1577,9 @@ static real constraint_update(const Model* m, Data* d, const real* jar, int set_
 #ifndef MYOO_NEWTON_NOISE
 #define MYOO_NEWTON_NOISE 0
 #endif
+#ifndef MYOO_GRAD_NOISE
+#define MYOO_GRAD_NOISE 0
+#endif
 static long g_ls_hist[64];
 static int g_ls_last;
 void myoo_ls_hist(long* out, int reset) { for (int k = 0; k < 64; k++) { out[k] = g_ls_hist[k]; if (reset) g_ls_hist[k] = 0; } }
@@ -1724,13 +1727,17 @@ static void fwd_constraint(const Model* m, Data* d) { /* mj_fwdConstraint + mj_s
     real oldcost = cost;
     cost = constraint_update(m, d, jar, 1);
     for (int k = 0; k < nv; k++) cost += (real)0.5 * (Ma[k] - d->qfrc_smooth[k]) * (d->qacc[k] - d->qacc_smooth[k]);
-    real gn = 0;
-    for (int k = 0; k < nv; k++) { real g = Ma[k] - d->qfrc_smooth[k] - d->qfrc_constraint[k]; gn += g * g; }
+    real gn = 0, gmag = 0;
+    for (int k = 0; k < nv; k++) {
+      real g = Ma[k] - d->qfrc_smooth[k] - d->qfrc_constraint[k]; gn += g * g;
+      real t = fabs(Ma[k]) + fabs(d->qfrc_smooth[k]) + fabs(d->qfrc_constraint[k]); gmag += t * t;   /* round-off scale of the gradient */
+    }
     d->solver_improvement = scale * (oldcost - cost);
     d->solver_gradient = scale * sqrt(gn);
     iter++;
 #ifdef MYOO_FLOAT
-    if (d->solver_improvement < maxr(m->tolerance, MYOO_NEWTON_NOISE * scale * fabs(cost)) || d->solver_gradient < m->tolerance) break;
+    if (d->solver_improvement < maxr(m->tolerance, MYOO_NEWTON_NOISE * scale * fabs(cost)) ||
+        d->solver_gradient < maxr(m->tolerance, MYOO_GRAD_NOISE * scale * sqrt(gmag))) break;
 #else
     if (d->solver_improvement < m->tolerance || d->solver_gradient < m->tolerance) break;
 #endif
