@@ -1084,6 +1084,8 @@ static void portal_dir(const Sup* p, real* dir) { /* normal of the portal triang
 }
 
 /* returns 1 if penetrating; fills depth, dir (from obj1 to obj2), pos */
+static long g_mpr_hist[64];   /* developer statistics: refinement steps per MPR call */
+void myoo_mpr_hist(long* out, int reset) { for (int k = 0; k < 64; k++) { out[k] = g_mpr_hist[k]; if (reset) g_mpr_hist[k] = 0; } }
 static int mpr_penetration(const CObj* o1, const CObj* o2, real tol, int maxit, real* depth, real* dirout, real* posout) {
   Sup p[4];
   real dir[3], va[3], vb[3];
@@ -1149,7 +1151,7 @@ static int mpr_penetration(const CObj* o1, const CObj* o2, real tol, int maxit, 
     mink_support(o1, o2, dir, &v4);
     real dv4 = dot3(v4.v, dir);
     real dmin = minr(minr(dv4 - dot3(p[1].v, dir), dv4 - dot3(p[2].v, dir)), dv4 - dot3(p[3].v, dir));
-    if (dmin <= tol || it > maxit) break;
+    if (dmin <= tol || it > maxit) { g_mpr_hist[it < 63 ? it : 63]++; break; }
     cross3(va, v4.v, p[0].v);
     if (dot3(p[1].v, va) > 0) { if (dot3(p[2].v, va) > 0) p[1] = v4; else p[3] = v4; }
     else { if (dot3(p[3].v, va) > 0) p[2] = v4; else p[1] = v4; }
