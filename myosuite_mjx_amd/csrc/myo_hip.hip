@@ -248,7 +248,8 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
     {
       std::vector<int> fl, pi;
       if ((rc = load_i(m, blob, "hip_flags", &tmpi, &fl)) || (rc = load_i(m, blob, "hip_link_free", &w.link_free)) ||
-          (rc = load_i(m, blob, "hip_dof_qposadr", &w.dof_qposadr)) || (rc = load_i(m, blob, "hip_eq_i", &w.eq_i)) ||
+          (rc = load_i(m, blob, "hip_dof_qposadr", &w.dof_qposadr)) || (rc = load_i(m, blob, "hip_link_chain_adr", &w.link_chain_adr)) ||
+          (rc = load_i(m, blob, "hip_link_chain", &w.link_chain)) || (rc = load_i(m, blob, "hip_eq_i", &w.eq_i)) ||
           (rc = load_f(m, blob, "hip_eq_f", &w.eq_f)) || (rc = load_i(m, blob, "hip_pair_i", &tmpi, &pi))) { myo_model_free(m); return rc; }
       w.has_free = fl[0]; w.nq = fl[1]; w.neq = fl[2];
       const float* tf;

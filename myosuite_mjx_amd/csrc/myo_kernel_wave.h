@@ -29,7 +29,7 @@ struct DevModelW {
   int nwrapseg, ndl, has_tl;
   const float* tl;
   int nq, has_free, neq;          // free-floating root (nq = nv + 1), joint-coupling equalities
-  const int *link_free, *dof_qposadr, *eq_i;
+  const int *link_free, *dof_qposadr, *eq_i, *link_chain_adr, *link_chain;
   const float* eq_f;
 };
 
@@ -538,45 +538,36 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     WFOR(i, NVT * (NVT + 1)) E[Y.sq + i] = 0;
     SYNC();
     SUB(10);
-    for (int L = 0; L < nlevel_; L++) {
-      int l = M.level_adr[L] + lane;
-      if (l < M.level_adr[L + 1]) {
-        int par = M.link_parent[l];
-        float cvel[6], cacc[6];
-        if (par < 0) {
-          cvel[0] = cvel[1] = cvel[2] = cvel[3] = cvel[4] = cvel[5] = 0;
-          cacc[0] = cacc[1] = cacc[2] = 0; cacc[3] = -M.grav[0]; cacc[4] = -M.grav[1]; cacc[5] = -M.grav[2];
-        } else {
+    // velocity / acceleration sweep (mj_comVel + the forward half of mj_rne), ONE pass: lane = link walks the dofs of its whole
+    // ancestor chain root-first (lowering table).  The chains are <= 7 dofs long, so redoing a parent's sums in every descendant
+    // lane costs less than a level-by-level sweep with one barrier and a handful of active lanes per level.
+    if (lane < nl_) {
+      const int l = lane;
+      float cvel[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cacc[6] = {0.f, 0.f, 0.f, -M.grav[0], -M.grav[1], -M.grav[2]}, cvel_rot[6];
+      for (int c = W.link_chain_adr[l]; c < W.link_chain_adr[l + 1]; c++) {
+        const int e = W.link_chain[c], d = e & 255, j = (e >> 8) & 7;
+        const bool isfree = has_free && (e >> 12);
+        float cd[6], cdd[6], qv = E[Y.qvel + d];
 #pragma unroll
-          for (int k = 0; k < 6; k++) { cvel[k] = E[Y.cvel + 6 * par + k]; cacc[k] = E[Y.cacc + 6 * par + k]; }
+        for (int k = 0; k < 6; k++) cd[k] = E[Y.cdof + 6 * d + k];
+        if (isfree && j == 3) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) cvel_rot[k] = cvel[k];   // velocity after the translations, before any of the 3 rotations
         }
-        int da = M.link_dofadr[l], dn = M.link_dofnum[l];
-        const bool isfree = has_free && W.link_free[l];
-        float cvel_rot[6];
-        for (int j = 0; j < dn; j++) {
-          int d = da + j;
-          float cd[6], cdd[6], qv = E[Y.qvel + d];
+        cross_motion(cdd, (isfree && j >= 3) ? cvel_rot : cvel, cd);
 #pragma unroll
-          for (int k = 0; k < 6; k++) cd[k] = E[Y.cdof + 6 * d + k];
-          if (isfree && j == 3) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) cvel_rot[k] = cvel[k];   // velocity after the translations, before any of the 3 rotations
-          }
-          cross_motion(cdd, (isfree && j >= 3) ? cvel_rot : cvel, cd);
-#pragma unroll
-          for (int k = 0; k < 6; k++) { cacc[k] += cdd[k] * qv; cvel[k] += cd[k] * qv; }
-        }
-        float ci[10], f[6], t[6], t1[6];
-#pragma unroll
-        for (int k = 0; k < 10; k++) ci[k] = E[Y.cinert + 10 * l + k];
-        mul_inert_vec(f, ci, cacc);
-        mul_inert_vec(t, ci, cvel);
-        cross_force(t1, cvel, t);
-#pragma unroll
-        for (int k = 0; k < 6; k++) { E[Y.cvel + 6 * l + k] = cvel[k]; E[Y.cacc + 6 * l + k] = cacc[k]; E[Y.cfrc + 6 * l + k] = f[k] + t1[k]; }
+        for (int k = 0; k < 6; k++) { cacc[k] += cdd[k] * qv; cvel[k] += cd[k] * qv; }
       }
-      SYNC();
+      float ci[10], f[6], t[6], t1[6];
+#pragma unroll
+      for (int k = 0; k < 10; k++) ci[k] = E[Y.cinert + 10 * l + k];
+      mul_inert_vec(f, ci, cacc);
+      mul_inert_vec(t, ci, cvel);
+      cross_force(t1, cvel, t);
+#pragma unroll
+      for (int k = 0; k < 6; k++) { E[Y.cvel + 6 * l + k] = cvel[k]; E[Y.cfrc + 6 * l + k] = f[k] + t1[k]; }
     }
+    SYNC();
     if (FULL && op) {
       // ---- walk observation / reward (walk_v0.py:268-316, 363-470) from link frames and link velocities of this pass
       float* o = Bt.obs + (size_t)env * wk->obs_dim;

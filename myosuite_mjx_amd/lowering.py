@@ -456,6 +456,22 @@ def lower(cm):
     A["hip_mass"] = np.array([float(np.sum(m.body_mass)), *(sum((m.body_mass[b] * (xipos0[b] - A["hip_origin"]) for b in st), np.zeros(3)))])
     A["hip_dof_qposadr"] = dof_qposadr
     A["hip_link_free"] = link_free
+    # per link: the dofs of its whole ancestor chain, root first (the wave kernel's velocity / acceleration pass accumulates them in
+    # one sweep per lane instead of level by level).  entry = dof | index-within-a-free-joint << 8 | is-free-joint << 12
+    chain_adr = np.zeros(nl + 1, np.int32)
+    chain = []
+    for l in range(nl):
+        path = []
+        k = l
+        while k >= 0:
+            path.append(k)
+            k = int(link_parent[k])
+        for k in reversed(path):
+            for j in range(int(link_dofnum[k])):
+                chain.append(int(link_dofadr[k]) + j + ((j << 8) | (1 << 12) if link_free[k] else 0))
+        chain_adr[l + 1] = len(chain)
+    A["hip_link_chain_adr"] = chain_adr
+    A["hip_link_chain"] = np.array(chain, np.int32)
     A["hip_flags"] = np.array([int(has_free), int(A["sizes"][0]), neq], np.int32)
     A["hip_sizes"] = np.array([nl, nlevel, nv, nu, ngt, len(segs), len(dls), maxnnz, len(wgs), len(cgs), len(pairs_i),
                                maxkc, ns, len(cols), len(childs), pruned], np.int32)
