@@ -121,7 +121,7 @@ static void build_layout_w(const DevModel& d, DevModelW& w, int nvt, int kc, int
   int nv = d.nv, nu = d.nu, nl = d.nl;
   Y.qpos = take(w.nq); Y.qvel = take(nv); Y.act = take(nu); Y.ctrl = take(nu);
   Y.lpos = take(3 * nl); Y.lmat = take(9 * nl); Y.axis = take(3 * nv); Y.anchor = take(3 * nv);
-  Y.xv = take(nvt); Y.qfc = take(nvt); Y.sq = take(nvt * (nvt + 1));
+  Y.xv = take(nvt); Y.qfc = take(nvt); Y.sq = take(nvt * (nvt + 1)); Y.mprw = take(4 * MPRW);
   Y.tJp = w.has_tl ? take(d.ngt * d.maxnnz) : 0;
   Y.X = o;
   Y.tJ = take(d.ngt * d.maxnnz); Y.tlen = take(d.ngt); Y.tforce = take(nu); Y.seglen = take(d.nseg); Y.dlval = take(w.ndl);

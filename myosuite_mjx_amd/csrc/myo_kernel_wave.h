@@ -13,8 +13,9 @@
 //  * the LDS slice is <= 10 KB so 16 envs (= 16 waves, 4 per SIMD) are resident per CU.
 // ================================================================================================
 #define NCONW 32
+#define MPRW 14    // entries of the MPR warm-start table (pair id + normal): 224 B, the hand slice stays within 10 240 B = 16 waves per CU
 struct LayW {
-  int qpos, qvel, act, ctrl, lpos, lmat, axis, anchor, xv, qfc, sq, X;
+  int qpos, qvel, act, ctrl, lpos, lmat, axis, anchor, xv, qfc, sq, mprw, X;
   int tJ, tlen, tforce, seglen, dlval;            // region X, tendon phase
   int cdof, cinert, crb, cvel, cacc, cfrc;        // region X, dynamics phase
   int gpos, gax, cand, cdist, cpos, cnrm, cpair, cJ, cdofs;  // region X, collision + solver phase
@@ -314,6 +315,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     d_iter = a2; f_cand = a4 & 0xFFFF; f_ncon = a4 >> 16; f_mpr = a5; f_itcon = a6 & 0xFFFF; f_iter = a6 >> 16; f_ls = a7 & 0xFFFF; f_fact = a7 >> 16;
   }
   bool alive = true;
+  int n_mprw = 0;   // MPR warm-start table (pair id + last contact normal in geom 1's frame): entries of the previous substep
   SYNC();
   for (int step = s0; step < s1; step++) {
     const bool op = walk && step == nsub;   // observation pass: position / velocity stages at the post-step state, then out
@@ -762,11 +764,14 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       }
       if (ncand > NCAND) { flags |= MYO_FLAG_CAND_OVERFLOW; ncand = NCAND; }
       f_cand += ncand;
+      int n_mprw_new = 0;
       SYNC();
       STAMP(6);
       for (int base = 0; base < ncand; base += 64) {
         int ci = base + lane;
         int nsup = -8;                    // support evaluations of this lane's MPR refinement (-8: not an MPR pair)
+        bool mpr_hit = false;             // this lane's MPR call found a contact: its normal seeds the next substep's call
+        float mpr_n[3] = {0.f, 0.f, 0.f};
         bool hit = false, hit2 = false;   // a plane-capsule pair can give two contacts (one per end sphere)
         float dist = 0, dist2 = 0, cpos[3] = {0, 0, 0}, cpos2[3] = {0, 0, 0}, nrm[3] = {1, 0, 0};
         int p = -1;
@@ -863,10 +868,15 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             for (int k = 0; k < 3; k++) o1.pos[k] = 0.f;
             cobj_shape(o1, M.cg_type[g1], sz1); cobj_shape(o2, M.cg_type[g2], sz2);
             o1.margin = o2.margin = 0.5f * margin;
-            float depth, dir[3], pos[3];
-            if (mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup)) {
+            float depth, dir[3], pos[3], nw[3] = {0.f, 0.f, 0.f};
+            bool have_nw = false;
+            for (int i = 0; i < n_mprw; i++) {
+              if (((const int*)(E + Y.mprw))[4 * i] == p) { nw[0] = E[Y.mprw + 4 * i + 1]; nw[1] = E[Y.mprw + 4 * i + 2]; nw[2] = E[Y.mprw + 4 * i + 3]; have_nw = true; }
+            }
+            if (mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr)) {
               dist = margin - depth;
               normalize3(dir);
+              mpr_hit = true; mpr_n[0] = dir[0]; mpr_n[1] = dir[1]; mpr_n[2] = dir[2];
               float dw[3], pw[3];
               matvec(dw, R1, dir);
               matvec(pw, R1, pos);
@@ -885,6 +895,16 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           w = max(w, __builtin_amdgcn_update_dpp(0, w, 0x141, 0xf, 0xf, true));
           w = max(w, __builtin_amdgcn_update_dpp(0, w, 0x140, 0xf, 0xf, true));
           f_mpr += max(max(rdlanei(w, 0), rdlanei(w, 16)), max(rdlanei(w, 32), rdlanei(w, 48)));
+        }
+        {  // rebuild the warm-start table from this round's MPR contacts (all lookups of the round are done)
+          SYNC();
+          unsigned long long wb = __ballot(mpr_hit);
+          int wpos = n_mprw_new + __popcll(wb & ((1ull << lane) - 1ull));
+          if (mpr_hit && wpos < MPRW) {
+            ((int*)(E + Y.mprw))[4 * wpos] = p;
+            E[Y.mprw + 4 * wpos + 1] = mpr_n[0]; E[Y.mprw + 4 * wpos + 2] = mpr_n[1]; E[Y.mprw + 4 * wpos + 3] = mpr_n[2];
+          }
+          n_mprw_new = min(n_mprw_new + (int)__popcll(wb), MPRW);
         }
         unsigned long long bal = __ballot(hit);
         int pos = ncon + __popcll(bal & ((1ull << lane) - 1ull));
@@ -908,8 +928,9 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         }
       }
       if (ncon > NC) { flags |= MYO_FLAG_CONTACT_OVERFLOW; ncon = NC; }
+      n_mprw = n_mprw_new;
       SYNC();
-    }
+    } else n_mprw = 0;
     STAMP(4);
     // ---------------------------------------------------------------- constraint rows (registers: lane = dof / lane = contact)
     float lsign = 0.f, laref = 0.f, lD = 0.f;

@@ -315,12 +315,41 @@ __device__ __forceinline__ void expand_portal(Sup* p, const Sup& v4) {
   if (dot3(p[1].v, va) > 0) { if (dot3(p[2].v, va) > 0) p[1] = v4; else p[3] = v4; }
   else { if (dot3(p[3].v, va) > 0) p[2] = v4; else p[1] = v4; }
 }
-__device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup = nullptr) {
+// nwarm (optional): the contact normal this pair had in the previous substep of the same env step, in geom 1's frame.  Three support
+// points a small angle around it form a portal that is already ~R eps^2 / 2 flat; if the origin ray passes through it, portal
+// discovery and the first ~10 halving steps are skipped.  Otherwise (pair moved too much, new contact) the cold path runs.
+#ifndef MPR_WARM_EPS
+#define MPR_WARM_EPS 0.05f
+#endif
+__device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup = nullptr,
+                                const float* nwarm = nullptr) {
   Sup p[4];
   float dir[3], va[3], vb[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) { p[0].v1[k] = o1.pos[k]; p[0].v[k] = o1.pos[k] - o2.pos[k]; }
   if (norm3(p[0].v) < MINVALF) p[0].v[0] += 1e-5f;
+  bool warm_ok = false;
+  if (nwarm) {
+    float t1[3], t2[3];
+    make_frame(nwarm, t1, t2);
+    bool beyond = true;
+#pragma unroll
+    for (int k = 1; k <= 3; k++) {
+      const float c = k == 1 ? 1.f : -0.5f, sn = k == 1 ? 0.f : (k == 2 ? 0.8660254f : -0.8660254f);
+#pragma unroll
+      for (int i = 0; i < 3; i++) dir[i] = nwarm[i] + MPR_WARM_EPS * (c * t1[i] + sn * t2[i]);
+      normalize3(dir);
+      mink_support(o1, o2, dir, p[k]);
+      beyond = beyond && dot3(p[k].v, dir) >= 0;
+    }
+    float s12, s23, s31;
+    cross3(va, p[1].v, p[2].v); s12 = dot3(va, p[0].v);
+    cross3(va, p[2].v, p[3].v); s23 = dot3(va, p[0].v);
+    cross3(va, p[3].v, p[1].v); s31 = dot3(va, p[0].v);
+    if (beyond && s12 >= 0 && s23 >= 0 && s31 >= 0) { Sup t = p[2]; p[2] = p[3]; p[3] = t; warm_ok = true; }   // cold-path winding: all three <= 0
+    else warm_ok = beyond && s12 <= 0 && s23 <= 0 && s31 <= 0;
+  }
+  if (!warm_ok) {
   dir[0] = -p[0].v[0]; dir[1] = -p[0].v[1]; dir[2] = -p[0].v[2];
   normalize3(dir);
   mink_support(o1, o2, dir, p[1]);
@@ -358,6 +387,7 @@ __device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int m
     cross3(dir, va, vb);
     normalize3(dir);
   }
+  }  // cold portal discovery
   for (int it = 0;; it++) {
     if (it > maxit) return false;
     portal_dir(p, dir);
