@@ -106,3 +106,34 @@ def test_sim_scene_style_inline_model(tmp_path):
     for _ in range(10):
         assert o.step(1) == 0
     assert abs(o.time - 10 * 0.002) < 1e-12 and np.isfinite(o.field("qpos")).all()
+
+
+@pytest.mark.parametrize("name", ["hand", "finger", "legs"])
+def test_lowering_tables_are_consistent(name, request):
+    """Host-side invariants of the tables the wave kernel relies on: ancestor-dof chains are root-first and end with the link's own
+    dofs; the folded constant tendon lengths plus the remaining segments reproduce the numpy tendon lengths at qpos0; the
+    size signature the size-specialised kernel instantiations check."""
+    from myosuite_mjx_amd import setconst as sc
+    m = request.getfixturevalue(name)
+    A = m.arrays
+    nl = int(A["hip_sizes"][0])
+    par, da, dn = A["hip_link_parent"], A["hip_link_dofadr"], A["hip_link_dofnum"]
+    adr, chain = A["hip_link_chain_adr"], A["hip_link_chain"]
+    assert len(adr) == nl + 1 and adr[-1] == len(chain)
+    for l in range(nl):
+        dofs = [int(e) & 255 for e in chain[adr[l]:adr[l + 1]]]
+        want, k = [], l
+        while k >= 0:
+            want = list(range(int(da[k]), int(da[k]) + int(dn[k]))) + want
+            k = int(par[k])
+        assert dofs == want, (l, dofs, want)
+        free_flags = [(int(e) >> 12) & 1 for e in chain[adr[l]:adr[l + 1]]]
+        assert all(f == int(A["hip_link_free"][int(A["hip_dof_link"][d])]) for f, d in zip(free_flags, dofs))
+    # tendon lengths at qpos0: constant (folded) part + the kernel's segments == numpy tendon routine
+    L, _ = sc.tendons(m, np.asarray(m.qpos0, float), want_jac=False) if "want_jac" in sc.tendons.__code__.co_varnames else sc.tendons(m, np.asarray(m.qpos0, float))
+    gt = A["hip_gt_tendon"]
+    assert (A["hip_gt_len0"] >= 0).all() and (A["hip_gt_len0"] <= np.asarray(L)[gt] + 1e-12).all()
+    if name == "hand":
+        assert tuple(int(x) for x in A["hip_sizes"][[2, 3, 0, 1, 7, 5, 9, 10]]) == (23, 39, 17, 5, 7, 116, 27, 289)     # Sizes<1> in csrc/myo_kernel_wave.h
+    if name == "legs":
+        assert tuple(int(x) for x in A["hip_sizes"][[2, 3, 0, 1, 7, 5, 9, 10]]) == (34, 80, 13, 6, 11, 100, 32, 45)     # Sizes<2>
