@@ -217,3 +217,39 @@ def test_async_bench_rollout_interleaves_with_stream_work():
     assert torch.equal(e_sync.view(capi.F_OBS), e_async.view(capi.F_OBS))          # same steps, same results
     assert torch.equal(sink[512:], obs)
     assert e_async.batch.last_kernel_ms() == k_async                               # nothing pending: value is kept
+
+
+def test_bench_multi_gpu_loop_with_a_stand_in_collective():
+    """bench.py's N > 1 loop (async steps, staging copy, deferred wait on the previous gather) with the RCCL all-gather replaced by a
+    side-stream device copy that has the same handle contract (.wait() = stream-side wait)."""
+    import importlib.util, os, torch
+    from myosuite_mjx_amd import capi
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    env = _make("myoHandPoseRandom-v0", 512, seed=5)
+    ref = _make("myoHandPoseRandom-v0", 512, seed=5)
+    env.reset(seed=5); ref.reset(seed=5)
+    obs = env.view(capi.F_OBS)
+    staging = torch.empty_like(obs)
+    gathered = torch.zeros((2 * 512, env.obs_dim), device=obs.device)
+    side = torch.cuda.Stream()
+
+    class Handle:
+        def __init__(self, ev): self.ev = ev
+        def wait(self): torch.cuda.current_stream().wait_event(self.ev)
+
+    def gather_async(src):
+        ready = torch.cuda.Event(); ready.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            gathered[512:].copy_(src, non_blocking=True)
+            done = torch.cuda.Event(); done.record()
+        return Handle(done)
+
+    st = torch.cuda.current_stream().cuda_stream
+    mode = capi.BENCH_OBS | capi.BENCH_FRESH_ACTIONS | capi.BENCH_AUTORESET
+    ms, kms = bench.rollout_multi(torch, env, 15, mode, st, obs, staging, gather_async)
+    ref.batch.bench_rollout(15, 10, 0, mode, 100, st)
+    torch.cuda.synchronize()
+    assert ms > 0 and 0 < kms <= ms * 1.05
+    assert torch.equal(obs, ref.view(capi.F_OBS)) and torch.equal(gathered[512:], obs)
