@@ -124,7 +124,7 @@ static void build_layout_w(const DevModel& d, DevModelW& w, int nvt, int kc, int
   Y.xv = take(nvt); Y.qfc = take(nvt); Y.sq = take(nvt * (nvt + 1)); Y.mprw = take(4 * MPRW);
   Y.tJp = w.has_tl ? take(d.ngt * d.maxnnz) : 0;
   Y.X = o;
-  Y.tJ = take(d.ngt * d.maxnnz); Y.tlen = take(d.ngt); Y.tforce = take(nu); Y.seglen = take(d.nseg); Y.dlval = take(w.ndl);
+  Y.tJ = take(d.ngt * d.maxnnz); Y.tlen = take(d.ngt); Y.tforce = take(nu);
   int endT = o;
   o = Y.X;
   Y.cdof = take(6 * nv); Y.cinert = take(10 * nl); Y.crb = take(10 * nl); Y.cvel = take(6 * nl); Y.cacc = take(6 * nl); Y.cfrc = take(6 * nl);

@@ -16,7 +16,7 @@
 #define MPRW 14    // entries of the MPR warm-start table (pair id + normal): 224 B, the hand slice stays within 10 240 B = 16 waves per CU
 struct LayW {
   int qpos, qvel, act, ctrl, lpos, lmat, axis, anchor, xv, qfc, sq, mprw, X;
-  int tJ, tlen, tforce, seglen, dlval;            // region X, tendon phase
+  int tJ, tlen, tforce;                           // region X, tendon phase
   int cdof, cinert, crb, cvel, cacc, cfrc;        // region X, dynamics phase
   int gpos, gax, cand, cdist, cpos, cnrm, cpair, cJ, cdofs;  // region X, collision + solver phase
   int Mp;                                                     // packed mass matrix, aliases gpos/gax/cand once the contact rows exist
@@ -130,8 +130,10 @@ __device__ __forceinline__ void geom_world_mat(const DevModel& M, const LayW& Y,
     matmul3(R, E + Y.lmat + 9 * l, M.cg_lmat + 9 * g);
   }
 }
-// moment-arm entries of one straight tendon piece into dlval[]
-__device__ __forceinline__ float straight_w(const DevModel& M, const LayW& Y, float* E, const float* pa, const float* pb, int adr, int n,
+// moment-arm entries of one straight tendon piece
+// Jt = this tendon's sparse jacobian row in LDS (zeroed before the segment rounds): the entries are accumulated with LDS float atomics
+// by the segment lanes themselves (one wave: deterministic order) instead of being gathered entry by entry by the tendon's lane
+__device__ __forceinline__ float straight_w(const DevModel& M, const LayW& Y, float* E, float* Jt, const float* pa, const float* pb, int adr, int n,
                                             float invdiv, bool active) {
   float dif[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
   float dist = norm3(dif);
@@ -148,7 +150,7 @@ __device__ __forceinline__ float straight_w(const DevModel& M, const LayW& Y, fl
       cross3(c, ax, r);
       col = dot3(dif, c);
     } else col = dot3(dif, ax);
-    E[Y.dlval + adr + k] = active ? (float)e[1] * col * invdiv : 0.f;
+    if (active) atomicAdd(&Jt[e[2]], (float)e[1] * col * invdiv);
   }
   return active ? dist * invdiv : 0.f;
 }
@@ -404,6 +406,9 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     SUB0();
     // ---------------------------------------------------------------- tendons: lane = segment
     float tlen_r[NTR], tvel_r[NTR];
+    WFOR(i, ngt_ * maxnnz_) E[Y.tJ + i] = 0.f;
+    WFOR(i, ngt_) E[Y.tlen + i] = M.gt_len0[i];   // constant same-link segments, folded at lowering time
+    SYNC();
     for (int base = 0; base < nseg_; base += 64) {
       int idx = base + lane;
       if (idx < nseg_) {
@@ -432,14 +437,17 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           if (S[3] >= 0) site_world_w(M, Y, E, S[3], side);
           wlen = wrap_geom(wp, p0, p1, gpos, gmat, M.wg_radius[g], S[10] != 0, side, S[3] >= 0);
         }
+        SUB(7);
         bool wr = wlen >= 0;
-        float L = straight_w(M, Y, E, p0, p1, S[4], S[5], invdiv, !wr);
+        const int gts = W.seg_tendon[si];
+        float* Jt = E + Y.tJ + gts * maxnnz_;
+        float L = straight_w(M, Y, E, Jt, p0, p1, S[4], S[5], invdiv, !wr);
         if (S[2] >= 0) {
-          L += straight_w(M, Y, E, p0, wp, S[6], S[7], invdiv, wr);
-          L += straight_w(M, Y, E, wp + 3, p1, S[8], S[9], invdiv, wr);
+          L += straight_w(M, Y, E, Jt, p0, wp, S[6], S[7], invdiv, wr);
+          L += straight_w(M, Y, E, Jt, wp + 3, p1, S[8], S[9], invdiv, wr);
           if (wr) L += wlen * invdiv;
         }
-        E[Y.seglen + si] = L;
+        atomicAdd(&E[Y.tlen + gts], L);
       }
     }
     SYNC();
@@ -449,13 +457,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       int gt = lane + 64 * rr;
       tlen_r[rr] = 0.f; tvel_r[rr] = 0.f;
       if (gt >= ngt_) continue;
-      float* Jrow = E + Y.tJ + gt * maxnnz_;
-      for (int k = 0; k < maxnnz_; k++) Jrow[k] = 0;
-      float L = M.gt_len0[gt];   // constant same-link segments, folded at lowering time
-      for (int si = M.gt_seg_adr[gt]; si < M.gt_seg_adr[gt] + M.gt_seg_num[gt]; si++) L += E[Y.seglen + si];
-      int e0 = W.gt_dl[2 * gt], en = W.gt_dl[2 * gt + 1];
-      for (int e = e0; e < e0 + en; e++) Jrow[M.dl[3 * e + 2]] += E[Y.dlval + e];
-      E[Y.tlen + gt] = L;
+      const float* Jrow = E + Y.tJ + gt * maxnnz_;
+      const float L = E[Y.tlen + gt];
       tlen_r[rr] = L;
       float vel = 0;
       for (int k = 0; k < maxnnz_; k++) {

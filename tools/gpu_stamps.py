@@ -25,7 +25,7 @@ for lanes, bal in ((64, 0), (64, 1)):
     for k, n in enumerate(NAMES):
         print(f"   {n:26s} {st[:,k].mean()/10:12,.0f} cycles/substep  {100*st[:,k].mean()/tot.mean():5.1f}%")
     SUBN = ["newton: forces, cost, gradient, convergence test", "newton: Hessian assembly", "newton+euler: build rows, Cholesky, store L", "newton+euler: triangular solves",
-            "newton: M*search, J*search", "newton: line search", "newton: start (M*warm, J*warm)", "-", "tendons: segments (wrap + straight)", "tendons: gather + muscle",
+            "newton: M*search, J*search", "newton: line search", "newton: start (M*warm, J*warm)", "tendons: site / geom frames + wrap geometry", "tendons: moment arms of the straight pieces", "tendons: gather + muscle",
             "dynamics: cinert, cdof", "dynamics: RNE forward / backward, M assembly"]
     for k, n in enumerate(SUBN):
         if n != "-":
