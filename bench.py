@@ -24,6 +24,8 @@ B_ALG = 1560.0          # algorithmic HBM bytes per env-step, MyoHand pose (SURV
 F_ALG_EST = 1.2e6       # flop per env-step: SURVEY.md 8d ESTIMATE (1.0-1.5 Mflop), not an instrumented count
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md
 FP32_PEAK_TFLOPS = 157.3
+N_SIMD = 256 * 4        # MI355X_MICROARCH.md: 256 CUs, 4 SIMDs each
+CLOCK_HZ = 2.4e9        # max engine clock
 
 
 def cpu_baseline(seconds_target=12.0):
@@ -144,11 +146,13 @@ def main():
     # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process; the value is
     # the committed rocprofv3 measurement of the same kernel / batch (profiles/, separate FETCH_SIZE / WRITE_SIZE passes)
     traffic = None
+    valu_insts = None
     try:
         with open(os.path.join(ROOT, "profiles", "r1_f_pmc_step_kernel_hand.json")) as f:
-            t = json.load(f)["traffic"]
+            pmc = json.load(f)
         if B == B_PER_GPU and env_id == ENV_ID:
-            traffic = t["hbm_bytes_per_launch_raw"]
+            traffic = pmc["traffic"]["hbm_bytes_per_launch_raw"]
+            valu_insts = pmc["counters"]["SQ_INSTS_VALU"]["mean_per_launch"]
     except Exception:
         pass
     if rank == 0:
@@ -173,7 +177,13 @@ def main():
                          "alg_bytes_per_launch": b_alg * B,
                          "note": "path is FP32-VALU/latency bound, not HBM bound (SURVEY.md 8d); fp32 view alongside",
                          "fp32": {"achieved_tflops_est": F_ALG_EST * B / (k_ms * 1e-3) / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
-                                  "frac_est": F_ALG_EST * B / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "flop_per_env_step": "SURVEY 8d estimate"}},
+                                  "frac_est": F_ALG_EST * B / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "flop_per_env_step": "SURVEY 8d estimate"},
+                         # the resource that actually binds this kernel: VALU issue slots (one wave64 VALU instruction per SIMD per 4 cycles).
+                         # instruction count = committed rocprofv3 SQ_INSTS_VALU of the same kernel / batch, time = this run's kernel time
+                         "valu_issue": None if valu_insts is None else {
+                             "wave_insts_per_launch": valu_insts, "peak_wave_insts_per_s": N_SIMD * CLOCK_HZ / 4.0,
+                             "frac": valu_insts / (k_ms * 1e-3) / (N_SIMD * CLOCK_HZ / 4.0),
+                             "note": "share of the chip's VALU issue slots used over the whole launch (256 CUs x 4 SIMDs, 2.4 GHz)"}},
             "event_ms_per_step_rank0": ev_ms / args.steps,
             "flagged_envs": int((flags != 0).sum()),
         }
