@@ -327,7 +327,7 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   BA(d.qpos, (size_t)B * nq) BA(d.qvel, (size_t)B * nv) BA(d.act, (size_t)B * nu) BA(d.ctrl, (size_t)B * nu) BA(d.warm, (size_t)B * nv)
   BA(d.time, B) BA(d.target, (size_t)B * b->ntarget_alloc) BA(d.obs, (size_t)B * b->obs_alloc) BA(d.reward, B) BA(d.done, B)
   BA(d.solved, B) BA(d.qacc, (size_t)B * nv) BA(d.tenlen, (size_t)B * nu) BA(d.actforce, (size_t)B * nu) BA(d.sitexpos, (size_t)B * 24)
-  BA(d.flags, B) BA(d.diag, (size_t)B * 8) BA(d.elapsed, B) BA(d.episode, B)
+  BA(d.flags, B) BA(d.diag, (size_t)B * 8) BA(d.elapsed, B) BA(d.episode, B) BA(d.mprw, (size_t)B * 64)
   BA(b->d_tlo, b->ntarget_alloc) BA(b->d_thi, b->ntarget_alloc) BA(b->d_init, nq) BA(b->d_jlo, nv) BA(b->d_jhi, nv)
   BA(b->d_action, (size_t)B * nu)
   BA(d.fatigue, (size_t)B * 3 * nu)

@@ -14,6 +14,7 @@
 // ================================================================================================
 #define NCONW 32
 #define MPRW 14    // entries of the MPR warm-start table (pair id + normal): 224 B, the hand slice stays within 10 240 B = 16 waves per CU
+static_assert(4 * MPRW <= 63, "the scheduler carries the table in a 64-word row (word 63 = entry count)");
 struct LayW {
   int qpos, qvel, act, ctrl, lpos, lmat, axis, anchor, xv, qfc, sq, mprw, X;
   int tJ, tlen, tforce;                           // region X, tendon phase
@@ -318,6 +319,12 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   }
   bool alive = true;
   int n_mprw = 0;   // MPR warm-start table (pair id + last contact normal in geom 1's frame): entries of the previous substep
+  if (SCHED && s0 > 0) {   // ... which another wave ran: the table travels through the batch like the state rows, so that a scheduled
+    // launch computes exactly what the one-wave-per-env launch does
+    const int* Wt = Bt.mprw + (size_t)env * 64;
+    n_mprw = __builtin_amdgcn_readfirstlane(ldstatei<SCHED>(Wt + 63));
+    if (lane_id < 4 * n_mprw) ((int*)(E + Y.mprw))[lane_id] = ldstatei<SCHED>(Wt + lane_id);
+  }
   SYNC();
   for (int step = s0; step < s1; step++) {
     const bool op = walk && step == nsub;   // observation pass: position / velocity stages at the post-step state, then out
@@ -1355,6 +1362,11 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   for (int i = lane_id; i < nu; i += 64) {
     Bt.act[(size_t)env * nu + i] = E[Y.act + i];
     Bt.ctrl[(size_t)env * nu + i] = E[Y.ctrl + i];
+  }
+  if (SCHED && s1 < nsubtot) {
+    int* Wt = Bt.mprw + (size_t)env * 64;
+    if (lane_id < 4 * n_mprw) Wt[lane_id] = ((const int*)(E + Y.mprw))[lane_id];
+    if (lane_id == 63) Wt[63] = n_mprw;
   }
   if (lane_id == 0) {
     Bt.time[env] = time;
