@@ -66,6 +66,14 @@ def _reach_spec(random, far_th):
                 weights=dict(reach=1.0, bonus=4.0, penalty=50.0, act_reg=0.0))
 
 
+def _reach_box_spec(model, tips, lo, hi, far_th, max_episode_steps=100, frame_skip=10):
+    """ReachEnvV0 with target_reach_range given as absolute boxes (reach_v0.py:147-153: the target is always re-drawn at reset)."""
+    return dict(model=model, task="reach", max_episode_steps=max_episode_steps, frame_skip=frame_skip, normalize_act=True,
+                target_lo=np.asarray(lo, float).ravel(), target_hi=np.asarray(hi, float).ravel(), tips=tuple(tips), far_th=far_th,
+                reset_type="init", target_type="generate",
+                weights=dict(reach=1.0, bonus=4.0, penalty=50.0, act_reg=0.0))
+
+
 REGISTRY = {
     "myoHandPoseFixed-v0": _pose_spec(HAND_POSE_FIXED, HAND_POSE_FIXED, "init", "fixed"),
     "myoHandPoseRandom-v0": _pose_spec(ASL_QPOS.min(0), ASL_QPOS.max(0), "random", "generate"),
@@ -76,6 +84,12 @@ REGISTRY = {
 # target "generate", pose_thd 0.35 (pose_v0.py:46-57)
 REGISTRY["myoFingerPoseFixed-v0"] = _pose_spec([0, 0, 0.75, 0.75], [0, 0, 0.75, 0.75], "init", "generate", 0.35, "myofinger_v0")
 REGISTRY["myoFingerPoseRandom-v0"] = _pose_spec([-0.2, -0.4, 0.1, 0.1], [0.2, 1.0, 1.0, 1.0], "init", "generate", 0.35, "myofinger_v0")
+# myoElbowPose1D6M*-v0 (envs/myo/myobase/__init__.py:108-137): 1-dof elbow with 6 muscles, reset "random", pose_thd 0.175
+REGISTRY["myoElbowPose1D6MFixed-v0"] = _pose_spec([2.0], [2.0], "random", "generate", 0.175, "myoelbow_1dof6muscles")
+REGISTRY["myoElbowPose1D6MRandom-v0"] = _pose_spec([0.0], [2.27], "random", "generate", 0.175, "myoelbow_1dof6muscles")
+# myoFingerReach*-v0 (envs/myo/myobase/__init__.py:82-105): IFtip to an absolute target box; far_th = ReachEnvV0's default 0.35
+REGISTRY["myoFingerReachFixed-v0"] = _reach_box_spec("myofinger_v0", ("IFtip",), [(0.2, 0.05, 0.20)], [(0.2, 0.05, 0.20)], 0.35)
+REGISTRY["myoFingerReachRandom-v0"] = _reach_box_spec("myofinger_v0", ("IFtip",), [(0.1, -0.1, 0.1)], [(0.27, 0.1, 0.3)], 0.35)
 for _k in range(10):
     REGISTRY[f"myoHandPose{_k}Fixed-v0"] = _pose_spec(ASL_QPOS[_k], ASL_QPOS[_k], "init", "fixed")
 # myoLegWalk-v0 (envs/myo/myobase/__init__.py:443-459; WalkEnvV0 defaults walk_v0.py:187-266)

@@ -826,9 +826,16 @@ class _Compiler:
         wrap_geoms = {w["obj"] for w in self.wraps if w["type"] == -1}
         keep = [i for i, g in enumerate(self.geoms)
                 if (g["contype"] or g["conaffinity"]) or (g["name"] and g["name"] in wrap_geoms)]
-        for i in keep:
+        # mesh geoms: visual unless their contype / conaffinity bits can match some other geom's (myoelbow: contype 1, conaffinity 0
+        # everywhere -> nothing collides and the bone meshes only contribute inertia)
+        def _can_pair(i):
+            a = self.geoms[i]
+            return any(j != i and ((a["contype"] & b["conaffinity"]) or (b["contype"] & a["conaffinity"])) for j, b in enumerate(self.geoms))
+        for i in list(keep):
             if self.geoms[i]["type"] == GEOM_MESH:
-                raise NotImplementedError("colliding mesh geoms")
+                if _can_pair(i):
+                    raise NotImplementedError("colliding mesh geoms")
+                keep.remove(i)
         # explicit pairs may name geoms that neither collide dynamically nor wrap: keep them too
         pair_names = {pr[k] for pr in self.pairs for k in ("geom1", "geom2")}
         keep = sorted(set(keep) | {i for i, g in enumerate(self.geoms) if g["name"] and g["name"] in pair_names})

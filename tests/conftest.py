@@ -30,6 +30,12 @@ def legs():
 
 
 @pytest.fixture(scope="session")
+def elbow():
+    from myosuite_mjx_amd import model as M
+    return M.load_asset("myoelbow_1dof6muscles")
+
+
+@pytest.fixture(scope="session")
 def oracle64(hand):
     from oracle.oracle import Oracle
     return Oracle(hand.blob())

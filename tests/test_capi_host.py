@@ -73,6 +73,12 @@ def test_registry_matches_reference_specs():
     assert lw["weights"] == dict(vel_reward=5.0, done=-100.0, cyclic_hip=-10.0, ref_rot=10.0, joint_angle_rew=5.0)
     ff = REGISTRY["myoFingerPoseFixed-v0"]                       # envs/myo/myobase/__init__.py:222-236
     assert ff["model"] == "myofinger_v0" and ff["pose_thd"] == 0.35 and ff["target_lo"].tolist() == [0, 0, 0.75, 0.75]
+    eb = REGISTRY["myoElbowPose1D6MRandom-v0"]                   # envs/myo/myobase/__init__.py:123-137
+    assert eb["model"] == "myoelbow_1dof6muscles" and eb["pose_thd"] == 0.175 and eb["reset_type"] == "random"
+    assert eb["target_lo"].tolist() == [0.0] and eb["target_hi"].tolist() == [2.27] and REGISTRY["myoElbowPose1D6MFixed-v0"]["target_lo"].tolist() == [2.0]
+    fr = REGISTRY["myoFingerReachRandom-v0"]                     # envs/myo/myobase/__init__.py:94-105; far_th default reach_v0.py:47
+    assert fr["tips"] == ("IFtip",) and fr["far_th"] == 0.35 and fr["target_lo"].tolist() == [0.1, -0.1, 0.1] and fr["target_hi"].tolist() == [0.27, 0.1, 0.3]
+    assert "myoSarcElbowPose1D6MFixed-v0" in REGISTRY and "myoFatiFingerReachRandom-v0" in REGISTRY
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/myosuite"), reason="reference tree not present")

@@ -181,6 +181,21 @@ def test_finger_parity(finger, nsub):
     assert np.abs(g[2] - r[2]).max() < 1e-6
 
 
+@pytest.mark.parametrize("nsub", [1, 10])
+def test_elbow_parity(elbow, nsub):
+    """myoelbow_1dof6muscles: 1 dof, 6 muscles (sphere and cylinder wraps with side sites), no contacts, joint limit rows."""
+    rng = np.random.default_rng(30)
+    N, f32 = 128, np.float32
+    lo, hi = elbow.jnt_range[0]
+    st = (rng.uniform(lo - 0.1, hi + 0.1, (N, 1)).astype(f32), rng.normal(0, 1.0, (N, 1)).astype(f32),
+          rng.uniform(0, 1, (N, 6)).astype(f32), rng.uniform(0, 1, (N, 6)).astype(f32))
+    g, r = _finger_pair(elbow, elbow.blob(), *st, nsub)
+    assert (g[4] == 0).all() and r[3].max() >= 1
+    assert np.abs(g[0] - r[0]).max() < (2e-6 if nsub == 1 else 2e-5)
+    assert np.abs(g[1] - r[1]).max() < (1e-3 if nsub == 1 else 5e-3)
+    assert np.abs(g[2] - r[2]).max() < 1e-6
+
+
 def test_finger_tendon_limits_active(finger):
     """The shipped ranges (0..0.33 m) never bind; tighten them so the tendon-limit rows (lower and upper) are exercised."""
     from myosuite_mjx_amd import blob
@@ -209,6 +224,53 @@ def test_finger_env_config0():
         obs, rwd, term, trunc, info = env.step(0.01 * torch.rand((1, 5), device="cuda", generator=g))
         assert torch.isfinite(obs).all() and not term.any()
     assert trunc.all() and (env.status() == 0).all()
+
+
+def test_elbow_and_finger_reach_envs(elbow, finger):
+    """myoElbowPose1D6M{Fixed,Random}-v0 (obs 9 = qpos, qvel*dt, pose_err, act 6) and myoFingerReach{Fixed,Random}-v0 (obs 19 = qpos 4,
+    qvel 4, tip 3, reach_err 3, act 5): layouts, target boxes and reward formulas of pose_v0.py / reach_v0.py."""
+    import torch
+    import myosuite_mjx_amd as myo
+    from oracle.oracle import Oracle
+    for eid, tl, th in (("myoElbowPose1D6MFixed-v0", 2.0, 2.0), ("myoElbowPose1D6MRandom-v0", 0.0, 2.27)):
+        env = myo.make(eid, num_envs=64, seed=5, autoreset=False)
+        obs = env.reset(seed=5)
+        assert obs.shape == (64, 9) and env.max_episode_steps == 100 and abs(env.dt - 0.02) < 1e-9
+        st = env.get_env_state()
+        assert (st["target"] >= tl - 1e-6).all() and (st["target"] <= th + 1e-6).all()
+        assert (st["qpos"] >= elbow.jnt_range[0, 0] - 1e-6).all() and (st["qpos"] <= elbow.jnt_range[0, 1] + 1e-6).all() and st["qpos"].std() > 0.3
+        g = torch.Generator(device="cuda").manual_seed(1)
+        for _ in range(5):
+            obs, rwd, term, trunc, info = env.step(torch.rand((64, 6), device="cuda", generator=g) * 2 - 1)
+        st = env.get_env_state()
+        o = obs.cpu().numpy()
+        assert np.allclose(o[:, 0:1], st["qpos"], atol=1e-7) and np.allclose(o[:, 1:2], st["qvel"] * 0.02, atol=1e-6)
+        assert np.allclose(o[:, 2:3], st["target"] - st["qpos"], atol=1e-6) and np.allclose(o[:, 3:], st["act"], atol=1e-7)
+        dist = np.abs(o[:, 2])
+        ref = -dist + 4.0 * ((dist < 0.175) * 1.0 + (dist < 1.5 * 0.175) * 1.0) - np.linalg.norm(st["act"], axis=1) / 6 - 50.0 * (dist > 2 * np.pi)
+        assert np.allclose(rwd.cpu().numpy(), ref, atol=1e-5) and (env.status() == 0).all()
+    tip = finger.name2id("site", "IFtip")
+    orc = Oracle(finger.blob())
+    for eid, lo, hi in (("myoFingerReachFixed-v0", (0.2, 0.05, 0.2), (0.2, 0.05, 0.2)), ("myoFingerReachRandom-v0", (0.1, -0.1, 0.1), (0.27, 0.1, 0.3))):
+        env = myo.make(eid, num_envs=32, seed=6, autoreset=False)
+        obs = env.reset(seed=6)
+        assert obs.shape == (32, 19)
+        g = torch.Generator(device="cuda").manual_seed(2)
+        for _ in range(4):
+            obs, rwd, term, trunc, info = env.step(torch.rand((32, 5), device="cuda", generator=g) * 2 - 1)
+        st = env.get_env_state()
+        o = obs.cpu().numpy()
+        assert (st["target"] >= np.array(lo) - 1e-6).all() and (st["target"] <= np.array(hi) + 1e-6).all()
+        assert np.allclose(o[:, :4], st["qpos"], atol=1e-7) and np.allclose(o[:, 14:], st["act"], atol=1e-7)
+        for e in range(0, 32, 5):
+            orc.reset()
+            orc.set_state(qpos=st["qpos"][e])
+            orc.fwd_position()
+            assert np.abs(orc.field("site_xpos").reshape(-1, 3)[tip] - o[e, 8:11]).max() < 2e-6
+        assert np.allclose(o[:, 11:14], st["target"] - o[:, 8:11], atol=1e-6)
+        dist = np.linalg.norm(o[:, 11:14], axis=1)
+        ref = -dist + 4.0 * ((dist < 0.025) * 1.0 + (dist < 0.0125) * 1.0) - 50.0 * (dist > 0.35)     # t = 0.08 > 2 dt
+        assert np.allclose(rwd.cpu().numpy(), ref, atol=1e-5) and np.array_equal(term.cpu().numpy(), dist > 0.35)
 
 
 def test_size_specialised_and_generic_instantiations_agree(hand, legs):

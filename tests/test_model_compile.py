@@ -137,3 +137,20 @@ def test_lowering_tables_are_consistent(name, request):
         assert tuple(int(x) for x in A["hip_sizes"][[2, 3, 0, 1, 7, 5, 9, 10]]) == (23, 39, 17, 5, 7, 116, 27, 289)     # Sizes<1> in csrc/myo_kernel_wave.h
     if name == "legs":
         assert tuple(int(x) for x in A["hip_sizes"][[2, 3, 0, 1, 7, 5, 9, 10]]) == (34, 80, 13, 6, 11, 100, 32, 45)     # Sizes<2>
+
+
+def test_elbow_sizes(elbow):
+    # myoelbow_1dof6muscles.xml: one hinge, six muscles + the "error" visual tendon; geoms are contype 1 / conaffinity 0 so nothing
+    # collides and the bone meshes only contribute inertia (myoelbow_assets.xml:14-16)
+    assert (elbow.nq, elbow.nv, elbow.nu, elbow.ntendon) == (1, 1, 6, 7) and elbow.pair_geom.shape[0] == 0
+    assert np.allclose(elbow.jnt_range, [[0, 2.26893]]) and np.allclose(elbow.dof_damping, 0.5) and np.allclose(elbow.dof_armature, 0.01)
+    assert abs(elbow.timestep - 0.002) < 1e-12 and (elbow.actuator_has_lengthrange == 1).all()
+    assert (elbow.body_mass[-2:] > 1.0).all()                      # humerus / forearm masses from the bone meshes
+
+
+@needs_reference
+def test_elbow_asset_matches_fresh_compile(elbow):
+    from myosuite_mjx_amd import model as M
+    fresh = M.from_mjcf(os.path.join(REFERENCE, "envs/myo/assets/elbow/myoelbow_1dof6muscles.xml"))
+    for k, v in fresh.arrays.items():
+        assert np.allclose(np.asarray(v, float), np.asarray(elbow.arrays[k], float), rtol=0, atol=1e-12), k

@@ -271,3 +271,35 @@ def test_leg_f32_sensitivity(legs):
     assert np.isfinite(deep).all() and np.isfinite(mild).all()
     assert deep.max() > 1e-3
     assert np.median(mild) < 1e-4
+
+
+def test_elbow_lengthrange_goldens(elbow):
+    """MuJoCo-computed lengthranges stored in the reference's elbow model (myoelbow_1dof6muscles_body.xml <muscle lengthrange=...>):
+    the three single-joint muscles must reproduce them over the elbow's range (BRA, a cylinder-wrapped path, to 6 digits; the
+    biarticular TRIlong / BIClong / BICshort ranges were computed with the shoulder free and only bound the sweep)."""
+    from oracle.oracle import Oracle
+    o = Oracle(elbow.blob())
+    L = []
+    for q in np.linspace(elbow.jnt_range[0, 0], elbow.jnt_range[0, 1], 201):
+        o.reset()
+        o.set_state(qpos=[q])
+        o.fwd_position()
+        L.append(o.field("ten_length")[:6].copy())
+    L = np.array(L)
+    lr = elbow.actuator_lengthrange
+    span = lr[:, 1] - lr[:, 0]
+    rel_lo, rel_hi = (L.min(0) - lr[:, 0]) / span, (L.max(0) - lr[:, 1]) / span
+    names = elbow.names["actuator"]
+    for n, tol in (("BRA", 1e-5), ("TRIlat", 3e-3), ("TRImed", 2e-3)):
+        i = names.index(n)
+        assert abs(rel_lo[i]) < tol and abs(rel_hi[i]) < tol, (n, rel_lo[i], rel_hi[i])
+    for n in ("TRIlong", "BIClong"):
+        i = names.index(n)
+        assert rel_lo[i] > 0 and rel_hi[i] < 0
+    # and the stepper holds a loaded elbow inside its range
+    o.reset()
+    o.set_state(qpos=[1.0], ctrl=np.full(6, 0.3))
+    for _ in range(50):
+        assert o.step(10) == 0
+    q = o.field("qpos")[0]
+    assert elbow.jnt_range[0, 0] - 0.05 < q < elbow.jnt_range[0, 1] + 0.05

@@ -13,6 +13,7 @@ MODELS = {
     "myohand_pose": "myosuite/envs/myo/assets/hand/myohand_pose.xml",
     "myofinger_v0": "myosuite/simhive/myo_sim/finger/myofinger_v0.xml",
     "myolegs": "myosuite/simhive/myo_sim/leg/myolegs.xml",
+    "myoelbow_1dof6muscles": "myosuite/envs/myo/assets/elbow/myoelbow_1dof6muscles.xml",
 }
 
 if __name__ == "__main__":
