@@ -36,6 +36,8 @@ typedef struct myo_batch myo_batch;
 enum { MYO_OK = 0, MYO_E_ARG = -1, MYO_E_BLOB = -2, MYO_E_HIP = -3, MYO_E_UNSUPPORTED = -4, MYO_E_NOMEM = -5 };
 
 typedef struct myo_dims {
+  /* na = MuJoCo's na: actuators with an activation state (muscles).  Stateless actuators (<motor> etc.) still own a slot of the
+   * [B][nu]-wide MYO_F_ACT rows (kept at zero) so that actuator indices address every per-actuator field alike */
   int nq, nv, nu, na, nbody, ntendon, nsite, nlink, obs_dim, env_lds_bytes, lanes_per_env, ncon_max;
   float timestep;
 } myo_dims;
@@ -44,7 +46,7 @@ typedef struct myo_dims {
 typedef enum myo_field {
   MYO_F_QPOS = 0,    /* [B][nq] */
   MYO_F_QVEL,        /* [B][nv] */
-  MYO_F_ACT,         /* [B][na] */
+  MYO_F_ACT,         /* [B][nu]  activation per actuator (zero for stateless actuators) */
   MYO_F_CTRL,        /* [B][nu]  last applied control (after the action map) */
   MYO_F_WARMSTART,   /* [B][nv]  qacc_warmstart */
   MYO_F_TIME,        /* [B][1] */

@@ -64,6 +64,8 @@ struct DevModel {
   const int *cg_link, *cg_type, *pair_i, *pair_dl;
   const float *link_pos, *link_quat, *link_mass, *link_com, *link_inertia, *dof_pos, *dof_axis, *qpos0, *dof_damping,
       *dof_armature;
+  const int* act_obs;   // [nu] slot of the actuator's activation in the observation's act block (sim.data.act order), -1: stateless actuator
+  int na_obs;           // number of stateful (muscle) actuators = MuJoCo's na
   const float *site_lpos, *wg_lpos, *wg_lmat, *wg_radius, *seg_div, *gt_len0, *act, *cg_lpos, *cg_lmat, *cg_size, *cg_rbound,
       *pair_f, *jl;
   Lay lay;

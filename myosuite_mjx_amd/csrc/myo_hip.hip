@@ -44,6 +44,7 @@ struct myo_model {
   int wave_cfg = 0;             // 0: step_kernel_w<24,8,32,1,4> (hand / finger), 1: step_kernel_w<36,20,48,2,2> (legs)
   int nq = 0;
   int has_tl = 0;
+  bool has_affine = false;   // some actuator is a stateless affine one (motor / position / velocity): wave kernel only
   myo_dims dims{};
   std::vector<void*> dev_allocs;
   std::vector<float> qpos0, jnt_lo, jnt_hi;
@@ -252,13 +253,16 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
           (rc = load_i(m, blob, "hip_link_chain", &w.link_chain)) || (rc = load_i(m, blob, "hip_eq_i", &w.eq_i)) ||
           (rc = load_f(m, blob, "hip_eq_f", &w.eq_f)) || (rc = load_i(m, blob, "hip_pair_i", &tmpi, &pi))) { myo_model_free(m); return rc; }
       w.has_free = fl[0]; w.nq = fl[1]; w.neq = fl[2];
+      if (fl.size() < 6) { myo_model_free(m); return fail(MYO_E_BLOB, "hip_flags: blob predates the actuator-kind tables; recompile the model"); }
+      w.has_j0 = fl[3]; d.na_obs = fl[4]; m->has_affine = fl[5] != 0;
+      if ((rc = load_f(m, blob, "hip_gt_j0", &w.gt_j0)) || (rc = load_i(m, blob, "hip_act_obs", &d.act_obs))) { myo_model_free(m); return rc; }
       const float* tf;
       if ((rc = load_i(m, blob, "hip_body_link", &tmpi, &m->body_link)) || (rc = load_f(m, blob, "hip_body_lpos", &tf, &m->body_lpos)) ||
           (rc = load_f(m, blob, "hip_body_lquat", &tf, &m->body_lquat)) || (rc = load_f(m, blob, "hip_mass", &tf, &m->mass))) { myo_model_free(m); return rc; }
       if (w.nq != m->nq) { myo_model_free(m); return fail(MYO_E_BLOB, "hip_flags disagrees with sizes"); }
       for (int p = 0; p < d.npair; p++) { if (pi[6 * p + 4] >= 2) plane_pairs = true; if (pi[6 * p + 5] == 1) condim1 = true; }
       // the 16/32-lane generic kernel covers fixed-base models with hinge / slide joints and capsule / convex pairs only
-      m->generic_ok = !w.has_free && w.neq == 0 && !plane_pairs && !condim1 && w.nq == d.nv && d.maxkc <= KCMAX && !w.has_tl;
+      m->generic_ok = !w.has_free && w.neq == 0 && !plane_pairs && !condim1 && w.nq == d.nv && d.maxkc <= KCMAX && !w.has_tl && !m->has_affine;
     }
     const bool common = d.nl <= 64 && d.ncg <= 64 && w.nq <= 64 && w.neq <= 64 && d.maxnnz <= 20;
     const bool needs_full = w.has_free || w.neq > 0 || plane_pairs || condim1;
@@ -277,7 +281,7 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
     m->d_dm = (DevModel*)p1; m->d_dw = (DevModelW*)p2;
     if (hipMemcpy(p1, &d, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(p2, &w, sizeof(DevModelW), hipMemcpyHostToDevice) != hipSuccess) { myo_model_free(m); return fail(MYO_E_HIP, "upload model structs"); }
   }
-  m->dims = myo_dims{S[0], S[1], S[2], S[3], S[4], S[8], S[7], d.nl, 0, m->wave_ok ? m->env_lds_bytes_w : m->env_lds_bytes, 64,
+  m->dims = myo_dims{S[0], S[1], S[2], d.na_obs, S[4], S[8], S[7], d.nl, 0, m->wave_ok ? m->env_lds_bytes_w : m->env_lds_bytes, 64,
                      m->wave_ok ? (m->wave_cfg == 1 ? 32 : NCONW) : NCON, d.timestep};
   if (4 * m->env_lds_bytes > 160 * 1024) {
     if (!m->wave_ok) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "model working set exceeds 160 KB of LDS per workgroup"); }
@@ -385,8 +389,8 @@ int myo_batch_configure(myo_batch* b, const myo_task_config* c) {
   for (int i = 0; i < 8; i++) T.tip_site[i] = c->tip_site[i];
   T.pose_thd = c->pose_thd; T.far_th = c->far_th; T.near_th = c->near_th;
   T.w_pose = c->w_pose; T.w_bonus = c->w_bonus; T.w_act_reg = c->w_act_reg; T.w_penalty = c->w_penalty; T.w_reach = c->w_reach;
-  if (c->task == MYO_TASK_POSE) { if (c->ntarget != nv) return fail(MYO_E_ARG, "pose task: ntarget must equal nq"); T.obs_dim = 3 * nv + nu; }
-  else if (c->task == MYO_TASK_REACH) { if (c->ntarget != 3 * c->ntip) return fail(MYO_E_ARG, "reach task: ntarget must be 3*ntip"); T.obs_dim = 2 * nv + 6 * c->ntip + nu; }
+  if (c->task == MYO_TASK_POSE) { if (c->ntarget != nv) return fail(MYO_E_ARG, "pose task: ntarget must equal nq"); T.obs_dim = 3 * nv + b->model->dm.na_obs; }
+  else if (c->task == MYO_TASK_REACH) { if (c->ntarget != 3 * c->ntip) return fail(MYO_E_ARG, "reach task: ntarget must be 3*ntip"); T.obs_dim = 2 * nv + 6 * c->ntip + b->model->dm.na_obs; }
   else T.obs_dim = 0;
   if (T.obs_dim > b->obs_alloc) return fail(MYO_E_ARG, "obs_dim too large");
   if (c->ntarget > 0) {

@@ -31,6 +31,8 @@ struct DevModelW {
   int nwrapseg, ndl, has_tl;
   const float* tl;
   int nq, has_free, neq;          // free-floating root (nq = nv + 1), joint-coupling equalities
+  int has_j0;                     // some actuator drives a joint directly: constant moment arms gt_j0 [ngt][maxnnz]
+  const float* gt_j0;
   const int *link_free, *dof_qposadr, *eq_i, *link_chain_adr, *link_chain;
   const float* eq_f;
 };
@@ -413,8 +415,17 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     SUB0();
     // ---------------------------------------------------------------- tendons: lane = segment
     float tlen_r[NTR], tvel_r[NTR];
+    if (W.has_j0) {   // joint transmission: constant moment arm, length = arm * joint coordinate (mj_transmission, mjTRN_JOINT)
+      WFOR(i, ngt_ * maxnnz_) E[Y.tJ + i] = W.gt_j0[i];
+      WFOR(i, ngt_) {
+        float L = M.gt_len0[i];
+        for (int k = 0; k < maxnnz_; k++) { const float a = W.gt_j0[i * maxnnz_ + k]; if (a != 0.f) L += a * E[Y.qpos + W.dof_qposadr[M.gt_dofs[i * maxnnz_ + k]]]; }
+        E[Y.tlen + i] = L;
+      }
+    } else {
     WFOR(i, ngt_ * maxnnz_) E[Y.tJ + i] = 0.f;
     WFOR(i, ngt_) E[Y.tlen + i] = M.gt_len0[i];   // constant same-link segments, folded at lowering time
+    }
     SYNC();
     for (int base = 0; base < nseg_; base += 64) {
       int idx = base + lane;
@@ -477,7 +488,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       if (gt < nu) {
         const float* A = M.act + 16 * gt;
         float f, ad;
-        muscle(A, A[14] * L, A[14] * vel, E[Y.act + gt], E[Y.ctrl + gt], &f, &ad);
+        if (A[10] < 0.f) { f = A[0] * clipf(E[Y.ctrl + gt], A[12], A[13]) + A[1] + A[14] * (A[2] * L + A[3] * vel); ad = 0.f; }   // stateless affine actuator
+        else muscle(A, A[14] * L, A[14] * vel, E[Y.act + gt], E[Y.ctrl + gt], &f, &ad);
         actdot[rr] = ad;
         E[Y.tforce + gt] = f * A[14];
       }

@@ -157,10 +157,10 @@ __global__ void __launch_bounds__(64) obs_kernel(DevModel M, DevBatch Bt, TaskDe
       o[i] = qi; o[nv + i] = v[i] * dt; o[2 * nv + i] = pe;
       err2 += pe * pe;
     }
-    for (int i = lane; i < nu; i += 64) { float ai = a[i]; o[3 * nv + i] = ai; act2 += ai * ai; }
+    for (int i = lane; i < nu; i += 64) { float ai = a[i]; const int sl = M.act_obs[i]; if (sl >= 0) { o[3 * nv + sl] = ai; act2 += ai * ai; } }
     if (obs_only) return;
     float dist = sqrtf(wave_sum(err2));
-    float actn = sqrtf(wave_sum(act2)) / (float)(nu > 0 ? nu : 1);
+    float actn = sqrtf(wave_sum(act2)) / (float)(M.na_obs > 0 ? M.na_obs : 1);
     if (lane == 0) {
       float bonus = (dist < T.pose_thd ? 1.f : 0.f) + (dist < 1.5f * T.pose_thd ? 1.f : 0.f);
       float pen = dist > T.far_th ? -1.f : 0.f;
@@ -205,8 +205,8 @@ __global__ void __launch_bounds__(64) reach_obs_kernel(DevModel M, DevBatch Bt, 
   }
   err2 = grp_sum<G>(err2);
   float actn = 0;
-  GFOR(i, nu) { float a = Bt.act[(size_t)env * nu + i]; actn += a * a; if (valid) o[2 * nv + 6 * T.ntip + i] = a; }
-  actn = sqrtf(grp_sum<G>(actn)) / (float)(nu > 0 ? nu : 1);
+  GFOR(i, nu) { float a = Bt.act[(size_t)env * nu + i]; const int sl = M.act_obs[i]; if (sl >= 0) { actn += a * a; if (valid) o[2 * nv + 6 * T.ntip + sl] = a; } }
+  actn = sqrtf(grp_sum<G>(actn)) / (float)(M.na_obs > 0 ? M.na_obs : 1);
   if (valid) {
     GFOR(i, nv) { o[i] = E[Y.qpos + i]; o[nv + i] = Bt.qvel[(size_t)env * nv + i] * dt; }
     if (sub == 0 && !obs_only) {

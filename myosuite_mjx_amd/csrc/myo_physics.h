@@ -212,6 +212,10 @@ __device__ __forceinline__ float action_map(const DevBatch& Bt, const float* __r
   if (actmap == MYO_ACTMAP_SIGMOID_REAFFERENTATION) { if (i == Bt.reaf_epl) src = Bt.reaf_eip; else if (i == Bt.reaf_eip) return 0.f; }
   float c = action[(size_t)env * nu + src];
   if (actmap == MYO_ACTMAP_NONE) return c;
+  // stateless (non-muscle) actuators: untouched when the model has muscles (base_v0.py:87-93 only re-projects the muscle entries),
+  // re-projected from [-1, 1] onto their ctrlrange when it has none (Robot.process_actuator, robot/robot.py:773-782); the lowering
+  // stores the applicable scale / offset in the record
+  if (actprm[16 * i + 10] < 0.f) return actprm[16 * i + 6] + c * actprm[16 * i + 5];
   c = 1.0f / (1.0f + expf(-5.0f * (c - 0.5f)));
   if (actmap == MYO_ACTMAP_SIGMOID_FATIGUE) {
     float* S = Bt.fatigue + (size_t)env * 3 * nu;

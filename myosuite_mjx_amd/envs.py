@@ -87,6 +87,18 @@ REGISTRY["myoFingerPoseRandom-v0"] = _pose_spec([-0.2, -0.4, 0.1, 0.1], [0.2, 1.
 # myoElbowPose1D6M*-v0 (envs/myo/myobase/__init__.py:108-137): 1-dof elbow with 6 muscles, reset "random", pose_thd 0.175
 REGISTRY["myoElbowPose1D6MFixed-v0"] = _pose_spec([2.0], [2.0], "random", "generate", 0.175, "myoelbow_1dof6muscles")
 REGISTRY["myoElbowPose1D6MRandom-v0"] = _pose_spec([0.0], [2.27], "random", "generate", 0.175, "myoelbow_1dof6muscles")
+# motorFinger{Reach,Pose}*-v0 (envs/myo/myobase/__init__.py:55-81,188-219): the finger driven by five tendon motors (ctrlrange -1..0, no
+# activation state: observations carry no act block), frame_skip 5, 200-step episodes
+REGISTRY["motorFingerReachFixed-v0"] = _reach_box_spec("motorfinger_v0", ("IFtip",), [(0.2, 0.05, 0.20)], [(0.2, 0.05, 0.20)], 0.35, 200, 5)
+REGISTRY["motorFingerReachRandom-v0"] = _reach_box_spec("motorfinger_v0", ("IFtip",), [(0.1, -0.1, 0.1)], [(0.27, 0.1, 0.3)], 0.35, 200, 5)
+REGISTRY["motorFingerPoseFixed-v0"] = dict(_pose_spec([0, 0, 0.75, 0.75], [0, 0, 0.75, 0.75], "init", "generate", 0.35, "motorfinger_v0"),
+                                           max_episode_steps=200, frame_skip=5)
+REGISTRY["motorFingerPoseRandom-v0"] = dict(_pose_spec([-0.2, -0.4, 0.1, 0.1], [0.2, 1.0, 1.0, 1.0], "init", "generate", 0.35, "motorfinger_v0"),
+                                            max_episode_steps=200, frame_skip=5)
+# myoElbowPose1D6MExoFixed-v0 (envs/myo/myobase/__init__.py:140-160): the elbow with an exoskeleton motor on the joint (actuator 0) and
+# act_reg weight 5.  (ExoRandom additionally re-draws a body mass per episode -- a per-env model edit, not offered.)
+REGISTRY["myoElbowPose1D6MExoFixed-v0"] = dict(_pose_spec([2.0], [2.0], "random", "generate", 0.175, "myoelbow_1dof6muscles_1dofexo"),
+                                               weights=dict(pose=1.0, bonus=4.0, act_reg=5.0, penalty=50.0))
 # myoFingerReach*-v0 (envs/myo/myobase/__init__.py:82-105): IFtip to an absolute target box; far_th = ReachEnvV0's default 0.35
 REGISTRY["myoFingerReachFixed-v0"] = _reach_box_spec("myofinger_v0", ("IFtip",), [(0.2, 0.05, 0.20)], [(0.2, 0.05, 0.20)], 0.35)
 REGISTRY["myoFingerReachRandom-v0"] = _reach_box_spec("myofinger_v0", ("IFtip",), [(0.1, -0.1, 0.1)], [(0.27, 0.1, 0.3)], 0.35)
@@ -106,6 +118,7 @@ for _id in [k for k in list(REGISTRY) if k.startswith("myo")]:
         REGISTRY[_id[:3] + "Reaf" + _id[3:]] = dict(REGISTRY[_id], muscle_condition="reafferentation")
 # registered by the reference but not runnable on the HIP path (DESIGN.md "out of scope")
 UNSUPPORTED = {
+    "myoElbowPose1D6MExoRandom-v0": "re-draws the mass of body carry_weight per episode (a per-env model edit)",
     "myoLegRoughTerrainWalk-v0": "height-field terrain contacts are not implemented in the HIP kernel",
 }
 
@@ -170,7 +183,7 @@ class BatchedMyoEnv:
                                  target_lo=spec["target_lo"], target_hi=spec["target_hi"], init_qpos=m.qpos0,
                                  pose_thd=spec["pose_thd"], far_th=4 * np.pi / 2,
                                  w_pose=w["pose"], w_bonus=w["bonus"], w_act_reg=w["act_reg"], w_penalty=w["penalty"])
-            self.obs_dim = 3 * m.nq + m.na
+            self.obs_dim = 3 * m.nq + m.n_muscle
         elif spec["task"] == "walk":
             key_qpos = np.asarray(m.key_qpos).reshape(-1, m.nq)
             key_qvel = np.asarray(m.key_qvel).reshape(-1, m.nv)
@@ -197,7 +210,7 @@ class BatchedMyoEnv:
                                  target_hi=spec["target_hi"], init_qpos=m.qpos0, tip_sites=tips,
                                  far_th=spec["far_th"] * n, near_th=0.0125 * n,
                                  w_reach=w["reach"], w_bonus=w["bonus"], w_act_reg=w["act_reg"], w_penalty=w["penalty"])
-            self.obs_dim = 2 * m.nq + 6 * n + m.na
+            self.obs_dim = 2 * m.nq + 6 * n + m.n_muscle
         self.actmap = capi.ACTMAP_MUSCLE_SIGMOID
         if self.muscle_condition == "fatigue":                         # base_v0.py:70-74, 100-104
             self.actmap = capi.ACTMAP_SIGMOID_FATIGUE

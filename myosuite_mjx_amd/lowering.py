@@ -197,11 +197,14 @@ def lower(cm):
     # ---- tendons driven by actuators (gt index == actuator index), then limited-only tendons
     nu = len(m.actuator_trnid)
     gt_tendon = []
+    kind = np.asarray(m.arrays.get("actuator_kind", np.zeros(nu, np.int32)), np.int32)
     for i in range(nu):
-        if m.actuator_trntype[i] != 1:
-            raise NotImplementedError("HIP path: joint-transmission actuators")
-        gt_tendon.append(int(m.actuator_trnid[i]))
-    if len(set(gt_tendon)) != len(gt_tendon):
+        # a joint-transmission actuator becomes a pseudo tendon (-1): no segments, a constant unit moment arm on its dof
+        gt_tendon.append(int(m.actuator_trnid[i]) if m.actuator_trntype[i] == 1 else -1)
+        if m.actuator_trntype[i] != 1 and (kind[i] == 0 or m.jnt_type[m.actuator_trnid[i]] not in (JNT_HINGE, JNT_SLIDE)):
+            raise NotImplementedError("HIP path: joint transmission is for stateless actuators on hinge / slide joints")
+    real_t = [t for t in gt_tendon if t >= 0]
+    if len(set(real_t)) != len(real_t):
         raise NotImplementedError("HIP path: two actuators on one tendon")
     for t in range(len(m.tendon_adr)):
         if t not in gt_tendon and (m.tendon_limited[t] or m.tendon_stiffness[t] or m.tendon_damping[t]):
@@ -216,10 +219,17 @@ def lower(cm):
             wg_ids[g] = len(wg_ids)
         return wg_ids[g]
 
-    for t in gt_tendon:
-        adr, num = m.tendon_adr[t], m.tendon_num[t]
+    gt_j0 = []      # per tendon: constant moment arms (joint transmission), by slot of its Jacobian row
+    for ti, t in enumerate(gt_tendon):
         gt_seg_adr.append(len(segs))
         gt_len0.append(0.0)
+        if t < 0:
+            gt_seg_num.append(0)
+            gt_dofs.append([int(m.jnt_dofadr[m.actuator_trnid[ti]])])
+            gt_j0.append([1.0])
+            continue
+        gt_j0.append([])
+        adr, num = m.tendon_adr[t], m.tendon_num[t]
         row = []       # dofs of this tendon's sparse Jacobian row
 
         def add_list(la, lb):
@@ -282,8 +292,10 @@ def lower(cm):
     maxnnz = max([len(r) for r in gt_dofs] + [1])
     ngt = len(gt_tendon)
     gt_dof_tab = np.full((ngt, maxnnz), -1, np.int32)
+    gt_j0_tab = np.zeros((ngt, maxnnz))
     for i, r in enumerate(gt_dofs):
         gt_dof_tab[i, :len(r)] = r
+        gt_j0_tab[i, :len(gt_j0[i])] = gt_j0[i]
     # column CSR (per dof: which (tendon, slot) touch it), actuated tendons only
     col_adr = np.zeros(nv + 1, np.int32)
     cols = []
@@ -298,6 +310,18 @@ def lower(cm):
     act = np.zeros((nu, ACT_FLTS))
     for i in range(nu):
         gp, bp = m.actuator_gainprm[i], m.actuator_biasprm[i]
+        if kind[i] == 1:
+            # stateless affine actuator: force = gp[0] * clip(ctrl) + bp[0] + bp[1] * length + bp[2] * velocity.  Record: slots 0-3
+            # the four coefficients, slot 10 (activation time constant of a muscle) negative as the type mark
+            if m.actuator_forcelimited[i]:
+                raise NotImplementedError("HIP path: forcelimited actuators")
+            cr = m.actuator_ctrlrange[i] if m.actuator_ctrllimited[i] else (-1e30, 1e30)
+            act[i, :4] = [gp[0], bp[0], bp[1], bp[2]]
+            act[i, 10], act[i, 11] = -1.0, 1.0
+            cr_raw = m.actuator_ctrlrange[i]
+            act[i, 5:7] = [1.0, 0.0] if (kind == 0).any() else [(cr_raw[1] - cr_raw[0]) / 2.0, (cr_raw[1] + cr_raw[0]) / 2.0]
+            act[i, 12:15] = [cr[0], cr[1], m.actuator_gear[i]]
+            continue
         if not np.allclose(np.delete(gp, 2), np.delete(bp, 2)):
             raise NotImplementedError("HIP path: muscle gainprm != biasprm (other than the peak force)")
         force = gp[2] if gp[2] >= 0 else gp[3] / max(1e-15, m.actuator_acc0[i])
@@ -409,6 +433,8 @@ def lower(cm):
                  m.jnt_solref[j, 1], *m.jnt_solimp[j], m.dof_invweight0[d]]
     tl = np.zeros((ngt, 12))
     for i, t in enumerate(gt_tendon):
+        if t < 0:
+            continue
         tl[i] = [m.tendon_limited[t], m.tendon_range[t, 0], m.tendon_range[t, 1], m.tendon_margin[t],
                  m.tendon_solref[t, 0], m.tendon_solref[t, 1], *m.tendon_solimp[t], m.tendon_invweight0[t]]
         if m.tendon_stiffness[t] or m.tendon_damping[t]:
@@ -472,7 +498,11 @@ def lower(cm):
         chain_adr[l + 1] = len(chain)
     A["hip_link_chain_adr"] = chain_adr
     A["hip_link_chain"] = np.array(chain, np.int32)
-    A["hip_flags"] = np.array([int(has_free), int(A["sizes"][0]), neq], np.int32)
+    act_obs = np.full(nu, -1, np.int32)      # slot of each actuator's activation in the observation's "act" block (sim.data.act order)
+    act_obs[kind == 0] = np.arange(int((kind == 0).sum()))
+    A["hip_act_obs"] = act_obs
+    A["hip_gt_j0"] = gt_j0_tab
+    A["hip_flags"] = np.array([int(has_free), int(A["sizes"][0]), neq, int(gt_j0_tab.any()), int((kind == 0).sum()), int((kind == 1).any())], np.int32)
     A["hip_sizes"] = np.array([nl, nlevel, nv, nu, ngt, len(segs), len(dls), maxnnz, len(wgs), len(cgs), len(pairs_i),
                                maxkc, ns, len(cols), len(childs), pruned], np.int32)
     A["hip_level_adr"] = level_adr

@@ -202,6 +202,8 @@ def geom_rbound(gtype, size):
         return max(size)
     if gtype == GEOM_BOX:
         return float(np.linalg.norm(size))
+    if gtype == GEOM_MESH:
+        return float(size[0])      # conservative sphere about the geom frame origin (see _finalize)
     return 0.0
 
 
@@ -396,6 +398,7 @@ class _Compiler:
             p = os.path.normpath(os.path.join(base, self.comp["meshdir"], m["file"]))
             tris = _read_stl(p) * m["scale"][None, None, :]
             m["props"] = mesh_mass_properties(tris)
+            m["rmax"] = float(np.linalg.norm(tris.reshape(-1, 3), axis=1).max())   # sphere about the mesh origin containing it
         return m["props"]
 
     def _do_body(self, e, parent, childclass):
@@ -527,7 +530,7 @@ class _Compiler:
 
     def _do_actuator(self, e):
         for a in e:
-            if a.tag not in ("muscle", "general"):
+            if a.tag not in _ACT_TAGS:
                 raise NotImplementedError(f"actuator <{a.tag}>")
             at = self._attrs(a, a.tag, None)
             act = dict(name=at.get("name", f"act{len(self.actuators)}"))
@@ -560,15 +563,37 @@ class _Compiler:
                 act["dynprm"] = np.array([tc[0], tc[1], float(at.get("tausmooth", 0))])
                 act["gainprm"] = prm.copy()
                 act["biasprm"] = prm.copy()
+            elif a.tag in ("motor", "position", "velocity"):
+                # shortcuts for stateless affine actuators: force = gainprm[0] * ctrl + biasprm[0] + biasprm[1] * length + biasprm[2] * velocity
+                act["dyntype"], act["gaintype"] = "none", "fixed"
+                act["dynprm"] = np.array([1.0, 0, 0])
+                gp, bp = np.zeros(9), np.zeros(9)
+                if a.tag == "motor":
+                    gp[0] = 1.0
+                    act["biastype"] = "none"
+                elif a.tag == "position":
+                    kp, kv = float(at.get("kp", 1)), float(at.get("kv", 0))
+                    gp[0], bp[1], bp[2] = kp, -kp, -kv
+                    act["biastype"] = "affine"
+                else:
+                    kv = float(at.get("kv", 1))
+                    gp[0], bp[2] = kv, -kv
+                    act["biastype"] = "affine"
+                act["gainprm"], act["biasprm"] = gp, bp
             else:
                 act["dyntype"] = at.get("dyntype", "none")
                 act["gaintype"] = at.get("gaintype", "fixed")
                 act["biastype"] = at.get("biastype", "none")
-                if not (act["dyntype"] == act["gaintype"] == act["biastype"] == "muscle"):
-                    raise NotImplementedError("only muscle-type general actuators are supported")
+                affine = act["dyntype"] == "none" and act["gaintype"] == "fixed" and act["biastype"] in ("none", "affine")
+                if not (act["dyntype"] == act["gaintype"] == act["biastype"] == "muscle") and not affine:
+                    raise NotImplementedError("general actuators: only muscle-type, or stateless fixed-gain / affine-bias ones")
                 act["dynprm"] = _pad(_floats(at.get("dynprm", "1")), [1, 0, 0])[:3]
                 act["gainprm"] = _pad(_floats(at.get("gainprm", "1")), [1] + [0] * 8)[:9]
                 act["biasprm"] = _pad(_floats(at.get("biasprm", "0")), [0] * 9)[:9]
+                if affine and act["biastype"] == "none":
+                    act["biasprm"] = np.zeros(9)
+            # kind 0: muscle (activation state + FLV curves); kind 1: stateless affine (motor / position / velocity / general)
+            act["kind"] = 0 if act["dyntype"] == "muscle" else 1
             self.actuators.append(act)
 
     def _do_contact(self, e):
@@ -831,11 +856,15 @@ class _Compiler:
         def _can_pair(i):
             a = self.geoms[i]
             return any(j != i and ((a["contype"] & b["conaffinity"]) or (b["contype"] & a["conaffinity"])) for j, b in enumerate(self.geoms))
+        # A mesh that can pair is kept as a bounding sphere only: the lowering must prove each of its pairs out of reach (it raises
+        # otherwise), and the oracle's bounding-sphere filter then never lets one reach a narrow phase (it flags it if one does)
         for i in list(keep):
             if self.geoms[i]["type"] == GEOM_MESH:
                 if _can_pair(i):
-                    raise NotImplementedError("colliding mesh geoms")
-                keep.remove(i)
+                    self._mesh_props(self.geoms[i]["mesh"])
+                    self.geoms[i]["size"] = np.array([self.meshes[self.geoms[i]["mesh"]]["rmax"], 0.0, 0.0])
+                else:
+                    keep.remove(i)
         # explicit pairs may name geoms that neither collide dynamically nor wrap: keep them too
         pair_names = {pr[k] for pr in self.pairs for k in ("geom1", "geom2")}
         keep = sorted(set(keep) | {i for i, g in enumerate(self.geoms) if g["name"] and g["name"] in pair_names})
@@ -912,6 +941,7 @@ class _Compiler:
         A["actuator_lengthrange"] = np.stack([a["lengthrange"] for a in self.actuators]) if nu else np.zeros((0, 2))
         A["actuator_has_lengthrange"] = np.array([a["has_lengthrange"] for a in self.actuators], np.int32)
         A["actuator_acc0"] = np.zeros(nu)
+        A["actuator_kind"] = np.array([a["kind"] for a in self.actuators], np.int32)
         # collision pair table (static part of mj_collision's filtering)
         excl = set()
         for b1, b2 in self.excludes:

@@ -37,7 +37,12 @@ class Model:
     @property
     def nu(self): return int(self.arrays["sizes"][2])
     @property
-    def na(self): return int(self.arrays["sizes"][3])
+    def na(self): return int(self.arrays["sizes"][3])     # activation slots of the state arrays (one per actuator)
+
+    @property
+    def n_muscle(self):
+        """MuJoCo's na for these models: actuators with an activation state (muscles); stateless motors keep an unused slot."""
+        return int((np.asarray(self.arrays["actuator_kind"]) == 0).sum())
     @property
     def nbody(self): return int(self.arrays["sizes"][4])
     @property

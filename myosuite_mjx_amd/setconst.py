@@ -337,7 +337,7 @@ def set_constants(m, lengthrange_grid=5):
     # muscles without an explicit lengthrange (finger model): MuJoCo finds the range by a
     # damped simulation (mj_setLengthRange).  Here: min/max tendon length over a joint-range
     # grid, which that procedure converges towards.  Documented as "parity unpinned".
-    missing = [i for i in range(nu) if not m.actuator_has_lengthrange[i]]
+    missing = [i for i in range(nu) if not m.actuator_has_lengthrange[i] and m.actuator_kind[i] == 0 and m.actuator_trntype[i] == 1]
     if missing:
         lim = np.array([m.jnt_range[j] if m.jnt_limited[j] else (-math.pi, math.pi) for j in range(len(m.jnt_type))])
         if len(lim) > 6:

@@ -66,7 +66,7 @@ typedef struct {
   int *tendon_adr, *tendon_num, *tendon_limited;
   real *tendon_range, *tendon_margin, *tendon_stiffness, *tendon_damping, *tendon_solref, *tendon_solimp,
       *tendon_invweight0;
-  int *actuator_trnid, *actuator_trntype, *actuator_ctrllimited, *actuator_forcelimited;
+  int *actuator_trnid, *actuator_trntype, *actuator_ctrllimited, *actuator_forcelimited, *actuator_kind;
   real *actuator_gear, *actuator_dynprm, *actuator_gainprm, *actuator_biasprm, *actuator_ctrlrange,
       *actuator_forcerange, *actuator_lengthrange, *actuator_acc0;
   int *pair_geom, *pair_condim;
@@ -173,7 +173,7 @@ Model* myoo_load(const void* blobv, size_t nbytes) {
   LI(site_bodyid); LF(site_pos); LI(wrap_type); LI(wrap_objid); LF(wrap_prm);
   LI(tendon_adr); LI(tendon_num); LI(tendon_limited); LF(tendon_range); LF(tendon_margin); LF(tendon_stiffness);
   LF(tendon_damping); LF(tendon_solref); LF(tendon_solimp); LF(tendon_invweight0);
-  LI(actuator_trnid); LI(actuator_trntype); LI(actuator_ctrllimited); LI(actuator_forcelimited);
+  LI(actuator_trnid); LI(actuator_trntype); LI(actuator_ctrllimited); LI(actuator_forcelimited); LI(actuator_kind);
   LF(actuator_gear); LF(actuator_dynprm); LF(actuator_gainprm); LF(actuator_biasprm); LF(actuator_ctrlrange);
   LF(actuator_forcerange); LF(actuator_lengthrange); LF(actuator_acc0);
   LI(pair_geom); LI(pair_condim);
@@ -901,6 +901,17 @@ static void collision(const Model* m, Data* d) { /* mj_collision over the compil
       real bound = m->geom_rbound[g1] + m->geom_rbound[g2] + margin;
       if (dot3(dif, dif) > bound * bound) continue;
     }
+    /* cylinder cap filter: a bounding sphere entirely beyond one of the cylinder's cap planes cannot touch it (the scene's pedestal is a
+       tall cylinder whose own bounding sphere reaches far above its top) */
+    if (t1 == GEOM_CYLINDER || t2 == GEOM_CYLINDER) {
+      int gc = t1 == GEOM_CYLINDER ? g1 : g2, go = t1 == GEOM_CYLINDER ? g2 : g1;
+      const real* Rc = d->geom_xmat + 9 * gc;
+      real ax[3] = {Rc[2], Rc[5], Rc[8]};
+      real dif[3] = {d->geom_xpos[3 * go] - d->geom_xpos[3 * gc], d->geom_xpos[3 * go + 1] - d->geom_xpos[3 * gc + 1],
+                     d->geom_xpos[3 * go + 2] - d->geom_xpos[3 * gc + 2]};
+      real h = dot3(dif, ax);
+      if ((h < 0 ? -h : h) - m->geom_size[3 * gc + 1] - m->geom_rbound[go] > margin) continue;
+    }
     Contact c;
     memset(&c, 0, sizeof c);
     int hit = 0;
@@ -1011,6 +1022,8 @@ static void collision(const Model* m, Data* d) { /* mj_collision over the compil
       }
       continue;
     } else {
+      d->warning |= 4;   /* a pair type with no narrow phase here (mesh, box, hfield) came within bounding-sphere range: the model
+                            compiler only admits such pairs when they are provably out of reach, so this is an error */
       continue;
     }
     if (!hit) continue;
@@ -1535,6 +1548,18 @@ static void fwd_actuation(const Model* m, Data* d) { /* mj_fwdActuation, muscle 
   for (int i = 0; i < m->nu; i++) {
     real ctrl = d->ctrl[i];
     if (m->actuator_ctrllimited[i]) ctrl = clipr(ctrl, m->actuator_ctrlrange[2 * i], m->actuator_ctrlrange[2 * i + 1]);
+    if (m->actuator_kind[i] == 1) { /* stateless affine actuator (motor / position / velocity / general with dyntype none): [3P] mj_fwdActuation,
+                                       gaintype fixed: gain = gainprm[0]; biastype affine: bias = b0 + b1 * length + b2 * velocity; force = gain * ctrl + bias.
+                                       The (unused) activation slot stays at zero */
+      const real* gp = m->actuator_gainprm + 9 * i;
+      const real* bp = m->actuator_biasprm + 9 * i;
+      real fa = gp[0] * ctrl + bp[0] + bp[1] * d->actuator_length[i] + bp[2] * d->actuator_velocity[i];
+      if (m->actuator_forcelimited[i]) fa = clipr(fa, m->actuator_forcerange[2 * i], m->actuator_forcerange[2 * i + 1]);
+      d->act_dot[i] = 0;
+      d->actuator_force[i] = fa;
+      for (int k = 0; k < nv; k++) d->qfrc_actuator[k] += d->actuator_moment[(size_t)i * nv + k] * fa;
+      continue;
+    }
     d->act_dot[i] = muscle_dynamics(ctrl, d->act[i], m->actuator_dynprm + 3 * i);
     real gain = muscle_gain(d->actuator_length[i], d->actuator_velocity[i], m->actuator_lengthrange + 2 * i,
                             m->actuator_acc0[i], m->actuator_gainprm + 9 * i);
@@ -1817,6 +1842,7 @@ static void euler(const Model* m, Data* d) { /* mj_Euler with implicit joint dam
 int myoo_step1(const Model* m, Data* d) {
   if (is_bad(d->qpos, m->nq) || is_bad(d->qvel, m->nv)) { myoo_reset(m, d); d->warning |= 1; return 1; }
   myoo_forward(m, d);
+  if (d->warning & 4) return 4;
   if (is_bad(d->qacc, m->nv)) { myoo_reset(m, d); d->warning |= 2; return 2; }
   euler(m, d);
   return 0;

@@ -36,6 +36,18 @@ def elbow():
 
 
 @pytest.fixture(scope="session")
+def exo():
+    from myosuite_mjx_amd import model as M
+    return M.load_asset("myoelbow_1dof6muscles_1dofexo")
+
+
+@pytest.fixture(scope="session")
+def motorfinger():
+    from myosuite_mjx_amd import model as M
+    return M.load_asset("motorfinger_v0")
+
+
+@pytest.fixture(scope="session")
 def oracle64(hand):
     from oracle.oracle import Oracle
     return Oracle(hand.blob())

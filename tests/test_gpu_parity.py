@@ -157,7 +157,7 @@ def _finger_pair(finger, blob_bytes, qpos, qvel, act, ctrl, nsub):
     for e in range(N):
         o.reset()
         o.set_state(qpos=qpos[e], qvel=qvel[e], act=act[e], ctrl=ctrl[e])
-        o.step(nsub)
+        assert o.step(nsub) == 0
         rq[e], rv[e], ra[e], ne[e] = o.field("qpos"), o.field("qvel"), o.field("act"), o.nefc
     return (gq, gv, ga, dg, fl), (rq, rv, ra, ne)
 
@@ -194,6 +194,25 @@ def test_elbow_parity(elbow, nsub):
     assert np.abs(g[0] - r[0]).max() < (2e-6 if nsub == 1 else 2e-5)
     assert np.abs(g[1] - r[1]).max() < (1e-3 if nsub == 1 else 5e-3)
     assert np.abs(g[2] - r[2]).max() < 1e-6
+
+
+@pytest.mark.parametrize("which", ["motorfinger", "exo"])
+def test_stateless_actuator_parity(which, request):
+    """<motor> actuators: on tendons (motorfinger_v0: gear 5-20, ctrl clamped to [-1, 0]) and on a joint next to muscles (elbow exo:
+    a pseudo tendon with a constant unit moment arm); ctrl written directly (ACTMAP_NONE), outside the ctrlrange on purpose."""
+    m = request.getfixturevalue(which)
+    rng = np.random.default_rng(40)
+    N, f32 = 128, np.float32
+    lo, hi = m.jnt_range[:, 0], m.jnt_range[:, 1]
+    ctrl = rng.uniform(-1.5, 0.5, (N, m.nu)) if which == "motorfinger" else np.concatenate([rng.uniform(-1, 1, (N, 1)), rng.uniform(0, 1, (N, 6))], 1)
+    act = np.zeros((N, m.nu)) if which == "motorfinger" else np.concatenate([np.zeros((N, 1)), rng.uniform(0, 1, (N, 6))], 1)
+    st = (rng.uniform(lo - 0.05, hi + 0.05, (N, m.nq)).astype(f32), rng.normal(0, 1.0, (N, m.nv)).astype(f32), act.astype(f32), ctrl.astype(f32))
+    for nsub in (1, 10):
+        g, r = _finger_pair(m, m.blob(), *st, nsub)
+        assert (g[4] == 0).all()
+        assert np.abs(g[0] - r[0]).max() < (5e-6 if nsub == 1 else 1e-4)
+        assert np.abs(g[1] - r[1]).max() < (2e-3 if nsub == 1 else 2e-2)
+        assert np.abs(g[2] - r[2]).max() < 1e-6 and (g[2][:, m.actuator_kind == 1] == 0).all()
 
 
 def test_finger_tendon_limits_active(finger):
@@ -271,6 +290,46 @@ def test_elbow_and_finger_reach_envs(elbow, finger):
         dist = np.linalg.norm(o[:, 11:14], axis=1)
         ref = -dist + 4.0 * ((dist < 0.025) * 1.0 + (dist < 0.0125) * 1.0) - 50.0 * (dist > 0.35)     # t = 0.08 > 2 dt
         assert np.allclose(rwd.cpu().numpy(), ref, atol=1e-5) and np.array_equal(term.cpu().numpy(), dist > 0.35)
+
+
+def test_motor_envs_action_map_and_observation_layout(motorfinger, exo):
+    """motorFinger*-v0: no muscles -> actions re-projected onto the ctrlrange (robot/robot.py:773-782), no act block in the observation
+    (pose 12 = qpos, qvel, pose_err; reach 14), frame_skip 5, 200 steps.  myoElbowPose1D6MExoFixed-v0: the motor's action passes
+    through unchanged next to the sigmoid-mapped muscles (base_v0.py:87-93); act block = the six muscle activations; act_reg 5."""
+    import torch
+    import myosuite_mjx_amd as myo
+    from myosuite_mjx_amd import capi
+    env = myo.make("motorFingerPoseRandom-v0", num_envs=32, seed=1, autoreset=False)
+    obs = env.reset(seed=1)
+    assert obs.shape == (32, 12) and env.max_episode_steps == 200 and env.frame_skip == 5 and abs(env.dt - 0.01) < 1e-9
+    a = torch.rand((32, 5), device="cuda") * 2 - 1
+    obs, rwd, term, trunc, info = env.step(a)
+    assert np.allclose(env.batch.read(capi.F_CTRL), -0.5 + 0.5 * a.cpu().numpy(), atol=1e-6)
+    st = env.get_env_state()
+    o = obs.cpu().numpy()
+    assert np.allclose(o[:, :4], st["qpos"], atol=1e-7) and np.allclose(o[:, 4:8], st["qvel"] * 0.01, atol=1e-6) and np.allclose(o[:, 8:], st["target"] - st["qpos"], atol=1e-6)
+    dist = np.linalg.norm(o[:, 8:], axis=1)
+    ref = -dist + 4.0 * ((dist < 0.35) * 1.0 + (dist < 1.5 * 0.35) * 1.0) - 50.0 * (dist > 2 * np.pi)       # act_mag = 0 without muscles
+    assert np.allclose(rwd.cpu().numpy(), ref, atol=1e-5) and (st["act"] == 0).all()
+    env = myo.make("motorFingerReachRandom-v0", num_envs=8, seed=1)
+    assert env.reset(seed=1).shape == (8, 14)
+    env.step(torch.zeros((8, 5), device="cuda"))
+    env = myo.make("myoElbowPose1D6MExoFixed-v0", num_envs=32, seed=2, autoreset=False)
+    obs = env.reset(seed=2)
+    assert obs.shape == (32, 9)
+    a = torch.rand((32, 7), device="cuda") * 2 - 1
+    obs, rwd, term, trunc, info = env.step(a)
+    an = a.cpu().numpy()
+    want = np.concatenate([an[:, :1], 1.0 / (1.0 + np.exp(-5.0 * (an[:, 1:] - 0.5)))], 1)
+    assert np.allclose(env.batch.read(capi.F_CTRL), want, atol=1e-6)
+    st = env.get_env_state()
+    o = obs.cpu().numpy()
+    assert np.allclose(o[:, 3:], st["act"][:, 1:], atol=1e-7) and (st["act"][:, 0] == 0).all()
+    dist = np.abs(o[:, 2])
+    ref = -dist + 4.0 * ((dist < 0.175) * 1.0 + (dist < 1.5 * 0.175) * 1.0) - 5.0 * np.linalg.norm(st["act"][:, 1:], axis=1) / 6 - 50.0 * (dist > 2 * np.pi)
+    assert np.allclose(rwd.cpu().numpy(), ref, atol=1e-5)
+    with pytest.raises(NotImplementedError):
+        myo.make("myoElbowPose1D6MExoRandom-v0", num_envs=1)
 
 
 def test_size_specialised_and_generic_instantiations_agree(hand, legs):

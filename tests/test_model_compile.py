@@ -154,3 +154,31 @@ def test_elbow_asset_matches_fresh_compile(elbow):
     fresh = M.from_mjcf(os.path.join(REFERENCE, "envs/myo/assets/elbow/myoelbow_1dof6muscles.xml"))
     for k, v in fresh.arrays.items():
         assert np.allclose(np.asarray(v, float), np.asarray(elbow.arrays[k], float), rtol=0, atol=1e-12), k
+
+
+def test_stateless_actuator_models(exo, motorfinger, hand):
+    """<motor> actuators (motorfinger_v0.xml:10-16 on tendons, myoelbow_1dof6muscles_1dofexo_body.xml:174 on the joint): kind 1 =
+    stateless affine, gain 1, no bias; the exo model's bone meshes can pair with the scene's floor / pedestal and are kept as
+    bounding spheres whose pairs the lowering proves out of reach."""
+    assert (hand.actuator_kind == 0).all() and hand.n_muscle == 39
+    assert (motorfinger.nu, motorfinger.n_muscle) == (5, 0) and (motorfinger.actuator_kind == 1).all()
+    assert (motorfinger.actuator_trntype == 1).all() and np.allclose(motorfinger.actuator_gear, [20, 5, 5, 10, 10])
+    assert np.allclose(motorfinger.actuator_ctrlrange, [[-1, 0]] * 5) and (motorfinger.actuator_ctrllimited == 1).all()
+    assert np.allclose(motorfinger.actuator_gainprm[:, 0], 1) and np.allclose(motorfinger.actuator_biasprm, 0)
+    assert (exo.nu, exo.n_muscle, exo.nv) == (7, 6, 1) and exo.actuator_kind.tolist() == [1, 0, 0, 0, 0, 0, 0]
+    assert int(exo.actuator_trntype[0]) == 0 and abs(exo.actuator_gear[0] - 8.5) < 1e-12 and int(exo.actuator_ctrllimited[0]) == 0
+    assert exo.hip_act_obs.tolist() == [-1, 0, 1, 2, 3, 4, 5] and int(exo.hip_flags[3]) == 1 and int(exo.hip_flags[4]) == 6
+    assert (exo.geom_type == 7).sum() > 10 and int(exo.hip_sizes[10]) == 0 and int(exo.hip_sizes[15]) == exo.pair_geom.shape[0]
+    # action re-projection stored with the record (lowering): motorfinger has no muscles -> [-1, 1] onto the ctrlrange;
+    # the exo motor rides along with muscles -> passed through
+    assert np.allclose(motorfinger.hip_act[:, 5:7], [[0.5, -0.5]] * 5) and np.allclose(exo.hip_act[0, 5:7], [1.0, 0.0])
+
+
+@needs_reference
+@pytest.mark.parametrize("stem,rel", [("myoelbow_1dof6muscles_1dofexo", "envs/myo/assets/elbow/myoelbow_1dof6muscles_1dofexo.xml"),
+                                      ("motorfinger_v0", "simhive/myo_sim/finger/motorfinger_v0.xml")])
+def test_motor_assets_match_fresh_compile(stem, rel):
+    from myosuite_mjx_amd import model as M
+    fresh, asset = M.from_mjcf(os.path.join(REFERENCE, rel)), M.load_asset(stem)
+    for k, v in fresh.arrays.items():
+        assert np.allclose(np.asarray(v, float), np.asarray(asset.arrays[k], float), rtol=0, atol=1e-12), k

@@ -303,3 +303,35 @@ def test_elbow_lengthrange_goldens(elbow):
         assert o.step(10) == 0
     q = o.field("qpos")[0]
     assert elbow.jnt_range[0, 0] - 0.05 < q < elbow.jnt_range[0, 1] + 0.05
+
+
+def test_stateless_actuators_in_the_oracle(exo, motorfinger):
+    """mj_fwdActuation for dyntype none / gaintype fixed: force = gain * clip(ctrl), moment = gear * (tendon jacobian | joint dof)."""
+    from oracle.oracle import Oracle
+    o = Oracle(motorfinger.blob())
+    o.reset()
+    q = np.array([0.1, 0.3, 0.4, 0.2])
+    ctrl = np.array([-0.5, -2.0, 0.7, -0.25, -1.0])            # clamped to [-1, 0]
+    o.set_state(qpos=q, qvel=np.zeros(4), ctrl=ctrl)
+    o.forward()
+    f = o.field("actuator_force")
+    assert np.allclose(f, np.clip(ctrl, -1, 0)) and np.allclose(o.field("act_dot"), 0)
+    J = o.field("ten_J").reshape(5, 4)[motorfinger.actuator_trnid]
+    want = (J * motorfinger.actuator_gear[:, None] * f[:, None]).sum(0)
+    assert np.allclose(o.field("qfrc_actuator"), want, atol=1e-12) and np.abs(want).max() > 0.01
+    for _ in range(20):
+        assert o.step(5) == 0
+    assert np.allclose(o.field("act"), 0)
+    o2 = Oracle(exo.blob())
+    o2.reset()
+    c = np.zeros(7); c[0] = 0.4
+    o2.set_state(qpos=[1.0], qvel=[0.0], act=np.zeros(7), ctrl=c)
+    o2.forward()
+    base = o2.field("qfrc_actuator")[0]
+    c[0] = -0.6
+    o2.set_state(ctrl=c)
+    o2.forward()
+    assert abs((base - o2.field("qfrc_actuator")[0]) - 8.5 * 1.0) < 1e-9         # unclamped motor, gear 8.5 on the elbow dof
+    assert abs(o2.field("actuator_length")[0] - 8.5 * 1.0) < 1e-12
+    for _ in range(20):
+        assert o2.step(10) == 0                                                    # scene pairs never come into range (else rc 4)

@@ -14,6 +14,8 @@ MODELS = {
     "myofinger_v0": "myosuite/simhive/myo_sim/finger/myofinger_v0.xml",
     "myolegs": "myosuite/simhive/myo_sim/leg/myolegs.xml",
     "myoelbow_1dof6muscles": "myosuite/envs/myo/assets/elbow/myoelbow_1dof6muscles.xml",
+    "myoelbow_1dof6muscles_1dofexo": "myosuite/envs/myo/assets/elbow/myoelbow_1dof6muscles_1dofexo.xml",
+    "motorfinger_v0": "myosuite/simhive/myo_sim/finger/motorfinger_v0.xml",
 }
 
 if __name__ == "__main__":
