@@ -79,18 +79,21 @@ enum {
 };
 
 /* tasks understood by myo_obs / myo_reset */
-typedef enum myo_task { MYO_TASK_NONE = 0, MYO_TASK_POSE = 1, MYO_TASK_REACH = 2, MYO_TASK_WALK = 3 } myo_task;
+typedef enum myo_task { MYO_TASK_NONE = 0, MYO_TASK_POSE = 1, MYO_TASK_REACH = 2, MYO_TASK_WALK = 3,
+                        MYO_TASK_HOLD = 4 /* ObjHoldFixedEnvV0 (envs/myo/myobase/obj_hold_v0.py:13-118): the model's LAST joint is the free
+                                             object; obs = hand qpos, hand qvel*dt, object position, goal - object, act; target = goal (3) */
+} myo_task;
 
 typedef struct myo_task_config {
   int task;              /* myo_task */
   int frame_skip;        /* substeps per env step; obs scales qvel by frame_skip*timestep */
   int reset_random;      /* pose: 1 = qpos ~ U(jnt_range) (reset_type "random"), 0 = init_qpos */
   int target_generate;   /* 1 = sample target ~ U(target_lo, target_hi) on reset, 0 = fixed (target_lo) */
-  int ntarget;           /* pose: nq; reach: 3*ntip */
+  int ntarget;           /* pose: nq; reach: 3*ntip; hold: 3 */
   int ntip;              /* reach: number of tip sites */
   int tip_site[8];       /* reach: site ids (compiled-model numbering) */
-  float pose_thd, far_th, near_th;
-  float w_pose, w_bonus, w_act_reg, w_penalty, w_reach;
+  float pose_thd, far_th, near_th;   /* hold: near_th = goal threshold (0.010), far_th = drop distance (0.300) */
+  float w_pose, w_bonus, w_act_reg, w_penalty, w_reach;   /* hold: w_reach weighs goal_dist */
   const float* target_lo; /* host pointers, ntarget floats each (copied) */
   const float* target_hi;
   const float* init_qpos; /* host pointer, nq floats (copied); NULL = qpos0 */

@@ -19,6 +19,7 @@ INT_FIELDS = (F_FLAGS, F_DIAG, F_ELAPSED)
 BENCH_OBS, BENCH_FRESH_ACTIONS, BENCH_AUTORESET = 1, 2, 4
 ACTMAP_NONE, ACTMAP_MUSCLE_SIGMOID, ACTMAP_SIGMOID_FATIGUE, ACTMAP_SIGMOID_REAFFERENTATION = 0, 1, 2, 3
 TASK_NONE, TASK_POSE, TASK_REACH = 0, 1, 2
+TASK_HOLD = 4
 FLAG_BAD_STATE, FLAG_BAD_QACC, FLAG_CONTACT_OVERFLOW, FLAG_CAND_OVERFLOW = 1, 2, 4, 8
 
 

@@ -83,7 +83,7 @@ struct DevBatch {
 };
 
 struct TaskDev {
-  int task, frame_skip, reset_random, target_generate, ntarget, ntip, obs_dim;
+  int task, frame_skip, reset_random, target_generate, ntarget, ntip, obs_dim, nq;
   int tip_site[8];
   float pose_thd, far_th, near_th, w_pose, w_bonus, w_act_reg, w_penalty, w_reach;
   const float *target_lo, *target_hi, *init_qpos, *jnt_lo, *jnt_hi;

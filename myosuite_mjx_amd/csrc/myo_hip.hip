@@ -391,7 +391,13 @@ int myo_batch_configure(myo_batch* b, const myo_task_config* c) {
   T.w_pose = c->w_pose; T.w_bonus = c->w_bonus; T.w_act_reg = c->w_act_reg; T.w_penalty = c->w_penalty; T.w_reach = c->w_reach;
   if (c->task == MYO_TASK_POSE) { if (c->ntarget != nv) return fail(MYO_E_ARG, "pose task: ntarget must equal nq"); T.obs_dim = 3 * nv + b->model->dm.na_obs; }
   else if (c->task == MYO_TASK_REACH) { if (c->ntarget != 3 * c->ntip) return fail(MYO_E_ARG, "reach task: ntarget must be 3*ntip"); T.obs_dim = 2 * nv + 6 * c->ntip + b->model->dm.na_obs; }
+  else if (c->task == MYO_TASK_HOLD) {
+    if (c->ntarget != 3) return fail(MYO_E_ARG, "hold task: ntarget must be 3 (goal position)");
+    if (!(b->model->wave_ok && b->model->dw.has_free && b->model->nq == nv + 1 && nv > 6)) return fail(MYO_E_UNSUPPORTED, "hold task needs a model whose last joint is one free object");
+    T.obs_dim = (b->model->nq - 7) + (nv - 6) + 6 + b->model->dm.na_obs;
+  }
   else T.obs_dim = 0;
+  T.nq = b->model->nq;
   if (T.obs_dim > b->obs_alloc) return fail(MYO_E_ARG, "obs_dim too large");
   if (c->ntarget > 0) {
     if (!c->target_lo) return fail(MYO_E_ARG, "target_lo required");
@@ -642,7 +648,7 @@ static int launch_obs(myo_batch* b, hipStream_t s, int obs_only = 0, int reset_o
   if (b->task.task == MYO_TASK_WALK) {
     // the walk observation lives in the step kernel: run it with zero substeps as an observation-only pass
     return launch_step(b, nullptr, MYO_ACTMAP_NONE, 0, s, KF_AUX | (obs_only ? KF_OBS_ONLY : 0) | (reset_only ? KF_RESET_ONLY : 0));
-  } else if (b->task.task == MYO_TASK_POSE) {
+  } else if (b->task.task == MYO_TASK_POSE || b->task.task == MYO_TASK_HOLD) {
     hipLaunchKernelGGL(obs_kernel, dim3(B), dim3(64), 0, s, m->dm, b->db, b->task, obs_only, reset_only);
   } else if (b->task.task == MYO_TASK_REACH) {
     const int EPW = 4;

@@ -1329,17 +1329,23 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     if (alive) {
 #pragma unroll
       for (int rr = 0; rr < NTR; rr++) if (lane + 64 * rr < nu) E[Y.act + lane + 64 * rr] += h * actdot[rr];
+      bool frot = false;
       if (lane < nv) {
         float v = E[Y.qvel + lane] + h * qaccE;
         E[Y.qvel + lane] = v;
-        if (!(has_free && lane >= 3 && lane < 6)) E[Y.qpos + W.dof_qposadr[lane]] += h * v;
+        // rotational dofs of a free joint (dofs 3..5 of its link) integrate through the quaternion below
+        const int fl = M.dof_link[lane];
+        frot = has_free && W.link_free[fl] && lane - M.link_dofadr[fl] >= 3;
+        if (!frot) E[Y.qpos + W.dof_qposadr[lane]] += h * v;
       }
-      if (has_free) {   // root free joint: quaternion integrated with the body-frame angular velocity (mju_quatIntegrate)
+      if (has_free) {   // free joints: quaternion integrated with the body-frame angular velocity (mju_quatIntegrate); one lane per joint
         SYNC();
-        if (lane == 3) {
-          float w[3] = {E[Y.qvel + 3], E[Y.qvel + 4], E[Y.qvel + 5]};
+        const int fl = lane < nv ? M.dof_link[lane] : 0;
+        if (frot && lane - M.link_dofadr[fl] == 3) {
+          const int qa = W.dof_qposadr[M.link_dofadr[fl]] + 3;
+          float w[3] = {E[Y.qvel + lane], E[Y.qvel + lane + 1], E[Y.qvel + lane + 2]};
           float wn = norm3(w), ang = h * wn;
-          float q[4] = {E[Y.qpos + 3], E[Y.qpos + 4], E[Y.qpos + 5], E[Y.qpos + 6]};
+          float q[4] = {E[Y.qpos + qa], E[Y.qpos + qa + 1], E[Y.qpos + qa + 2], E[Y.qpos + qa + 3]};
           if (wn >= MINVALF) {
             float sn, cs;
             sincosf(0.5f * ang, &sn, &cs);
@@ -1349,7 +1355,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             o[2] = q[0] * r[2] - q[1] * r[3] + q[2] * r[0] + q[3] * r[1];
             o[3] = q[0] * r[3] + q[1] * r[2] - q[2] * r[1] + q[3] * r[0];
             float on = 1.0f / sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
-            E[Y.qpos + 3] = o[0] * on; E[Y.qpos + 4] = o[1] * on; E[Y.qpos + 5] = o[2] * on; E[Y.qpos + 6] = o[3] * on;
+            E[Y.qpos + qa] = o[0] * on; E[Y.qpos + qa + 1] = o[1] * on; E[Y.qpos + qa + 2] = o[2] * on; E[Y.qpos + qa + 3] = o[3] * on;
           }
         }
       }

@@ -168,6 +168,30 @@ __global__ void __launch_bounds__(64) obs_kernel(DevModel M, DevBatch Bt, TaskDe
       Bt.solved[e] = dist < T.pose_thd ? 1.f : 0.f;
       Bt.done[e] = dist > T.far_th ? 1.f : 0.f;
     }
+  } else if (T.task == MYO_TASK_HOLD) {
+    // obj_hold_v0.py:66-118.  The object's site sits at the origin of its free body, whose world position is the free joint's qpos
+    // (free-floating models are not origin-shifted); the goal site is world-fixed = the target row
+    const int nq = T.nq, nqh = nq - 7, nvh = nv - 6;
+    const float* qq = Bt.qpos + (size_t)e * nq;
+    for (int i = lane; i < nqh; i += 64) o[i] = qq[i];
+    for (int i = lane; i < nvh; i += 64) o[nqh + i] = v[i] * dt;
+    float err2 = 0.f, act2 = 0.f;
+    if (lane < 3) {
+      float p = qq[nqh + lane] + M.origin[lane], er = Bt.target[(size_t)e * T.ntarget + lane] - p;
+      o[nqh + nvh + lane] = p; o[nqh + nvh + 3 + lane] = er;
+      err2 = er * er;
+    }
+    for (int i = lane; i < nu; i += 64) { float ai = a[i]; const int sl = M.act_obs[i]; if (sl >= 0) { o[nqh + nvh + 6 + sl] = ai; act2 += ai * ai; } }
+    if (obs_only) return;
+    float dist = sqrtf(wave_sum(err2));
+    float actn = sqrtf(wave_sum(act2)) / (float)(M.na_obs > 0 ? M.na_obs : 1);
+    if (lane == 0) {
+      float bonus = (dist < 2.f * T.near_th ? 1.f : 0.f) + (dist < T.near_th ? 1.f : 0.f);
+      float drop = dist > T.far_th ? 1.f : 0.f;
+      Bt.reward[e] = T.w_reach * (-dist) + T.w_bonus * bonus + T.w_act_reg * (-actn) + T.w_penalty * (-drop);
+      Bt.solved[e] = dist < T.near_th ? 1.f : 0.f;
+      Bt.done[e] = drop;
+    }
   }
 }
 

@@ -99,6 +99,12 @@ REGISTRY["motorFingerPoseRandom-v0"] = dict(_pose_spec([-0.2, -0.4, 0.1, 0.1], [
 # act_reg weight 5.  (ExoRandom additionally re-draws a body mass per episode -- a per-env model edit, not offered.)
 REGISTRY["myoElbowPose1D6MExoFixed-v0"] = dict(_pose_spec([2.0], [2.0], "random", "generate", 0.175, "myoelbow_1dof6muscles_1dofexo"),
                                                weights=dict(pose=1.0, bonus=4.0, act_reg=5.0, penalty=50.0))
+# myoHandObjHoldFixed-v0 (envs/myo/myobase/__init__.py:596-604, obj_hold_v0.py:13-118): MyoHand palm up + a free ellipsoid object; goal = the
+# model's goal site.  (ObjHoldRandom re-draws the object's geom size per episode: a per-env model edit, not offered.)
+REGISTRY["myoHandObjHoldFixed-v0"] = dict(
+    model="myohand_hold", task="hold", max_episode_steps=75, frame_skip=10, normalize_act=True, reset_type="init",
+    goal=(-0.240, -0.520, 1.470), goal_th=0.010, drop_th=0.300,
+    weights=dict(goal_dist=100.0, bonus=4.0, penalty=10.0, act_reg=0.0))
 # myoFingerReach*-v0 (envs/myo/myobase/__init__.py:82-105): IFtip to an absolute target box; far_th = ReachEnvV0's default 0.35
 REGISTRY["myoFingerReachFixed-v0"] = _reach_box_spec("myofinger_v0", ("IFtip",), [(0.2, 0.05, 0.20)], [(0.2, 0.05, 0.20)], 0.35)
 REGISTRY["myoFingerReachRandom-v0"] = _reach_box_spec("myofinger_v0", ("IFtip",), [(0.1, -0.1, 0.1)], [(0.27, 0.1, 0.3)], 0.35)
@@ -119,6 +125,7 @@ for _id in [k for k in list(REGISTRY) if k.startswith("myo")]:
 # registered by the reference but not runnable on the HIP path (DESIGN.md "out of scope")
 UNSUPPORTED = {
     "myoElbowPose1D6MExoRandom-v0": "re-draws the mass of body carry_weight per episode (a per-env model edit)",
+    "myoHandObjHoldRandom-v0": "re-draws the object's geom size per episode (a per-env model edit)",
     "myoLegRoughTerrainWalk-v0": "height-field terrain contacts are not implemented in the HIP kernel",
 }
 
@@ -202,6 +209,15 @@ class BatchedMyoEnv:
                 weights=[w[k] for k in ("vel_reward", "done", "cyclic_hip", "ref_rot", "joint_angle_rew")],
                 init_qpos=key_qpos[2], init_qvel=key_qvel[2])
             self.obs_dim = (m.nq - 2) + m.nv + 16 + 4 * m.nu
+        elif spec["task"] == "hold":
+            init = np.array(m.qpos0, float)
+            init[:-7] = 0.0                                            # obj_hold_v0.py:63-64: fully open hand, palm up
+            init[0] = -1.5
+            self.batch.configure(task=capi.TASK_HOLD, frame_skip=self.frame_skip, reset_random=0, target_generate=0,
+                                 target_lo=np.asarray(spec["goal"], float), target_hi=np.asarray(spec["goal"], float), init_qpos=init,
+                                 near_th=spec["goal_th"], far_th=spec["drop_th"],
+                                 w_reach=w["goal_dist"], w_bonus=w["bonus"], w_act_reg=w["act_reg"], w_penalty=w["penalty"])
+            self.obs_dim = (m.nq - 7) + (m.nv - 6) + 6 + m.n_muscle
         else:
             tips = [m.name2id("site", t) for t in spec["tips"]]
             n = len(tips)

@@ -391,7 +391,11 @@ def lower(cm):
             if np.isfinite(r) and (c - top) @ axis - r > margin:
                 pruned += 1
                 continue
-            if not (m.geom_type[stat] == GEOM_PLANE and stat == g1 and m.geom_type[mov] in (GEOM_CAPSULE, GEOM_ELLIPSOID)):
+            # not provably out of reach (e.g. a free object over the scene's floor / pedestal): a plane goes to the analytic plane
+            # narrow phases, a static cylinder to the generic convex one (the kernel's geom frames accept world-fixed geoms)
+            plane_ok = m.geom_type[stat] == GEOM_PLANE and stat == g1 and m.geom_type[mov] in (GEOM_CAPSULE, GEOM_ELLIPSOID)
+            cyl_ok = m.geom_type[stat] == GEOM_CYLINDER and m.geom_type[mov] in (GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_SPHERE, GEOM_CYLINDER)
+            if not (plane_ok or cyl_ok):
                 raise NotImplementedError(f"HIP path: cannot prune static geom {stat} against moving geom {mov}")
         ok = (GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_SPHERE, GEOM_CYLINDER)
         plane_pair = t1 == GEOM_PLANE

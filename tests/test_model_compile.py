@@ -182,3 +182,21 @@ def test_motor_assets_match_fresh_compile(stem, rel):
     fresh, asset = M.from_mjcf(os.path.join(REFERENCE, rel)), M.load_asset(stem)
     for k, v in fresh.arrays.items():
         assert np.allclose(np.asarray(v, float), np.asarray(asset.arrays[k], float), rtol=0, atol=1e-12), k
+
+
+def test_hand_object_model():
+    """myohand_hold.xml: MyoHand + a free ellipsoid object (second root link with a free joint, condim 1 geom mixing to 3 against the hand's
+    geoms) over the scene's floor plane and pedestal cylinder, which stay in the pair table as world-fixed geoms."""
+    from myosuite_mjx_amd import model as M
+    m = M.load_asset("myohand_hold")
+    assert (m.nq, m.nv, m.nu, m.n_muscle) == (30, 29, 39, 39) and int(m.jnt_type[-1]) == 0 and int(m.hip_flags[0]) == 1
+    assert np.allclose(m.qpos0[-7:], [-0.235, -0.51, 1.45, 1, 0, 0, 0])
+    og, cg = m.name2id("geom", "object"), list(m.hip_cg_geom)
+    rows = [r for r in m.hip_pair_i if cg[r[0]] == og or cg[r[1]] == og]
+    partners = {int(cg[r[0]]) if cg[r[1]] == og else int(cg[r[1]]) for r in rows}
+    assert {0, 1} <= partners and len(partners) >= 28          # floor, pedestal and every collidable hand geom
+    assert all(r[5] == 3 for r in rows)                          # condim max(1, 3)
+    if os.path.isdir(REFERENCE):
+        fresh = M.from_mjcf(os.path.join(REFERENCE, "envs/myo/assets/hand/myohand_hold.xml"))
+        for k, v in fresh.arrays.items():
+            assert np.allclose(np.asarray(v, float), np.asarray(m.arrays[k], float), rtol=0, atol=1e-12), k

@@ -16,6 +16,7 @@ MODELS = {
     "myoelbow_1dof6muscles": "myosuite/envs/myo/assets/elbow/myoelbow_1dof6muscles.xml",
     "myoelbow_1dof6muscles_1dofexo": "myosuite/envs/myo/assets/elbow/myoelbow_1dof6muscles_1dofexo.xml",
     "motorfinger_v0": "myosuite/simhive/myo_sim/finger/motorfinger_v0.xml",
+    "myohand_hold": "myosuite/envs/myo/assets/hand/myohand_hold.xml",
 }
 
 if __name__ == "__main__":
