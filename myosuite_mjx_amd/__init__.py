@@ -13,5 +13,6 @@ importable, so the directory is `myosuite_mjx_amd`.
 from .envs import REGISTRY, UNSUPPORTED, BatchedMyoEnv, make  # noqa: F401
 from .policy import BraxPolicy  # noqa: F401
 from .sim import HipSimScene, get, make_data, put_model, set_, step  # noqa: F401
+from . import trace  # noqa: F401  (batched rollouts <-> the reference's Trace logger layout)
 
 __version__ = "0.1.0"
