@@ -64,6 +64,8 @@ typedef enum myo_field {
   MYO_F_ELAPSED,     /* [B][1] int32 env steps since the last reset (gym TimeLimit counter) */
   MYO_F_ACTION,      /* [B][nu]  library-owned action buffer: write normalised actions here and pass its pointer to myo_step */
   MYO_F_FATIGUE,     /* [B][3*nu] fatigue compartments MA | MR | MF (muscle condition "fatigue") */
+  MYO_F_HFIELD,      /* [B][nrow*ncol] height-field elevation per env (terrain models: mjModel.hfield_data, rewritten per episode by
+                        TerrainEnvV0.reset, walk_v0.py:563-622); absent (MYO_E_ARG) for models without a colliding height field */
   MYO_F_COUNT
 } myo_field;
 
@@ -113,7 +115,12 @@ typedef struct myo_walk_config {
   float w_vel_reward, w_done, w_cyclic_hip, w_ref_rot, w_joint_angle_rew;
   const float* init_qpos;                                      /* host, nq floats: reset pose (reset_type "init": key_qpos[2]) */
   const float* init_qvel;                                      /* host, nv floats or NULL (zero) */
+  /* TerrainEnvV0 (walk_v0.py:490-671, myoLeg{Rough,Hilly,Stair}TerrainWalk-v0), terrain models only; all zero for WalkEnvV0 */
+  float knee_height;                                           /* > 0: also done when COM height - mean feet height < this (0.61, :660-671) */
+  int terrain;                                                 /* myo_terrain: elevation grid re-drawn at every reset of an env (:563-622) */
+  float terrain_scalar_lo, terrain_scalar_hi;                  /* hilly / stairs height scale ~ U(lo, hi); variant "fixed": lo == hi */
 } myo_walk_config;
+typedef enum myo_terrain { MYO_TERRAIN_NONE = 0, MYO_TERRAIN_ROUGH = 1, MYO_TERRAIN_HILLY = 2, MYO_TERRAIN_STAIRS = 3 } myo_terrain;
 
 const char* myo_last_error(void);
 int myo_version(void);

@@ -14,7 +14,7 @@ SRC_PATH = os.path.join(_HERE, "csrc", "myo_hip.hip")
 
 # field ids (myo_field)
 (F_QPOS, F_QVEL, F_ACT, F_CTRL, F_WARMSTART, F_TIME, F_TARGET, F_OBS, F_REWARD, F_DONE, F_SOLVED, F_FLAGS, F_DIAG,
- F_QACC, F_TENLEN, F_ACTFORCE, F_SITEXPOS, F_ELAPSED, F_ACTION, F_FATIGUE) = range(20)
+ F_QACC, F_TENLEN, F_ACTFORCE, F_SITEXPOS, F_ELAPSED, F_ACTION, F_FATIGUE, F_HFIELD) = range(21)
 INT_FIELDS = (F_FLAGS, F_DIAG, F_ELAPSED)
 BENCH_OBS, BENCH_FRESH_ACTIONS, BENCH_AUTORESET = 1, 2, 4
 ACTMAP_NONE, ACTMAP_MUSCLE_SIGMOID, ACTMAP_SIGMOID_FATIGUE, ACTMAP_SIGMOID_REAFFERENTATION = 0, 1, 2, 3
@@ -44,7 +44,11 @@ class WalkConfig(C.Structure):
                 ("body_talus_l", C.c_int), ("body_talus_r", C.c_int), ("body_pelvis", C.c_int), ("body_torso", C.c_int),
                 ("qadr_hip_flexion_l", C.c_int), ("qadr_hip_flexion_r", C.c_int), ("qadr_joint_angle", C.c_int * 4),
                 ("w_vel_reward", C.c_float), ("w_done", C.c_float), ("w_cyclic_hip", C.c_float), ("w_ref_rot", C.c_float),
-                ("w_joint_angle_rew", C.c_float), ("init_qpos", C.POINTER(C.c_float)), ("init_qvel", C.POINTER(C.c_float))]
+                ("w_joint_angle_rew", C.c_float), ("init_qpos", C.POINTER(C.c_float)), ("init_qvel", C.POINTER(C.c_float)),
+                ("knee_height", C.c_float), ("terrain", C.c_int), ("terrain_scalar_lo", C.c_float), ("terrain_scalar_hi", C.c_float)]
+
+
+TERRAIN_NONE, TERRAIN_ROUGH, TERRAIN_HILLY, TERRAIN_STAIRS = 0, 1, 2, 3
 
 
 def build_library(force=False, verbose=False):
@@ -183,7 +187,7 @@ class HipBatch:
         _chk(lib().myo_batch_configure(self.h, C.byref(c)))
 
     def configure_walk(self, *, frame_skip, hip_period, min_height, max_rot, target_x_vel, target_y_vel, target_rot, bodies, qadr_hip_flexion,
-                       qadr_joint_angle, weights, init_qpos, init_qvel=None):
+                       qadr_joint_angle, weights, init_qpos, init_qvel=None, knee_height=0.0, terrain=0, terrain_scalar=(0.0, 0.0)):
         """walk task (WalkEnvV0).  bodies = (talus_l, talus_r, pelvis, torso) body ids; weights = (vel_reward, done, cyclic_hip,
         ref_rot, joint_angle_rew)."""
         c = WalkConfig()
@@ -198,6 +202,8 @@ class HipBatch:
         iv = np.ascontiguousarray(init_qvel, np.float32) if init_qvel is not None else None
         c.init_qpos = iq.ctypes.data_as(C.POINTER(C.c_float))
         c.init_qvel = iv.ctypes.data_as(C.POINTER(C.c_float)) if iv is not None else None
+        c.knee_height, c.terrain = float(knee_height), int(terrain)
+        c.terrain_scalar_lo, c.terrain_scalar_hi = float(terrain_scalar[0]), float(terrain_scalar[1])
         _chk(lib().myo_batch_configure_walk(self.h, C.byref(c)))
 
     def set_condition(self, frame_skip, epl_actuator=-1, eip_actuator=-1):

@@ -76,6 +76,7 @@ struct DevBatch {
   int B;
   float *qpos, *qvel, *act, *ctrl, *warm, *time, *target, *obs, *reward, *done, *solved, *qacc, *tenlen, *actforce, *sitexpos;
   int *flags, *diag, *elapsed, *episode;
+  float* hfield;   // [B][nrow * ncol] height-field elevation per env (terrain models; NULL otherwise)
   int* mprw;   // [B][64] MPR warm-start table carried between the substep tasks of the scheduler (word 63: entry count)
   float* fatigue;          // [B][3][nu]: MA, MR, MF of the 3CC-r fatigue model (muscle condition "fatigue")
   float fat_dt;            // its time step = frame_skip * timestep
@@ -88,6 +89,8 @@ struct TaskDev {
   float pose_thd, far_th, near_th, w_pose, w_bonus, w_act_reg, w_penalty, w_reach;
   const float *target_lo, *target_hi, *init_qpos, *jnt_lo, *jnt_hi;
   const float* init_qvel;   // walk task: reset velocity (NULL = zero)
+  int terrain, hf_n;        // terrain walk: myo_terrain kind and cells of the elevation grid re-drawn at reset (0: none)
+  float terrain_lo, terrain_hi;
 };
 
 // walk task (walk_v0.py:WalkEnvV0): its observation needs a forward pass at the post-step state, which the wave kernel
@@ -101,6 +104,7 @@ struct DevWalk {
   int qadr_hfl, qadr_hfr, qadr_ja[4];
   float w_vel, w_done, w_cyc, w_rot, w_ja;
   float mass_total, static_mcom[3];
+  float knee_height;   // > 0 (TerrainEnvV0): also done when COM height - mean feet height falls below it
 };
 enum { KF_AUX = 1, KF_OBS_ONLY = 2, KF_RESET_ONLY = 4 };   // step_kernel_w flags: observation pass without stepping / without reward / only for just-reset envs
 

@@ -255,6 +255,14 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
       w.has_free = fl[0]; w.nq = fl[1]; w.neq = fl[2];
       if (fl.size() < 6) { myo_model_free(m); return fail(MYO_E_BLOB, "hip_flags: blob predates the actuator-kind tables; recompile the model"); }
       w.has_j0 = fl[3]; d.na_obs = fl[4]; m->has_affine = fl[5] != 0;
+      {
+        std::vector<int> hi; std::vector<float> hf; const float* tf2;
+        if ((rc = load_i(m, blob, "hip_hf_i", &tmpi, &hi)) || (rc = load_f(m, blob, "hip_hf_f", &tf2, &hf))) { myo_model_free(m); return rc; }
+        w.hf.on = hi[0]; w.hf.nrow = hi[1]; w.hf.ncol = hi[2]; w.hf.cg = hi[3];
+        for (int k = 0; k < 4; k++) w.hf.size[k] = hf[k];
+        for (int k = 0; k < 3; k++) w.hf.pos[k] = hf[4 + k];
+        if (w.hf.on && (w.hf.nrow > 128 || w.hf.ncol > 100 || d.npair > 1023)) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "height field: at most 128 x 100 cells and 1023 pairs"); }
+      }
       if ((rc = load_f(m, blob, "hip_gt_j0", &w.gt_j0)) || (rc = load_i(m, blob, "hip_act_obs", &d.act_obs))) { myo_model_free(m); return rc; }
       const float* tf;
       if ((rc = load_i(m, blob, "hip_body_link", &tmpi, &m->body_link)) || (rc = load_f(m, blob, "hip_body_lpos", &tf, &m->body_lpos)) ||
@@ -335,6 +343,8 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   BA(b->d_tlo, b->ntarget_alloc) BA(b->d_thi, b->ntarget_alloc) BA(b->d_init, nq) BA(b->d_jlo, nv) BA(b->d_jhi, nv)
   BA(b->d_action, (size_t)B * nu)
   BA(d.fatigue, (size_t)B * 3 * nu)
+  d.hfield = nullptr;
+  if (m->dw.hf.on) { BA(d.hfield, (size_t)B * m->dw.hf.nrow * m->dw.hf.ncol) }   // zero-filled: flat terrain at the geom's height
   BA(b->d_initv, nv)
   { void* pw = nullptr; if ((rc = balloc(b, &pw, sizeof(DevWalk)))) { myo_batch_free(b); return rc; } b->d_walk = (DevWalk*)pw; }
   BA(b->d_stamps, (size_t)B * 12 * 2 * 2)      // 2 x 12 long long per workgroup (diagnostic build)
@@ -384,6 +394,7 @@ int myo_batch_configure(myo_batch* b, const myo_task_config* c) {
   if (c->ntarget > b->ntarget_alloc || c->ntip > 8) return fail(MYO_E_ARG, "myo_batch_configure: ntarget/ntip too large");
   if (c->task == MYO_TASK_WALK) return fail(MYO_E_ARG, "use myo_batch_configure_walk for the walk task");
   T.init_qvel = nullptr;
+  T.terrain = 0; T.hf_n = 0;
   T.task = c->task; T.frame_skip = c->frame_skip; T.reset_random = c->reset_random; T.target_generate = c->target_generate;
   T.ntarget = c->ntarget; T.ntip = c->ntip;
   for (int i = 0; i < 8; i++) T.tip_site[i] = c->tip_site[i];
@@ -436,6 +447,10 @@ int myo_batch_configure_walk(myo_batch* b, const myo_walk_config* c) {
   w.qadr_hfl = c->qadr_hip_flexion_l; w.qadr_hfr = c->qadr_hip_flexion_r;
   w.w_vel = c->w_vel_reward; w.w_done = c->w_done; w.w_cyc = c->w_cyclic_hip; w.w_rot = c->w_ref_rot; w.w_ja = c->w_joint_angle_rew;
   w.mass_total = m->mass[0];
+  w.knee_height = c->knee_height;
+  if (c->terrain != MYO_TERRAIN_NONE && !(m->dw.hf.on && m->dw.hf.nrow == 100 && m->dw.hf.ncol == 100))
+    return fail(MYO_E_UNSUPPORTED, "terrain walk needs a model with a colliding 100 x 100 height field");
+  if (c->terrain < 0 || c->terrain > MYO_TERRAIN_STAIRS) return fail(MYO_E_ARG, "walk task: bad terrain kind");
   HIPCHK(hipSetDevice(m->device));
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(b->d_walk, &w, sizeof w, hipMemcpyHostToDevice));
@@ -445,6 +460,7 @@ int myo_batch_configure_walk(myo_batch* b, const myo_walk_config* c) {
   T.task = MYO_TASK_WALK; T.frame_skip = c->frame_skip; T.reset_random = 0; T.target_generate = 0; T.ntarget = 0; T.ntip = 0;
   T.obs_dim = w.obs_dim;
   T.init_qvel = c->init_qvel ? b->d_initv : nullptr;
+  T.terrain = c->terrain; T.hf_n = c->terrain ? m->dw.hf.nrow * m->dw.hf.ncol : 0; T.terrain_lo = c->terrain_scalar_lo; T.terrain_hi = c->terrain_scalar_hi;
   return MYO_OK;
 }
 
@@ -472,6 +488,9 @@ static int field_info(myo_batch* b, int f, void** p, size_t* pitch, size_t* widt
     case MYO_F_ELAPSED: *p = d.elapsed; *pitch = *width = 1; break;
     case MYO_F_ACTION: *p = b->d_action; *pitch = *width = nu; break;
     case MYO_F_FATIGUE: *p = d.fatigue; *pitch = *width = 3 * nu; break;
+    case MYO_F_HFIELD:
+      if (!d.hfield) return fail(MYO_E_ARG, "MYO_F_HFIELD: the model has no colliding height field");
+      *p = d.hfield; *pitch = *width = b->model->dw.hf.nrow * b->model->dw.hf.ncol; break;
     case MYO_F_SITEXPOS: *p = d.sitexpos; *pitch = *width = b->task.ntip > 0 ? 3 * b->task.ntip : 1; break;
     default: return fail(MYO_E_ARG, "unknown field");
   }
@@ -576,6 +595,7 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       attr_w = true;
     }
     const int* order = nullptr;
@@ -591,7 +611,7 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     }
     const int resident = n_cu * (m->wave_cfg == 1 ? 8 : 16);
     const bool sched_ok = !kflags && Bn >= 64 && Bn <= SCHED_ENV_MASK && nsub + (wk ? 1 : 0) <= 15 && nsub > 0;
-    const bool sched = sched_ok && (sched_mode == 1 || (sched_mode == -1 && m->wave_cfg == 1 && Bn >= 2 * resident));
+    const bool sched = sched_ok && !m->dw.hf.on && (sched_mode == 1 || (sched_mode == -1 && m->wave_cfg == 1 && Bn >= 2 * resident));
     if (b->balance && Bn >= 1024 && Bn % 4 == 0 && !kflags && !sched) {
       static int prio_mode = -1;
       if (prio_mode < 0) { const char* e = getenv("MYO_PRIO"); prio_mode = e ? atoi(e) : 2; }
@@ -620,6 +640,9 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     else if (m->wave_cfg == 0)
       hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, false, 0>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                          (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0, S);
+    else if (m->dw.hf.on)     // terrain models: the instantiation with the height-field narrow phase
+      hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, false, 0, true>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, wk, kflags, S);
     else if (m->leg_sizes)
       hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, false, 2>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                          (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, wk, kflags, S);

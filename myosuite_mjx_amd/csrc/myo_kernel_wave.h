@@ -24,8 +24,11 @@ struct LayW {
   int tJp;                                                    // persistent sparse tendon rows (only for models with tendon limits)
   int total;
 };
+// colliding height field (terrain models): world-fixed, axis-aligned; elevation data lives per env in DevBatch.hfield
+struct HfDev { int on, nrow, ncol, cg; float size[4], pos[3]; };
 struct DevModelW {
   LayW lay;
+  HfDev hf;
   const int *seg_order, *seg_tendon, *gt_dl;
   const float* link_mat0;
   int nwrapseg, ndl, has_tl;
@@ -159,6 +162,45 @@ __device__ __forceinline__ float straight_w(const DevModel& M, const LayW& Y, fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// ---- height field vs convex primitive (mjc_ConvexHField [3P], restated in oracle/myo_oracle.c convex_hfield) -------------------------
+// sub-grid of cells under the geom's AABB (rel = geom centre - height field position, ext = AABB half extents); false: cannot touch
+__device__ __forceinline__ bool hf_range(const HfDev& H, const float* rel, const float* ext, float rb, float margin, int& r0, int& r1, int& c0, int& c1, float& zmin) {
+  if (H.size[0] < rel[0] - rb - margin || -H.size[0] > rel[0] + rb + margin || H.size[1] < rel[1] - rb - margin || -H.size[1] > rel[1] + rb + margin) return false;
+  if (H.size[2] < rel[2] - rb - margin || -H.size[3] > rel[2] + rb + margin) return false;
+  const float lo[3] = {rel[0] - ext[0], rel[1] - ext[1], rel[2] - ext[2]}, hi[3] = {rel[0] + ext[0], rel[1] + ext[1], rel[2] + ext[2]};
+  if (lo[0] - margin > H.size[0] || hi[0] + margin < -H.size[0] || lo[1] - margin > H.size[1] || hi[1] + margin < -H.size[1] ||
+      lo[2] - margin > H.size[2] || hi[2] + margin < -H.size[3]) return false;
+  c0 = max(0, (int)floorf((lo[0] + H.size[0]) / (2.f * H.size[0]) * (float)(H.ncol - 1)));
+  c1 = min(H.ncol - 1, (int)ceilf((hi[0] + H.size[0]) / (2.f * H.size[0]) * (float)(H.ncol - 1)));
+  r0 = max(0, (int)floorf((lo[1] + H.size[1]) / (2.f * H.size[1]) * (float)(H.nrow - 1)));
+  r1 = min(H.nrow - 1, (int)ceilf((hi[1] + H.size[1]) / (2.f * H.size[1]) * (float)(H.nrow - 1)));
+  zmin = lo[2];
+  return r1 > r0 && c1 > c0;
+}
+// the three strip vertices ending at zig-zag index j of cell row r: vertex jj sits at column jj / 2, row r + 1 (jj even) or r (jj odd)
+__device__ __forceinline__ void hf_prism(const HfDev& H, const float* data, int r, int j, float* x, float* y, float* z) {
+  const float dx = 2.f * H.size[0] / (float)(H.ncol - 1), dy = 2.f * H.size[1] / (float)(H.nrow - 1);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int jj = j - 2 + k, c = jj >> 1, rr = r + ((jj & 1) ? 0 : 1);
+    x[k] = dx * (float)c - H.size[0]; y[k] = dy * (float)rr - H.size[1]; z[k] = data[rr * H.ncol + c] * H.size[2];
+  }
+}
+// walks the prisms of the sub-grid in mjc_ConvexHField's order; counts those whose top is not wholly below the geom and, when out != NULL,
+// writes their candidate words (pair | row << 10 | zig-zag index << 17) from position `at`
+__device__ __forceinline__ int hf_walk(const HfDev& H, const float* data, int r0, int r1, int c0, int c1, float zcut, int p, int* out, int at, int cap) {
+  int n = 0;
+  for (int r = r0; r < r1; r++)
+    for (int j = 2 * c0 + 2; j <= 2 * c1 + 1; j++) {
+      float x[3], y[3], z[3];
+      hf_prism(H, data, r, j, x, y, z);
+      if (z[0] < zcut && z[1] < zcut && z[2] < zcut) continue;
+      if (out && at + n < cap) out[at + n] = p | (r << 10) | (j << 17);
+      n++;
+    }
+  return n;
+}
+
 // Substep-granular dynamic scheduling (opt-in, MYO_SCHED=1).  With one workgroup per env, a launch of B = 4096 envs fills every
 // wave slot of the chip exactly once and lasts as long as its slowest SIMD (env work varies +-12 %).  Here the waves are
 // persistent instead: the unit of work is ONE substep of one env.  Each XCD owns a FIFO ring of its envs (state stays in that
@@ -215,7 +257,7 @@ template <int SPEC> static bool sizes_match(int nq, int nv, int nu, int nl, int 
          ncg == Z::ncg && npair == Z::npair;
 }
 
-template <int NVT, int KC, int NC, int NTR, int WPE, bool SCHED, int SPEC>
+template <int NVT, int KC, int NC, int NTR, int WPE, bool SCHED, int SPEC, bool HF = false>
 __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restrict__ Mp, const DevModelW* __restrict__ Wp, DevBatch Bt,
                                                         const float* __restrict__ action, int actmap, int nsub, long long* stamps,
                                                         const int* __restrict__ order, const DevWalk* __restrict__ wk, int kflags, SchedDev S) {
@@ -658,6 +700,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           float ja = expf(-5.0f * mag);
           float r00 = 1.0f - 2.0f * (q[2] * q[2] + q[3] * q[3]) / (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
           float done = (height < wk->min_height || fabsf(r00) > wk->max_rot) ? 1.f : 0.f;
+          if (wk->knee_height > 0.f && height - 0.5f * (pl[2] + pr[2]) < wk->knee_height) done = 1.f;   // TerrainEnvV0._get_knee_condition (walk_v0.py:660-671)
           Bt.reward[env] = wk->w_vel * vel_reward + wk->w_done * done + wk->w_cyc * cyclic + wk->w_rot * ref_rot + wk->w_ja * ja;
           Bt.done[env] = done;
           Bt.solved[env] = vel_reward >= 1.0f ? 1.f : 0.f;
@@ -721,9 +764,31 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       for (int base = 0; base < npair_; base += 64) {
         int p = base + lane;
         bool hit = false;
+        int nh = 0, hr0 = 0, hr1 = 0, hc0 = 0, hc1 = 0;   // height-field pair: cell range under the geom, prisms that can touch it
+        float hzcut = 0.f;
         if (p < npair_) {
           const int* P = M.pair_i + 6 * p;
-          if (!(M.disable_ellipsoid && P[4] == 0)) {
+          if (HF && P[4] == 4) {
+            const int g2 = P[1], ty = M.cg_type[g2];
+            const float *x2 = E + Y.gpos + 3 * g2, *ax = E + Y.gax + 3 * g2, *sz = M.cg_size + 3 * g2;
+            const float rel[3] = {x2[0] - W.hf.pos[0], x2[1] - W.hf.pos[1], x2[2] - W.hf.pos[2]}, margin = M.pair_f[12 * p];
+            float ext[3];
+            if (ty == GEOM_ELLIPSOID) {
+              float R[9];
+              geom_world_mat(M, Y, E, g2, R);
+#pragma unroll
+              for (int k = 0; k < 3; k++) { const float a = R[3 * k] * sz[0], b = R[3 * k + 1] * sz[1], c = R[3 * k + 2] * sz[2]; ext[k] = sqrtf(a * a + b * b + c * c); }
+            } else {
+#pragma unroll
+              for (int k = 0; k < 3; k++)
+                ext[k] = ty == GEOM_SPHERE ? sz[0] : (ty == GEOM_CAPSULE ? sz[0] + sz[1] * fabsf(ax[k]) : sz[1] * fabsf(ax[k]) + sz[0] * sqrtf(fmaxf(0.f, 1.f - ax[k] * ax[k])));
+            }
+            float zmin;
+            if (hf_range(W.hf, rel, ext, M.cg_rbound[g2], margin, hr0, hr1, hc0, hc1, zmin)) {
+              hzcut = zmin - margin;
+              nh = hf_walk(W.hf, Bt.hfield + (size_t)env * W.hf.nrow * W.hf.ncol, hr0, hr1, hc0, hc1, hzcut, p, nullptr, 0, 0);
+            }
+          } else if (!(M.disable_ellipsoid && P[4] == 0)) {
             int g1 = P[0], g2 = P[1];
             const float *x1 = E + Y.gpos + 3 * g1, *x2 = E + Y.gpos + 3 * g2;
             float dif[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
@@ -783,6 +848,17 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         int pos = ncand + __popcll(bal & ((1ull << lane) - 1ull));
         if (hit && pos < NCAND) cand[pos] = p;
         ncand += __popcll(bal);
+        if (HF) {   // height-field pairs expand into one candidate per prism, appended in pair order
+          unsigned long long hb = __ballot(nh > 0);
+          int myat = 0;
+          while (hb) {
+            const int L = __ffsll((long long)hb) - 1;
+            hb &= hb - 1ull;
+            if (lane == L) myat = ncand;
+            ncand += rdlanei(nh, L);
+          }
+          if (nh > 0) hf_walk(W.hf, Bt.hfield + (size_t)env * W.hf.nrow * W.hf.ncol, hr0, hr1, hc0, hc1, hzcut, p, cand, myat, NCAND);
+        }
       }
       if (ncand > NCAND) { flags |= MYO_FLAG_CAND_OVERFLOW; ncand = NCAND; }
       f_cand += ncand;
@@ -798,7 +874,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         float dist = 0, dist2 = 0, cpos[3] = {0, 0, 0}, cpos2[3] = {0, 0, 0}, nrm[3] = {1, 0, 0};
         int p = -1;
         if (ci < ncand) {
-          p = cand[ci];
+          const int cw = cand[ci];
+          p = HF ? (cw & 1023) : cw;
           const int* P = M.pair_i + 6 * p;
           int g1 = P[0], g2 = P[1];
           float margin = M.pair_f[12 * p];
@@ -872,9 +949,25 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             nsup = 0;
             // MPR in geom1's own frame: obj1 needs no rotation / translation at all (identity frame), obj2 carries the
             // relative pose R1^T R2, R1^T (x2 - x1); normal and position are rotated back afterwards
-            float R1[9];
-            geom_world_mat(M, Y, E, g1, R1);
+            float R1[9], xo[3] = {x1[0], x1[1], x1[2]};
             CObj o1, o2;
+            const bool prism = HF && P[4] == 4;
+            if (prism) {
+              // obj1 = one triangular prism of the height field, about its centroid, in the (axis-aligned) height-field frame
+              float hx[3], hy[3], hz[3];
+              hf_prism(W.hf, Bt.hfield + (size_t)env * W.hf.nrow * W.hf.ncol, (cw >> 10) & 127, cw >> 17, hx, hy, hz);
+              const float cen[3] = {(hx[0] + hx[1] + hx[2]) * (1.f / 3.f), (hy[0] + hy[1] + hy[2]) * (1.f / 3.f), 0.5f * ((hz[0] + hz[1] + hz[2]) * (1.f / 3.f) - W.hf.size[3])};
+#pragma unroll
+              for (int k = 0; k < 3; k++) { o1.mat[k] = hx[k] - cen[0]; o1.mat[3 + k] = hy[k] - cen[1]; o1.mat[6 + k] = hz[k] - cen[2]; o1.pos[k] = 0.f; xo[k] += cen[k]; }
+              o1.S[0] = -W.hf.size[3] - cen[2]; o1.S[1] = o1.S[2] = 0.f; o1.h = -1.f;
+#pragma unroll
+              for (int k = 0; k < 9; k++) R1[k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
+              geom_world_mat(M, Y, E, g2, o2.mat);
+#pragma unroll
+              for (int k = 0; k < 3; k++) o2.pos[k] = x2[k] - xo[k];
+              cobj_shape(o2, M.cg_type[g2], sz2);
+            } else {
+            geom_world_mat(M, Y, E, g1, R1);
             {
               float R2[9], rel[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
               geom_world_mat(M, Y, E, g2, R2);
@@ -889,21 +982,22 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
 #pragma unroll
             for (int k = 0; k < 3; k++) o1.pos[k] = 0.f;
             cobj_shape(o1, M.cg_type[g1], sz1); cobj_shape(o2, M.cg_type[g2], sz2);
+            }
             o1.margin = o2.margin = 0.5f * margin;
             float depth, dir[3], pos[3], nw[3] = {0.f, 0.f, 0.f};
             bool have_nw = false;
-            for (int i = 0; i < n_mprw; i++) {
+            for (int i = 0; i < (prism ? 0 : n_mprw); i++) {   // (prisms are not warm-started: the table is keyed by pair)
               if (((const int*)(E + Y.mprw))[4 * i] == p) { nw[0] = E[Y.mprw + 4 * i + 1]; nw[1] = E[Y.mprw + 4 * i + 2]; nw[2] = E[Y.mprw + 4 * i + 3]; have_nw = true; }
             }
-            if (mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr)) {
+            if (mpr_penetration<HF>(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr)) {
               dist = margin - depth;
               normalize3(dir);
-              mpr_hit = true; mpr_n[0] = dir[0]; mpr_n[1] = dir[1]; mpr_n[2] = dir[2];
+              mpr_hit = !prism; mpr_n[0] = dir[0]; mpr_n[1] = dir[1]; mpr_n[2] = dir[2];
               float dw[3], pw[3];
               matvec(dw, R1, dir);
               matvec(pw, R1, pos);
 #pragma unroll
-              for (int k = 0; k < 3; k++) { cpos[k] = pw[k] + x1[k]; nrm[k] = dw[k]; }
+              for (int k = 0; k < 3; k++) { cpos[k] = pw[k] + xo[k]; nrm[k] = dw[k]; }
               hit = true;
             }
           }

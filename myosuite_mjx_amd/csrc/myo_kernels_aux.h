@@ -137,6 +137,35 @@ __global__ void __launch_bounds__(64) reset_kernel(DevBatch Bt, TaskDev T, int n
     float lo = T.target_lo[i], hi = T.target_hi[i];
     Bt.target[(size_t)e * T.ntarget + i] = T.target_generate ? lo + (hi - lo) * u01(seed, ge * 4096 + 2048 + i, 2) : lo;
   }
+  if (T.terrain && Bt.hfield) {
+    // TerrainEnvV0.reset (walk_v0.py:563-622): a fresh 100 x 100 elevation grid per episode (in units of the height field's z scale).
+    // Distribution parity only for the random draws, as for every reset.
+    float* H = Bt.hfield + (size_t)e * T.hf_n;
+    const int n = T.hf_n;
+    if (T.terrain == MYO_TERRAIN_ROUGH) {
+      // rough ~ U(-0.5, 0.5)^n, min-max normalised over the grid, * 0.08 - 0.02 (:563-567)
+      float mn = 1e30f, mx = -1e30f;
+      for (int i = lane; i < n; i += 64) { float u = u01(seed ^ 0x9E3779B97F4A7C15ull, ge * 16384 + i, 3); mn = fminf(mn, u); mx = fmaxf(mx, u); }
+      for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
+      const float inv = 1.0f / fmaxf(mx - mn, 1e-12f);
+      for (int i = lane; i < n; i += 64) H[i] = (u01(seed ^ 0x9E3779B97F4A7C15ull, ge * 16384 + i, 3) - mn) * inv * 0.08f - 0.02f;
+    } else {
+      const float sc = T.terrain_lo + (T.terrain_hi - T.terrain_lo) * u01(seed ^ 0x9E3779B97F4A7C15ull, ge * 16384, 4);
+      for (int i = lane; i < n; i += 64) {
+        const int k = n - 1 - i;             // np.flip(grid, [0, 1]) of a row-major grid = the flat array reversed
+        float v;
+        if (T.terrain == MYO_TERRAIN_HILLY) {
+          // 3000 flat cells at the top level, then -2 + 0.5 (sin(linspace(0, 3 pi, 7000) + pi/2) - 1), min-max normalised: 0.5 + 0.5 cos(t) (:569-592)
+          v = k < 3000 ? 1.0f : 0.5f + 0.5f * cosf((float)(k - 3000) * (3.0f * 3.14159265358979f / 6999.0f));
+        } else {
+          // 52 flat rows, then 12 stairs of 4 rows each, 0.1 high, normalised by 2 + 0.1 * 12 (:594-620)
+          const int row = k / 100;
+          v = row < 52 ? 0.0f : 0.1f * (float)((row - 52) / 4) / 3.2f;
+        }
+        H[i] = v * sc;
+      }
+    }
+  }
 }
 
 // observation + reward (pose_v0.py:98-138, obs_vec_dict.py:86-98); one 64-lane workgroup per env, rows written coalesced

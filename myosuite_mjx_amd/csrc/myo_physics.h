@@ -293,8 +293,22 @@ struct Sup { float v[3], v1[3]; };  // Minkowski point and its witness on obj1 (
 // Minkowski-difference support of the two margin-inflated shapes.  Contract of the wave kernel's caller: obj `a` sits in the
 // identity frame at the origin (the pair is expressed in geom 1's frame) and `dir` is a unit vector, so a's support needs no
 // rotation and the spherical inflation is just +-margin * dir (no norm, no division).
+// HF (height-field kernels only): obj `a` may instead be a triangular prism of the height field (mjc_ConvexHField's prism_support), marked by
+// a.h < 0 and stored in a's otherwise unused frame slots: a.mat = x[3] | y[3] | z_top[3] of the three columns, a.S[0] = z of the base;
+// only the bottom or the top triangle can be extremal, by the sign of dir_z.
+template <bool HF = false>
 __device__ void mink_support(const CObj& a, const CObj& b, const float* dir, Sup& s) {
   float nd[3] = {-dir[0], -dir[1], -dir[2]}, dl[3], pl[3], w2[3];
+  if (HF && a.h < 0.f) {
+    const bool top = dir[2] >= 0.f;
+    float d0 = dir[0] * a.mat[0] + dir[1] * a.mat[3], d1 = dir[0] * a.mat[1] + dir[1] * a.mat[4], d2 = dir[0] * a.mat[2] + dir[1] * a.mat[5];
+    if (top) { d0 += dir[2] * a.mat[6]; d1 += dir[2] * a.mat[7]; d2 += dir[2] * a.mat[8]; }
+    int best = d1 > d0 ? 1 : 0;
+    if (d2 > fmaxf(d0, d1)) best = 2;
+    s.v1[0] = best == 0 ? a.mat[0] : (best == 1 ? a.mat[1] : a.mat[2]);
+    s.v1[1] = best == 0 ? a.mat[3] : (best == 1 ? a.mat[4] : a.mat[5]);
+    s.v1[2] = top ? (best == 0 ? a.mat[6] : (best == 1 ? a.mat[7] : a.mat[8])) : a.S[0];
+  } else
   support_local(a.S, a.h, dir, s.v1);
   matTvec(dl, b.mat, nd);
   support_local(b.S, b.h, dl, pl);
@@ -325,6 +339,7 @@ __device__ __forceinline__ void expand_portal(Sup* p, const Sup& v4) {
 #ifndef MPR_WARM_EPS
 #define MPR_WARM_EPS 0.05f
 #endif
+template <bool HF = false>
 __device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup = nullptr,
                                 const float* nwarm = nullptr) {
   Sup p[4];
@@ -343,7 +358,7 @@ __device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int m
 #pragma unroll
       for (int i = 0; i < 3; i++) dir[i] = nwarm[i] + MPR_WARM_EPS * (c * t1[i] + sn * t2[i]);
       normalize3(dir);
-      mink_support(o1, o2, dir, p[k]);
+      mink_support<HF>(o1, o2, dir, p[k]);
       beyond = beyond && dot3(p[k].v, dir) >= 0;
     }
     float s12, s23, s31;
@@ -356,7 +371,7 @@ __device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int m
   if (!warm_ok) {
   dir[0] = -p[0].v[0]; dir[1] = -p[0].v[1]; dir[2] = -p[0].v[2];
   normalize3(dir);
-  mink_support(o1, o2, dir, p[1]);
+  mink_support<HF>(o1, o2, dir, p[1]);
   if (dot3(p[1].v, dir) < 0) return false;
   cross3(dir, p[0].v, p[1].v);
   if (norm3(dir) < 1e-12f) {
@@ -367,7 +382,7 @@ __device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int m
     return true;
   }
   normalize3(dir);
-  mink_support(o1, o2, dir, p[2]);
+  mink_support<HF>(o1, o2, dir, p[2]);
   if (dot3(p[2].v, dir) < 0) return false;
 #pragma unroll
   for (int k = 0; k < 3; k++) { va[k] = p[1].v[k] - p[0].v[k]; vb[k] = p[2].v[k] - p[0].v[k]; }
@@ -376,7 +391,7 @@ __device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int m
   if (dot3(dir, p[0].v) > 0) { Sup t = p[1]; p[1] = p[2]; p[2] = t; dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
   for (int it = 0;; it++) {
     if (it > maxit) return false;
-    mink_support(o1, o2, dir, p[3]);
+    mink_support<HF>(o1, o2, dir, p[3]);
     if (dot3(p[3].v, dir) < 0) return false;
     bool cont = false;
     cross3(va, p[1].v, p[3].v);
@@ -397,7 +412,7 @@ __device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int m
     portal_dir(p, dir);
     if (dot3(dir, p[1].v) >= 0) break;
     Sup v4;
-    mink_support(o1, o2, dir, v4);
+    mink_support<HF>(o1, o2, dir, v4);
     float dv4 = dot3(v4.v, dir);
     float dmin = fminf(fminf(dv4 - dot3(p[1].v, dir), dv4 - dot3(p[2].v, dir)), dv4 - dot3(p[3].v, dir));
     if (dv4 < 0 || dmin <= tol) return false;
@@ -406,7 +421,7 @@ __device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int m
   Sup v4;
   for (int it = 0;; it++) {
     portal_dir(p, dir);
-    mink_support(o1, o2, dir, v4);
+    mink_support<HF>(o1, o2, dir, v4);
     float dv4 = dot3(v4.v, dir);
     float dmin = fminf(fminf(dv4 - dot3(p[1].v, dir), dv4 - dot3(p[2].v, dir)), dv4 - dot3(p[3].v, dir));
     if (dmin <= tol || it > maxit) { if (nsup) *nsup = it; break; }

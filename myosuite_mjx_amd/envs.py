@@ -115,6 +115,11 @@ REGISTRY["myoLegWalk-v0"] = dict(
     model="myolegs", task="walk", max_episode_steps=1000, frame_skip=10, normalize_act=True, reset_type="init",
     min_height=0.8, max_rot=0.8, hip_period=100, target_x_vel=0.0, target_y_vel=1.2, target_rot=None,
     weights=dict(vel_reward=5.0, done=-100.0, cyclic_hip=-10.0, ref_rot=10.0, joint_angle_rew=5.0))
+# myoLeg{Rough,Hilly,Stair}TerrainWalk-v0 (envs/myo/myobase/__init__.py:462-520; TerrainEnvV0, walk_v0.py:490-671): the walk task on a height
+# field re-drawn per episode; hilly / stairs are registered with variant "fixed" (height scale 0.63 / 2.5; otherwise U(0.53, 0.73) / U(1.5, 3.5))
+for _id, _kind, _sc in (("myoLegRoughTerrainWalk-v0", "rough", (0.0, 0.0)), ("myoLegHillyTerrainWalk-v0", "hilly", (0.63, 0.63)),
+                        ("myoLegStairTerrainWalk-v0", "stairs", (2.5, 2.5))):
+    REGISTRY[_id] = dict(REGISTRY["myoLegWalk-v0"], model="myolegs_terrain", terrain=_kind, terrain_scalar=_sc, knee_height=0.61)
 # muscle-condition variants (register_env_with_variants, envs/myo/myobase/__init__.py:14-48): myoSarc* (sarcopenia), myoFati* (fatigue)
 # for every myo* id, myoReaf* (EIP -> EPL tendon transfer) for the myoHand* ids
 for _id in [k for k in list(REGISTRY) if k.startswith("myo")]:
@@ -124,9 +129,9 @@ for _id in [k for k in list(REGISTRY) if k.startswith("myo")]:
         REGISTRY[_id[:3] + "Reaf" + _id[3:]] = dict(REGISTRY[_id], muscle_condition="reafferentation")
 # registered by the reference but not runnable on the HIP path (DESIGN.md "out of scope")
 UNSUPPORTED = {
+    # (nothing of the walk family: the terrain envs run on the height-field instantiation of the leg kernel)
     "myoElbowPose1D6MExoRandom-v0": "re-draws the mass of body carry_weight per episode (a per-env model edit)",
     "myoHandObjHoldRandom-v0": "re-draws the object's geom size per episode (a per-env model edit)",
-    "myoLegRoughTerrainWalk-v0": "height-field terrain contacts are not implemented in the HIP kernel",
 }
 
 
@@ -207,7 +212,9 @@ class BatchedMyoEnv:
                 qadr_hip_flexion=[jadr("hip_flexion_l"), jadr("hip_flexion_r")],
                 qadr_joint_angle=[jadr(n) for n in ("hip_adduction_l", "hip_adduction_r", "hip_rotation_l", "hip_rotation_r")],
                 weights=[w[k] for k in ("vel_reward", "done", "cyclic_hip", "ref_rot", "joint_angle_rew")],
-                init_qpos=key_qpos[2], init_qvel=key_qvel[2])
+                init_qpos=key_qpos[2], init_qvel=key_qvel[2], knee_height=spec.get("knee_height", 0.0),
+                terrain={"rough": capi.TERRAIN_ROUGH, "hilly": capi.TERRAIN_HILLY, "stairs": capi.TERRAIN_STAIRS}.get(spec.get("terrain"), capi.TERRAIN_NONE),
+                terrain_scalar=spec.get("terrain_scalar", (0.0, 0.0)))
             self.obs_dim = (m.nq - 2) + m.nv + 16 + 4 * m.nu
         elif spec["task"] == "hold":
             init = np.array(m.qpos0, float)

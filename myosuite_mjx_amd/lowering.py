@@ -22,7 +22,7 @@ import math
 
 import numpy as np
 
-from .mjcf import (GEOM_CAPSULE, GEOM_CYLINDER, GEOM_ELLIPSOID, GEOM_PLANE, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE,
+from .mjcf import (GEOM_CAPSULE, GEOM_CYLINDER, GEOM_ELLIPSOID, GEOM_HFIELD, GEOM_PLANE, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE,
                    WRAP_CYLINDER, WRAP_PULLEY, WRAP_SITE, WRAP_SPHERE, mat2quat, quat2mat, quat_mul)
 from . import setconst as sc
 
@@ -399,7 +399,8 @@ def lower(cm):
                 raise NotImplementedError(f"HIP path: cannot prune static geom {stat} against moving geom {mov}")
         ok = (GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_SPHERE, GEOM_CYLINDER)
         plane_pair = t1 == GEOM_PLANE
-        if not plane_pair and (t1 not in ok or t2 not in ok):
+        hfield_pair = t1 == GEOM_HFIELD and t2 in ok and geom_link[g1] < 0      # world-fixed height field first (the compiler orders it so)
+        if not plane_pair and not hfield_pair and (t1 not in ok or t2 not in ok):
             raise NotImplementedError(f"HIP path: geom pair types {t1},{t2}")
         lst = dof_list(geom_link[g1], geom_link[g2])
         # contact parameter mixing (mj_contactParam), equal priorities
@@ -422,7 +423,7 @@ def lower(cm):
         b1, b2 = m.geom_bodyid[g1], m.geom_bodyid[g2]
         invw = m.body_invweight0[b1, 0] + m.body_invweight0[b2, 0]
         # narrow-phase type: 1 capsule-capsule (analytic), 2 plane-capsule, 3 plane-ellipsoid, 0 generic convex (MPR)
-        ptype = 1 if (t1 == GEOM_CAPSULE and t2 == GEOM_CAPSULE) else (2 if (plane_pair and t2 == GEOM_CAPSULE) else (3 if plane_pair else 0))
+        ptype = 1 if (t1 == GEOM_CAPSULE and t2 == GEOM_CAPSULE) else (2 if (plane_pair and t2 == GEOM_CAPSULE) else (3 if plane_pair else (4 if hfield_pair else 0)))
         pairs_i.append([cg_index(g1), cg_index(g2), len(pair_dl), len(lst), ptype, condim])
         pairs_f.append([margin, max(m.geom_gap[g1], m.geom_gap[g2]), fric[0], invw, solref[0], solref[1],
                         solimp[0], solimp[1], solimp[2], solimp[3], solimp[4], 0.0])
@@ -504,6 +505,10 @@ def lower(cm):
     A["hip_link_chain"] = np.array(chain, np.int32)
     act_obs = np.full(nu, -1, np.int32)      # slot of each actuator's activation in the observation's "act" block (sim.data.act order)
     act_obs[kind == 0] = np.arange(int((kind == 0).sum()))
+    # height field (terrain models): [on, nrow, ncol, collision-geom index] and [x, y half extents, z scale, base depth, position]
+    hfg = int(A["hfield_dims"][2]) if "hfield_dims" in A else -1
+    A["hip_hf_i"] = np.array([int(hfg >= 0), int(A["hfield_dims"][0]), int(A["hfield_dims"][1]), cgs.index(hfg) if hfg >= 0 else -1] if "hfield_dims" in A else [0, 0, 0, -1], np.int32)
+    A["hip_hf_f"] = np.array([*A["hfield_size"], *(geom_lpos[hfg] if hfg >= 0 else np.zeros(3))] if "hfield_dims" in A else np.zeros(7))
     A["hip_act_obs"] = act_obs
     A["hip_gt_j0"] = gt_j0_tab
     A["hip_flags"] = np.array([int(has_free), int(A["sizes"][0]), neq, int(gt_j0_tab.any()), int((kind == 0).sum()), int((kind == 1).any())], np.int32)

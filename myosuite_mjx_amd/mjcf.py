@@ -204,6 +204,8 @@ def geom_rbound(gtype, size):
         return float(np.linalg.norm(size))
     if gtype == GEOM_MESH:
         return float(size[0])      # conservative sphere about the geom frame origin (see _finalize)
+    if gtype == GEOM_HFIELD:
+        return float(np.linalg.norm(size))
     return 0.0
 
 
@@ -243,8 +245,10 @@ class CompiledModel:
 
 # --------------------------------------------------------------------------- the compiler
 class _Compiler:
-    def __init__(self, path):
+    def __init__(self, path, terrain=False):
         self.path = os.path.abspath(path)
+        self.terrain = terrain      # True: keep the height field's pairs and raise its geom to z = 0 (TerrainEnvV0.reset, walk_v0.py:624-630)
+        self.hfields = {}
         self.comp = dict(angle="degree", eulerseq="xyz", inertiafromgeom="auto", balanceinertia=False,
                          boundmass=0.0, boundinertia=0.0, meshdir="", autolimits=True,
                          settotalmass=-1.0, inertiagrouprange=(0, 5))
@@ -386,6 +390,10 @@ class _Compiler:
 
     def _do_asset(self, e):
         for ch in e:
+            if ch.tag == "hfield":
+                if "file" in ch.attrib:
+                    raise NotImplementedError("hfield file")
+                self.hfields[ch.attrib["name"]] = dict(size=_floats(ch.attrib["size"], 4), nrow=int(ch.attrib["nrow"]), ncol=int(ch.attrib["ncol"]))
             if ch.tag == "mesh":
                 name = ch.attrib.get("name") or os.path.splitext(os.path.basename(ch.attrib["file"]))[0]
                 self.meshes[name] = dict(file=ch.attrib["file"], dir=ch.attrib.get("__dir"),
@@ -499,7 +507,12 @@ class _Compiler:
                  solref=_floats(at.get("solref", "0.02 1"), 2), solimp=_solimp(at.get("solimp")),
                  solmix=float(at.get("solmix", 1)), priority=int(at.get("priority", 0)),
                  density=float(at.get("density", 1000)), mass=float(at["mass"]) if "mass" in at else None,
-                 group=int(at.get("group", 0)), mesh=at.get("mesh"))
+                 group=int(at.get("group", 0)), mesh=at.get("mesh"), hfield=at.get("hfield"))
+        if gtype == GEOM_HFIELD:
+            hf = self.hfields[g["hfield"]]
+            g["size"] = np.array(hf["size"][:3], float)          # (x half-extent, y half-extent, z scale); the base depth lives in hfield_size
+            if self.terrain:
+                g["pos"] = np.array([pos[0], pos[1], 0.0])
         self.geoms.append(g)
         self.bodies[bid]["geoms"].append(len(self.geoms) - 1)
 
@@ -967,8 +980,25 @@ class _Compiler:
         # heightfield geoms: kept as geoms, but their pairs are dropped (myoLegWalk-v0 parks the terrain below the floor plane,
         # envs/myo/myobase/walk_v0.py:257-261); recorded so that callers can see it
         nhf = sum(1 for (a, b) in pairs if geoms[a]["type"] == GEOM_HFIELD or geoms[b]["type"] == GEOM_HFIELD)
-        pairs = [(a, b) for (a, b) in pairs if geoms[a]["type"] != GEOM_HFIELD and geoms[b]["type"] != GEOM_HFIELD]
+        hf_geoms = [i for i, g in enumerate(geoms) if g["type"] == GEOM_HFIELD]
+        if len(hf_geoms) > 1:
+            raise NotImplementedError("more than one height field geom")
+        if self.terrain:
+            # height-field model variant (TerrainEnvV0): pairs kept, hfield geom first in each pair (mj_collision orders by geom type)
+            nhf = 0
+            g = geoms[hf_geoms[0]]
+            if not np.allclose(g["quat"], [1, 0, 0, 0]) or self.bodies[g["body"]]["parent"] >= 0 and weld[g["body"]] != 0:
+                raise NotImplementedError("height field geom must be world-fixed and axis-aligned")
+            pairs = [(b, a) if geoms[b]["type"] == GEOM_HFIELD else (a, b) for (a, b) in pairs]
+            for (a, b) in pairs:
+                if geoms[a]["type"] == GEOM_HFIELD and geoms[b]["type"] not in (GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER):
+                    raise NotImplementedError("height field against a non-convex-primitive geom")
+        else:
+            pairs = [(a, b) for (a, b) in pairs if geoms[a]["type"] != GEOM_HFIELD and geoms[b]["type"] != GEOM_HFIELD]
         A["dropped_hfield_pairs"] = np.array([nhf], np.int32)
+        hf = self.hfields[geoms[hf_geoms[0]]["hfield"]] if hf_geoms else None
+        A["hfield_size"] = np.array(hf["size"], float) if hf else np.zeros(4)            # x, y half-extents, z scale, base depth
+        A["hfield_dims"] = np.array([hf["nrow"], hf["ncol"], hf_geoms[0] if (hf and self.terrain) else -1] if hf else [0, 0, -1], np.int32)
         # explicit <contact><pair>: bypass the contype / parent filters; condim etc. from the pair element
         pair_condim = [-1] * len(pairs)          # -1: derive from the geoms (dynamic pair)
         for pr in self.pairs:
@@ -1035,6 +1065,7 @@ def _pad(v, default):
     return out
 
 
-def compile_mjcf(path) -> CompiledModel:
-    """Compile an MJCF file into flat arrays (see module docstring)."""
-    return _Compiler(path).compile()
+def compile_mjcf(path, terrain=False) -> CompiledModel:
+    """Compile an MJCF file into flat arrays (see module docstring).  terrain=True: the model variant the reference's TerrainEnvV0
+    creates at reset (height-field geom raised to z = 0 and colliding); False: its pairs are dropped (myoLegWalk-v0 parks it at -10 m)."""
+    return _Compiler(path, terrain).compile()

@@ -35,7 +35,8 @@ typedef double real;
 #define MAXVAL ((real)1e10)
 #define MINIMP ((real)0.0001)
 #define MAXIMP ((real)0.9999)
-#define NCON_MAX 64
+#define NCON_MAX 128
+#define GEOM_PRISM 100   /* internal shape of the height-field narrow phase: a triangular prism given by 6 vertices */
 
 enum { GEOM_PLANE = 0, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH };
 enum { JNT_FREE = 0, JNT_BALL, JNT_SLIDE, JNT_HINGE };
@@ -67,6 +68,8 @@ typedef struct {
   real *tendon_range, *tendon_margin, *tendon_stiffness, *tendon_damping, *tendon_solref, *tendon_solimp,
       *tendon_invweight0;
   int *actuator_trnid, *actuator_trntype, *actuator_ctrllimited, *actuator_forcelimited, *actuator_kind;
+  real* hfield_size;   /* x, y half-extents, z scale, base depth */
+  int* hfield_dims;    /* nrow, ncol, geom id of the colliding height field (-1: none) */
   real *actuator_gear, *actuator_dynprm, *actuator_gainprm, *actuator_biasprm, *actuator_ctrlrange,
       *actuator_forcerange, *actuator_lengthrange, *actuator_acc0;
   int *pair_geom, *pair_condim;
@@ -91,6 +94,8 @@ typedef struct {
   real *actuator_length, *actuator_moment;
   Contact con[NCON_MAX];
   int ncon, ncon_dropped;
+  float* hfield_data;   /* [nrow * ncol] elevation in [0, 1]-ish units of hfield_size[2], row-major (mjModel.hfield_data: per instance here, the
+                           terrain envs rewrite it per episode) */
   /* velocity stage */
   real *cvel, *cdof_dot, *ten_velocity, *actuator_velocity, *qfrc_bias, *qfrc_passive;
   /* acceleration stage */
@@ -174,6 +179,7 @@ Model* myoo_load(const void* blobv, size_t nbytes) {
   LI(tendon_adr); LI(tendon_num); LI(tendon_limited); LF(tendon_range); LF(tendon_margin); LF(tendon_stiffness);
   LF(tendon_damping); LF(tendon_solref); LF(tendon_solimp); LF(tendon_invweight0);
   LI(actuator_trnid); LI(actuator_trntype); LI(actuator_ctrllimited); LI(actuator_forcelimited); LI(actuator_kind);
+  LF(hfield_size); LI(hfield_dims);
   LF(actuator_gear); LF(actuator_dynprm); LF(actuator_gainprm); LF(actuator_biasprm); LF(actuator_ctrlrange);
   LF(actuator_forcerange); LF(actuator_lengthrange); LF(actuator_acc0);
   LI(pair_geom); LI(pair_condim);
@@ -285,11 +291,17 @@ Data* myoo_make_data(const Model* m) {
   AL(wk, 16 * nv + 2 * nv * nv + 8 * ne + 12 * nb + 64);
 #undef AL
   memcpy(d->qpos, m->qpos0, m->nq * sizeof(real));
+  d->hfield_data = (float*)calloc((size_t)m->hfield_dims[0] * m->hfield_dims[1] + 1, sizeof(float));
   return d;
+}
+
+void myoo_set_hfield(const Model* m, Data* d, const float* data) {
+  memcpy(d->hfield_data, data, (size_t)m->hfield_dims[0] * m->hfield_dims[1] * sizeof(float));
 }
 
 void myoo_free_data(Data* d) {
   if (!d) return;
+  free(d->hfield_data);
   real** f = (real**)&d->qpos;
   (void)f;
   free(d->qpos); free(d->qvel); free(d->act); free(d->ctrl); free(d->qacc_warmstart); free(d->xpos); free(d->xquat);
@@ -847,6 +859,7 @@ static int capsule_capsule(Contact* c, real margin, const real* pos1, const real
 
 /* ---- general convex pair (ellipsoid pads): margin-inflated MPR, see convex section below */
 static int convex_pair(const Model* m, const Data* d, Contact* c, real margin, int g1, int g2);
+static void convex_hfield(const Model* m, Data* d, real margin, real gap, int g1, int g2);
 
 static void contact_params(const Model* m, Contact* c, int g1, int g2) { /* mj_contactParam [3P] */
   int p1 = m->geom_priority[g1], p2 = m->geom_priority[g2];
@@ -912,6 +925,7 @@ static void collision(const Model* m, Data* d) { /* mj_collision over the compil
       real h = dot3(dif, ax);
       if ((h < 0 ? -h : h) - m->geom_size[3 * gc + 1] - m->geom_rbound[go] > margin) continue;
     }
+    if (t1 == GEOM_HFIELD) { convex_hfield(m, d, margin, gap, g1, g2); continue; }
     Contact c;
     memset(&c, 0, sizeof c);
     int hit = 0;
@@ -1065,6 +1079,14 @@ static void support_local(const CObj* o, const real* dl, real* out) {
       out[0] = n > MINVAL ? dl[0] / n * o->size[0] : 0;
       out[1] = n > MINVAL ? dl[1] / n * o->size[0] : 0;
       out[2] = dl[2] >= 0 ? o->size[1] : -o->size[1];
+      break;
+    }
+    case GEOM_PRISM: { /* prism_support [3P]: only the bottom (0..2) or top (3..5) triangle can be extremal, by the sign of dir_z */
+      const real* V = o->size;
+      int i0 = dl[2] < 0 ? 0 : 3, best = i0;
+      real bd = dot3(V + 3 * i0, dl);
+      for (int i = i0 + 1; i < i0 + 3; i++) { real t = dot3(V + 3 * i, dl); if (t > bd) { bd = t; best = i; } }
+      out[0] = V[3 * best]; out[1] = V[3 * best + 1]; out[2] = V[3 * best + 2];
       break;
     }
     default: out[0] = out[1] = out[2] = 0;
@@ -1221,6 +1243,86 @@ static int convex_pair(const Model* m, const Data* d, Contact* c, real margin, i
   for (int k = 0; k < 3; k++) { c->frame[k] = dir[k]; c->pos[k] = pos[k]; }
   for (int k = 3; k < 9; k++) c->frame[k] = 0;
   return 1;
+}
+
+/* Height field against a convex primitive: mjc_ConvexHField (engine_collision_convex.c) [3P, restated from the documented algorithm].
+ * In the height field's frame: bounding tests, the geom's AABB from six support queries, the sub-grid of cells under it; every row of
+ * cells is walked as a zig-zag strip of vertices (r+1, c), (r, c), (r+1, c+1), (r, c+1), ... and each three consecutive vertices span
+ * one triangular prism from the base depth up to the terrain surface; a prism whose top lies wholly below the geom is skipped, the
+ * others go through the same MPR as every convex pair (prism centre = mean of its six vertices), one contact each, at most 50 per
+ * pair (mjMAXCONPAIR).  Margin convention: as for the other convex pairs here (both shapes swept by margin / 2, dist = margin - depth);
+ * MuJoCo's own bookkeeping of the margin in this routine is not reproduced from a source and this 1 mm-level detail is parity-unpinned.
+ * The height field must be axis-aligned (checked by the model compiler). */
+static void convex_hfield(const Model* m, Data* d, real margin, real gap, int g1, int g2) {
+  const real* hs = m->hfield_size;
+  const int nrow = m->hfield_dims[0], ncol = m->hfield_dims[1];
+  const real* p1 = d->geom_xpos + 3 * g1;
+  real pos[3];
+  for (int k = 0; k < 3; k++) pos[k] = d->geom_xpos[3 * g2 + k] - p1[k];
+  const real r2 = m->geom_rbound[g2];
+  for (int i = 0; i < 2; i++) if (hs[i] < pos[i] - r2 - margin || -hs[i] > pos[i] + r2 + margin) return;
+  if (hs[2] < pos[2] - r2 - margin || -hs[3] > pos[2] + r2 + margin) return;
+  /* AABB of geom 2 in the height field frame */
+  CObj og = {pos, d->geom_xmat + 9 * g2, m->geom_size + 3 * g2, m->geom_type[g2], 0};
+  real lo[3], hi[3];
+  for (int a = 0; a < 3; a++) {
+    real dir[3] = {0, 0, 0}, s[3];
+    dir[a] = 1; support_world(&og, dir, s); hi[a] = s[a];
+    dir[a] = -1; support_world(&og, dir, s); lo[a] = s[a];
+  }
+  if (lo[0] - margin > hs[0] || hi[0] + margin < -hs[0] || lo[1] - margin > hs[1] || hi[1] + margin < -hs[1] ||
+      lo[2] - margin > hs[2] || hi[2] + margin < -hs[3]) return;
+  int cmin = (int)floor((lo[0] + hs[0]) / (2 * hs[0]) * (ncol - 1)), cmax = (int)ceil((hi[0] + hs[0]) / (2 * hs[0]) * (ncol - 1));
+  int rmin = (int)floor((lo[1] + hs[1]) / (2 * hs[1]) * (nrow - 1)), rmax = (int)ceil((hi[1] + hs[1]) / (2 * hs[1]) * (nrow - 1));
+  if (cmin < 0) cmin = 0;
+  if (rmin < 0) rmin = 0;
+  if (cmax > ncol - 1) cmax = ncol - 1;
+  if (rmax > nrow - 1) rmax = nrow - 1;
+  const real dx = 2 * hs[0] / (ncol - 1), dy = 2 * hs[1] / (nrow - 1);
+  const real ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, zero3[3] = {0, 0, 0};
+  int cnt = 0;
+  for (int r = rmin; r < rmax; r++) {
+    real vx[3] = {0, 0, 0}, vy[3] = {0, 0, 0}, vz[3] = {0, 0, 0};   /* the last three strip vertices (oldest first) */
+    int nvert = 0;
+    for (int c = cmin; c <= cmax; c++) {
+      for (int i = 0; i < 2; i++) {
+        const int rr = r + (i == 0 ? 1 : 0);
+        vx[0] = vx[1]; vy[0] = vy[1]; vz[0] = vz[1];
+        vx[1] = vx[2]; vy[1] = vy[2]; vz[1] = vz[2];
+        vx[2] = dx * c - hs[0]; vy[2] = dy * rr - hs[1]; vz[2] = (real)d->hfield_data[rr * ncol + c] * hs[2];
+        if (++nvert <= 2) continue;
+        if (vz[0] < lo[2] - margin && vz[1] < lo[2] - margin && vz[2] < lo[2] - margin) continue;   /* prism top wholly below the geom */
+        /* prism vertices relative to their mean */
+        real V[18], cen[3] = {0, 0, 0};
+        for (int k = 0; k < 3; k++) {
+          V[3 * k] = vx[k]; V[3 * k + 1] = vy[k]; V[3 * k + 2] = -hs[3];
+          V[9 + 3 * k] = vx[k]; V[9 + 3 * k + 1] = vy[k]; V[9 + 3 * k + 2] = vz[k];
+        }
+        for (int k = 0; k < 6; k++) for (int a = 0; a < 3; a++) cen[a] += V[3 * k + a] / 6;
+        for (int k = 0; k < 6; k++) for (int a = 0; a < 3; a++) V[3 * k + a] -= cen[a];
+        real rel[3] = {pos[0] - cen[0], pos[1] - cen[1], pos[2] - cen[2]};
+        CObj o1 = {zero3, ident, V, GEOM_PRISM, margin * (real)0.5};
+        CObj o2 = {rel, d->geom_xmat + 9 * g2, m->geom_size + 3 * g2, m->geom_type[g2], margin * (real)0.5};
+        real depth, dir[3], cp[3];
+#ifdef MYOO_FLOAT
+        if (!mpr_penetration(&o1, &o2, (real)1e-8, 60, &depth, dir, cp)) continue;
+#else
+        if (!mpr_penetration(&o1, &o2, (real)1e-11, 100, &depth, dir, cp)) continue;
+#endif
+        if (d->ncon >= NCON_MAX) { d->ncon_dropped++; continue; }
+        Contact* cc = &d->con[d->ncon];
+        memset(cc, 0, sizeof *cc);
+        cc->dist = margin - depth;
+        for (int k = 0; k < 3; k++) { cc->pos[k] = cp[k] + cen[k] + p1[k]; cc->frame[k] = dir[k]; }
+        make_frame(cc->frame);
+        contact_params(m, cc, g1, g2);
+        cc->includemargin = margin - gap;
+        cc->geom1 = g1; cc->geom2 = g2;
+        d->ncon++;
+        if (++cnt >= 50) return;
+      }
+    }
+  }
 }
 
 /* ------------------------------------------------------------------ constraints */

@@ -48,6 +48,7 @@ class Oracle:
         L.myoo_full_m.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         L.myoo_energy.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         L.myoo_set_switch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.myoo_set_hfield.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.myoo_step_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]
         self.real = np.float32 if L.myoo_sizeof_real() == 4 else np.float64
         self._blob = blob
@@ -81,6 +82,11 @@ class Oracle:
 
     def switches(self, disable_contact=0, disable_limit=0, disable_ellipsoid=0):
         self.lib.myoo_set_switch(self.m, disable_contact, disable_limit, disable_ellipsoid)
+
+    def set_hfield(self, data):
+        """Elevation grid [nrow, ncol] (mjModel.hfield_data) of the colliding height field."""
+        a = np.ascontiguousarray(data, np.float32).ravel()
+        self.lib.myoo_set_hfield(self.m, self.d, a.ctypes.data)
 
     def reset(self):
         self.lib.myoo_reset(self.m, self.d)

@@ -48,6 +48,12 @@ def motorfinger():
 
 
 @pytest.fixture(scope="session")
+def terrain():
+    from myosuite_mjx_amd import model as M
+    return M.load_asset("myolegs_terrain")
+
+
+@pytest.fixture(scope="session")
 def oracle64(hand):
     from oracle.oracle import Oracle
     return Oracle(hand.blob())

@@ -66,7 +66,11 @@ def test_registry_matches_reference_specs():
     assert np.allclose(f["target_lo"], HAND_POSE_FIXED) and f["reset_type"] == "init"
     rr = REGISTRY["myoHandReachRandom-v0"]
     assert rr["far_th"] == 0.034 and np.allclose(rr["target_lo"][:3], [-0.185, -0.577, 1.455]) and np.allclose(rr["target_hi"][:3], [-0.125, -0.517, 1.535])
-    assert "myoLegRoughTerrainWalk-v0" in UNSUPPORTED
+    for tid, kind, sc in (("myoLegRoughTerrainWalk-v0", "rough", (0.0, 0.0)), ("myoLegHillyTerrainWalk-v0", "hilly", (0.63, 0.63)),
+                          ("myoLegStairTerrainWalk-v0", "stairs", (2.5, 2.5))):      # envs/myo/myobase/__init__.py:462-520, walk_v0.py:569-597
+        t = REGISTRY[tid]
+        assert t["model"] == "myolegs_terrain" and t["terrain"] == kind and t["terrain_scalar"] == sc and t["knee_height"] == 0.61
+        assert t["max_episode_steps"] == 1000 and t["weights"] == REGISTRY["myoLegWalk-v0"]["weights"] and tid not in UNSUPPORTED
     lw = REGISTRY["myoLegWalk-v0"]                               # envs/myo/myobase/__init__.py:443-459, walk_v0.py:203-209
     assert lw["model"] == "myolegs" and lw["max_episode_steps"] == 1000 and lw["frame_skip"] == 10 and lw["reset_type"] == "init"
     assert (lw["min_height"], lw["max_rot"], lw["hip_period"], lw["target_x_vel"], lw["target_y_vel"]) == (0.8, 0.8, 100, 0.0, 1.2)

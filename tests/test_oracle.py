@@ -335,3 +335,52 @@ def test_stateless_actuators_in_the_oracle(exo, motorfinger):
     assert abs(o2.field("actuator_length")[0] - 8.5 * 1.0) < 1e-12
     for _ in range(20):
         assert o2.step(10) == 0                                                    # scene pairs never come into range (else rc 4)
+
+
+def _reference_terrain(kind, scalar=None, rng=None):
+    """The three elevation grids of TerrainEnvV0.reset (walk_v0.py:563-622), restated with numpy for the tests."""
+    if kind == "rough":
+        rough = rng.uniform(-0.5, 0.5, 10000)
+        return ((rough - rough.min()) / (rough.max() - rough.min()) * 0.08 - 0.02).reshape(100, 100)
+    if kind == "hilly":
+        comb = np.concatenate((-2 * np.ones(3000), -2 + 0.5 * (np.sin(np.linspace(0, 3 * np.pi, 7000) + np.pi / 2) - 1)))
+        norm = (comb - comb.min()) / (comb.max() - comb.min())
+        return np.flip(norm.reshape(100, 100) * scalar, [0, 1])
+    parts = [np.full((4, 100), -2 + 0.1 * j) for j in range(12)]
+    t = np.concatenate([np.full((52, 100), -2.0)] + parts, axis=0)
+    return np.flip(((t + 2) / (2 + 0.1 * 12)).reshape(100, 100) * scalar, [0, 1])
+
+
+def test_height_field_contacts_in_the_oracle(terrain):
+    """mjc_ConvexHField restated (oracle convex_hfield): the terrain model keeps the 31 height-field pairs (myolegs.xml:17,22, geom raised to
+    z = 0 as TerrainEnvV0.reset does); contact normals follow the local slope, a uniformly raised terrain lifts the standing model by the
+    same amount, and on flat ground at the floor's height the height field shares the load with the floor plane."""
+    from oracle.oracle import Oracle
+    m = terrain
+    hfg = int(m.hfield_dims[2])
+    assert m.hfield_dims.tolist()[:2] == [100, 100] and np.allclose(m.hfield_size, [7, 7, 1, 0.001]) and m.names["geom"][hfg] == "terrain"
+    assert sum(1 for p in m.pair_geom if hfg in p) == 31 and np.allclose(m.geom_pos[hfg], 0) and int(m.hip_hf_i[0]) == 1
+    kq = np.asarray(m.key_qpos).reshape(-1, m.nq)[2]
+    res = {}
+    for name, hf in (("flat", np.zeros((100, 100))), ("raised", np.full((100, 100), 0.05)),
+                     ("slope", np.tile(np.linspace(-0.3, 0.5, 100)[:, None], (1, 100)))):
+        o = Oracle(m.blob())
+        o.set_hfield(hf)
+        o.reset()
+        o.set_state(qpos=kq, qvel=np.zeros(m.nv), ctrl=np.zeros(80))
+        for _ in range(30):
+            assert o.step(10) == 0
+        cons = [c for c in o.contacts() if int(c[7]) == hfg]
+        res[name] = (o.field("qpos")[2], cons)
+    # (a geom reaching over a prism's side edge is pushed off that edge, not straight up: normals near cell boundaries tilt by a few degrees)
+    assert len(res["flat"][1]) >= 1 and all(c[6] > 0.99 for c in res["flat"][1])
+    assert 0.03 < res["raised"][0] - res["flat"][0] < 0.06                       # the whole model rides 5 cm higher (floor plane unloaded)
+    n = np.array([0.0, -0.8 / 14.0, 1.0]); n /= np.linalg.norm(n)                # slope of 0.8 m over the 14 m width, rising with y
+    assert len(res["slope"][1]) >= 1 and min(np.abs(c[4:7] - n).max() for c in res["slope"][1]) < 1e-6 and all(c[4:7] @ n > 0.99 for c in res["slope"][1])
+    # the reference's terrain shapes: ranges and the flip convention
+    rough = _reference_terrain("rough", rng=np.random.default_rng(0))
+    assert abs(rough.min() + 0.02) < 1e-12 and abs(rough.max() - 0.06) < 1e-12
+    hilly = _reference_terrain("hilly", 0.63)
+    assert abs(hilly.max() - 0.63) < 1e-9 and hilly.min() >= 0 and np.allclose(hilly[70:], 0.63) and hilly[50, 50] < 0.1
+    stairs = _reference_terrain("stairs", 2.5)
+    assert np.allclose(stairs[48:], 0) and np.allclose(np.diff(stairs[::-1][52::4, 0]), 0.1 / 3.2 * 2.5)

@@ -17,6 +17,7 @@ MODELS = {
     "myoelbow_1dof6muscles_1dofexo": "myosuite/envs/myo/assets/elbow/myoelbow_1dof6muscles_1dofexo.xml",
     "motorfinger_v0": "myosuite/simhive/myo_sim/finger/motorfinger_v0.xml",
     "myohand_hold": "myosuite/envs/myo/assets/hand/myohand_hold.xml",
+    "myolegs_terrain": ("myosuite/simhive/myo_sim/leg/myolegs.xml",),     # height field raised and colliding (TerrainEnvV0)
 }
 
 if __name__ == "__main__":
@@ -24,6 +25,6 @@ if __name__ == "__main__":
     for stem, rel in MODELS.items():
         if only and stem not in only:
             continue
-        m = M.from_mjcf(os.path.join(REF, rel))
+        m = M.from_mjcf(os.path.join(REF, rel[0]), terrain=True) if isinstance(rel, tuple) else M.from_mjcf(os.path.join(REF, rel))
         m.save(os.path.join(M.ASSET_DIR, stem))
         print(stem, dict(nq=m.nq, nv=m.nv, nu=m.nu, nbody=m.nbody, ntendon=m.ntendon, bytes=len(m.blob())))
