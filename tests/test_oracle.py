@@ -384,3 +384,55 @@ def test_height_field_contacts_in_the_oracle(terrain):
     assert abs(hilly.max() - 0.63) < 1e-9 and hilly.min() >= 0 and np.allclose(hilly[70:], 0.63) and hilly[50, 50] < 0.1
     stairs = _reference_terrain("stairs", 2.5)
     assert np.allclose(stairs[48:], 0) and np.allclose(np.diff(stairs[::-1][52::4, 0]), 0.1 / 3.2 * 2.5)
+
+
+def test_free_body_analytic_checks():
+    """Analytic pins for the free-joint path (no reference goldens exist for dynamics): a torque-free body (the ObjHold
+    ellipsoid) falls with exactly g and keeps its angular momentum and spin while its quaternion integrates, and at rest on
+    the scene's pedestal the contact carries its weight."""
+    from myosuite_mjx_amd import model as M
+    from oracle.oracle import Oracle
+    m = M.load_asset("myohand_hold")
+    o = Oracle(m.blob())
+    ob = m.name2id("body", "object")
+    mass, I = float(m.body_mass[ob]), np.asarray(m.body_inertia[ob], float)
+    assert 0.1 < mass < 0.13 and np.allclose(I, 1e-4)       # 4/3 pi abc rho = 0.113 kg; inertia clamped by boundinertia=1e-4 (myohand_assets.xml:11)
+    q = np.array(m.qpos0, float)
+    q[:23] = 0
+    q[23:26] = [0.6, -0.5, 2.0]                                                                  # far from the hand, 2 m up
+    quat = np.array([0.8, 0.3, -0.4, 0.33]); q[26:30] = quat / np.linalg.norm(quat)
+    v = np.zeros(m.nv)
+    v[23:26] = [0.3, -0.2, 0.5]
+    v[26:29] = [9.0, -6.0, 4.0]                                                                  # body-frame angular velocity (free joint convention)
+    o.reset()
+    o.set_state(qpos=q, qvel=v, ctrl=np.zeros(39))
+
+    def ang_mom():
+        qq = o.field("qpos")[26:30]
+        w = o.field("qvel")[26:29]
+        R = np.array([[1 - 2 * (qq[2] ** 2 + qq[3] ** 2), 2 * (qq[1] * qq[2] - qq[0] * qq[3]), 2 * (qq[1] * qq[3] + qq[0] * qq[2])],
+                      [2 * (qq[1] * qq[2] + qq[0] * qq[3]), 1 - 2 * (qq[1] ** 2 + qq[3] ** 2), 2 * (qq[2] * qq[3] - qq[0] * qq[1])],
+                      [2 * (qq[1] * qq[3] - qq[0] * qq[2]), 2 * (qq[2] * qq[3] + qq[0] * qq[1]), 1 - 2 * (qq[1] ** 2 + qq[2] ** 2)]])
+        Rb = R @ np.asarray(__import__("myosuite_mjx_amd.mjcf", fromlist=["quat2mat"]).quat2mat(np.asarray(m.body_iquat[ob], float)))
+        return Rb @ (I * (Rb.T @ (R @ w)))
+    L0, w0 = ang_mom(), v[26:29].copy()
+    nsteps = 200
+    for _ in range(nsteps):
+        assert o.step(1) == 0 and o.ncon == 0
+    t = nsteps * m.timestep
+    vel = o.field("qvel")
+    assert np.allclose(vel[23:25], v[23:25], atol=1e-12) and abs(vel[25] - (v[25] - 9.81 * t)) < 1e-9      # semi-implicit Euler is exact for constant g
+    L1 = ang_mom()
+    assert np.linalg.norm(L1 - L0) / np.linalg.norm(L0) < 2e-3                                    # first-order integrator: drift, not a torque
+    assert np.abs(vel[26:29] - w0).max() < 1e-9                                                   # isotropic inertia: no precession, no gyroscopic term
+    # at rest on the pedestal (top z = 0.015): one contact whose normal force is the weight
+    q[23:26] = [0.3, -0.5, 0.015 + 0.030]
+    q[26:30] = [1, 0, 0, 0]
+    o.reset()
+    o.set_state(qpos=q, qvel=np.zeros(m.nv), ctrl=np.zeros(39))
+    for _ in range(400):
+        assert o.step(1) == 0
+    assert o.ncon == 1 and np.abs(o.field("qvel")[23:26]).max() < 1e-3 and np.abs(o.field("qvel")[26:29]).max() < 2e-2   # settled (a slow residual roll remains)
+    f = o.field("efc_force")
+    # pyramidal condim 3: the normal force is the sum of the four edge forces (the limit rows of the hand come first)
+    assert abs(f[-4:].sum() - mass * 9.81) < 0.02 * mass * 9.81
