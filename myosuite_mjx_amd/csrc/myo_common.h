@@ -76,11 +76,11 @@ struct DevBatch {
   int B;
   float *qpos, *qvel, *act, *ctrl, *warm, *time, *target, *obs, *reward, *done, *solved, *qacc, *tenlen, *actforce, *sitexpos;
   int *flags, *diag, *elapsed, *episode;
-  float* hfield;   // [B][nrow * ncol] height-field elevation per env (terrain models; NULL otherwise)
   int* mprw;   // [B][64] MPR warm-start table carried between the substep tasks of the scheduler (word 63: entry count)
   float* fatigue;          // [B][3][nu]: MA, MR, MF of the 3CC-r fatigue model (muscle condition "fatigue")
   float fat_dt;            // its time step = frame_skip * timestep
   int reaf_epl, reaf_eip;  // actuator ids of the EIP -> EPL tendon transfer (muscle condition "reafferentation")
+  float* hfield;           // [B][nrow * ncol] height-field elevation per env (terrain models; NULL otherwise)
 };
 
 struct TaskDev {

@@ -28,7 +28,6 @@ struct LayW {
 struct HfDev { int on, nrow, ncol, cg; float size[4], pos[3]; };
 struct DevModelW {
   LayW lay;
-  HfDev hf;
   const int *seg_order, *seg_tendon, *gt_dl;
   const float* link_mat0;
   int nwrapseg, ndl, has_tl;
@@ -36,6 +35,7 @@ struct DevModelW {
   int nq, has_free, neq;          // free-floating root (nq = nv + 1), joint-coupling equalities
   int has_j0;                     // some actuator drives a joint directly: constant moment arms gt_j0 [ngt][maxnnz]
   const float* gt_j0;
+  HfDev hf;                       // (kept last: the field offsets of the tables above feed the hot loops' scalar loads)
   const int *link_free, *dof_qposadr, *eq_i, *link_chain_adr, *link_chain;
   const float* eq_f;
 };
@@ -945,26 +945,27 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
               for (int k = 0; k < 3; k++) cpos[k] = x2[k] + pw[k] - n[k] * 0.5f * d;
             }
           } else {
+            if constexpr (HF) {   // height-field kernels: generic convex pairs and prisms share one MPR call site
             const float zero3[3] = {0.f, 0.f, 0.f};
             nsup = 0;
             // MPR in geom1's own frame: obj1 needs no rotation / translation at all (identity frame), obj2 carries the
             // relative pose R1^T R2, R1^T (x2 - x1); normal and position are rotated back afterwards
-            float R1[9], xo[3] = {x1[0], x1[1], x1[2]};
+            float R1[9], cen[3] = {0.f, 0.f, 0.f};   // (cen: prism centroid; dead code unless HF -- nothing extra stays live across the MPR call)
             CObj o1, o2;
             const bool prism = HF && P[4] == 4;
             if (prism) {
               // obj1 = one triangular prism of the height field, about its centroid, in the (axis-aligned) height-field frame
               float hx[3], hy[3], hz[3];
               hf_prism(W.hf, Bt.hfield + (size_t)env * W.hf.nrow * W.hf.ncol, (cw >> 10) & 127, cw >> 17, hx, hy, hz);
-              const float cen[3] = {(hx[0] + hx[1] + hx[2]) * (1.f / 3.f), (hy[0] + hy[1] + hy[2]) * (1.f / 3.f), 0.5f * ((hz[0] + hz[1] + hz[2]) * (1.f / 3.f) - W.hf.size[3])};
+              cen[0] = (hx[0] + hx[1] + hx[2]) * (1.f / 3.f); cen[1] = (hy[0] + hy[1] + hy[2]) * (1.f / 3.f); cen[2] = 0.5f * ((hz[0] + hz[1] + hz[2]) * (1.f / 3.f) - W.hf.size[3]);
 #pragma unroll
-              for (int k = 0; k < 3; k++) { o1.mat[k] = hx[k] - cen[0]; o1.mat[3 + k] = hy[k] - cen[1]; o1.mat[6 + k] = hz[k] - cen[2]; o1.pos[k] = 0.f; xo[k] += cen[k]; }
+              for (int k = 0; k < 3; k++) { o1.mat[k] = hx[k] - cen[0]; o1.mat[3 + k] = hy[k] - cen[1]; o1.mat[6 + k] = hz[k] - cen[2]; o1.pos[k] = 0.f; }
               o1.S[0] = -W.hf.size[3] - cen[2]; o1.S[1] = o1.S[2] = 0.f; o1.h = -1.f;
 #pragma unroll
               for (int k = 0; k < 9; k++) R1[k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
               geom_world_mat(M, Y, E, g2, o2.mat);
 #pragma unroll
-              for (int k = 0; k < 3; k++) o2.pos[k] = x2[k] - xo[k];
+              for (int k = 0; k < 3; k++) o2.pos[k] = x2[k] - x1[k] - cen[k];
               cobj_shape(o2, M.cg_type[g2], sz2);
             } else {
             geom_world_mat(M, Y, E, g1, R1);
@@ -989,7 +990,10 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             for (int i = 0; i < (prism ? 0 : n_mprw); i++) {   // (prisms are not warm-started: the table is keyed by pair)
               if (((const int*)(E + Y.mprw))[4 * i] == p) { nw[0] = E[Y.mprw + 4 * i + 1]; nw[1] = E[Y.mprw + 4 * i + 2]; nw[2] = E[Y.mprw + 4 * i + 3]; have_nw = true; }
             }
-            if (mpr_penetration<HF>(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr)) {
+            bool pen;
+            if constexpr (HF) pen = mpr_penetration_t<true>(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr);
+            else pen = mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr);
+            if (pen) {
               dist = margin - depth;
               normalize3(dir);
               mpr_hit = !prism; mpr_n[0] = dir[0]; mpr_n[1] = dir[1]; mpr_n[2] = dir[2];
@@ -997,9 +1001,49 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
               matvec(dw, R1, dir);
               matvec(pw, R1, pos);
 #pragma unroll
-              for (int k = 0; k < 3; k++) { cpos[k] = pw[k] + xo[k]; nrm[k] = dw[k]; }
+              for (int k = 0; k < 3; k++) { cpos[k] = pw[k] + x1[k] + (prism ? cen[k] : 0.f); nrm[k] = dw[k]; }
               hit = true;
             }
+                      } else {   // all other kernels: the code exactly as it was before the height-field variant existed (register allocation of the hand kernel is sensitive to it)
+            const float zero3[3] = {0.f, 0.f, 0.f};
+            nsup = 0;
+            // MPR in geom1's own frame: obj1 needs no rotation / translation at all (identity frame), obj2 carries the
+            // relative pose R1^T R2, R1^T (x2 - x1); normal and position are rotated back afterwards
+            float R1[9];
+            geom_world_mat(M, Y, E, g1, R1);
+            CObj o1, o2;
+            {
+              float R2[9], rel[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
+              geom_world_mat(M, Y, E, g2, R2);
+#pragma unroll
+              for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) o2.mat[3 * i + j] = R1[i] * R2[j] + R1[3 + i] * R2[3 + j] + R1[6 + i] * R2[6 + j];
+              matTvec(o2.pos, R1, rel);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) o1.mat[k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) o1.pos[k] = 0.f;
+            cobj_shape(o1, M.cg_type[g1], sz1); cobj_shape(o2, M.cg_type[g2], sz2);
+            o1.margin = o2.margin = 0.5f * margin;
+            float depth, dir[3], pos[3], nw[3] = {0.f, 0.f, 0.f};
+            bool have_nw = false;
+            for (int i = 0; i < n_mprw; i++) {
+              if (((const int*)(E + Y.mprw))[4 * i] == p) { nw[0] = E[Y.mprw + 4 * i + 1]; nw[1] = E[Y.mprw + 4 * i + 2]; nw[2] = E[Y.mprw + 4 * i + 3]; have_nw = true; }
+            }
+            if (mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr)) {
+              dist = margin - depth;
+              normalize3(dir);
+              mpr_hit = true; mpr_n[0] = dir[0]; mpr_n[1] = dir[1]; mpr_n[2] = dir[2];
+              float dw[3], pw[3];
+              matvec(dw, R1, dir);
+              matvec(pw, R1, pos);
+#pragma unroll
+              for (int k = 0; k < 3; k++) { cpos[k] = pw[k] + x1[k]; nrm[k] = dw[k]; }
+              hit = true;
+            }
+                      }
           }
           if (hit && !(dist < margin - M.pair_f[12 * p + 1])) hit = false;
           if (hit2 && !(dist2 < margin - M.pair_f[12 * p + 1])) hit2 = false;

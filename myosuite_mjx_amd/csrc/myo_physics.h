@@ -339,9 +339,9 @@ __device__ __forceinline__ void expand_portal(Sup* p, const Sup& v4) {
 #ifndef MPR_WARM_EPS
 #define MPR_WARM_EPS 0.05f
 #endif
-template <bool HF = false>
-__device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup = nullptr,
-                                const float* nwarm = nullptr) {
+template <bool HF>
+__device__ bool mpr_penetration_t(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup = nullptr,
+                                  const float* nwarm = nullptr) {
   Sup p[4];
   float dir[3], va[3], vb[3];
 #pragma unroll
@@ -451,6 +451,12 @@ __device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int m
                        bw[2] * (p[2].v1[k] - 0.5f * p[2].v[k]) + bw[3] * (p[3].v1[k] - 0.5f * p[3].v[k]));
   }
   return true;
+}
+// the plain (non height-field) instantiation behind an ordinary function, as before the height-field variant existed: the caller's register
+// allocation around this call is sensitive to how it is inlined (67 vs 93 spilled VGPRs in the MyoHand kernel)
+__device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup = nullptr,
+                                const float* nwarm = nullptr) {
+  return mpr_penetration_t<false>(o1, o2, tol, maxit, depth, dirout, posout, nsup, nwarm);
 }
 
 #endif  // MYO_PHYSICS_H

@@ -12,5 +12,9 @@ python bench.py --batch 32768 --steps 50 --warmup 10 --no-cpu-baseline 2>/dev/nu
 python bench.py --env myoLegWalk-v0 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_g_bench_line_legs.json
 python bench.py --env myoHandPoseFixed-v0 --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_f_bench_line_config2_posefixed_1000steps.json
 python bench.py --env myoHandReachRandom-v0 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_f_bench_line_reach.json
+python bench.py --env myoLegRoughTerrainWalk-v0 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_h_bench_line_terrain.json
+python bench.py --env myoHandObjHoldFixed-v0 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_h_bench_line_objhold.json
+python bench.py --env myoFingerPoseFixed-v0 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_h_bench_line_finger.json
+python tools/parity_report.py > gpurun_out/parity_report.log 2>&1 || true
 grep -h '^{"metric"' gpurun_out/prof_r1f_trace.log > gpurun_out/r1_f_bench_line_under_rocprof.json
 echo evidence refreshed
