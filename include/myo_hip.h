@@ -82,6 +82,8 @@ enum {
 
 /* tasks understood by myo_obs / myo_reset */
 typedef enum myo_task { MYO_TASK_NONE = 0, MYO_TASK_POSE = 1, MYO_TASK_REACH = 2, MYO_TASK_WALK = 3,
+                        MYO_TASK_STAND = 5, /* walk_v0.py:13-183 ReachEnvV0 (myoLegStandRandom-v0): reach with a site of the free root link; obs = qpos, qvel*dt,
+                                               tip (3), target - tip (3), act; reward 10 - d - 10 |qvel dt| + bonus - 100 |act|/na - penalty */
                         MYO_TASK_HOLD = 4 /* ObjHoldFixedEnvV0 (envs/myo/myobase/obj_hold_v0.py:13-118): the model's LAST joint is the free
                                              object; obs = hand qpos, hand qvel*dt, object position, goal - object, act; target = goal (3) */
 } myo_task;
@@ -99,6 +101,11 @@ typedef struct myo_task_config {
   const float* target_lo; /* host pointers, ntarget floats each (copied) */
   const float* target_hi;
   const float* init_qpos; /* host pointer, nq floats (copied); NULL = qpos0 */
+  /* optional reset noise (walk_v0.py:152-167 generate_qpos): qpos = clip(init_qpos + U(noise_lo, noise_hi), clip_lo, clip_hi) per qpos
+   * entry; host pointers, nq floats each (copied), all four or none (NULL) */
+  const float *reset_noise_lo, *reset_noise_hi, *reset_clip_lo, *reset_clip_hi;
+  const float* init_qvel; /* host pointer, nv floats (copied) or NULL = zero */
+  float tip_lpos[3];      /* stand: the tip site's position in the root link's frame */
 } myo_task_config;
 
 /* walk task (WalkEnvV0: envs/myo/myobase/walk_v0.py:187-470, registered as myoLegWalk-v0 in envs/myo/myobase/__init__.py:443-459).

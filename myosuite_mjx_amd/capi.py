@@ -20,6 +20,7 @@ BENCH_OBS, BENCH_FRESH_ACTIONS, BENCH_AUTORESET = 1, 2, 4
 ACTMAP_NONE, ACTMAP_MUSCLE_SIGMOID, ACTMAP_SIGMOID_FATIGUE, ACTMAP_SIGMOID_REAFFERENTATION = 0, 1, 2, 3
 TASK_NONE, TASK_POSE, TASK_REACH = 0, 1, 2
 TASK_HOLD = 4
+TASK_STAND = 5
 FLAG_BAD_STATE, FLAG_BAD_QACC, FLAG_CONTACT_OVERFLOW, FLAG_CAND_OVERFLOW = 1, 2, 4, 8
 
 
@@ -34,7 +35,10 @@ class TaskConfig(C.Structure):
                 ("pose_thd", C.c_float), ("far_th", C.c_float), ("near_th", C.c_float),
                 ("w_pose", C.c_float), ("w_bonus", C.c_float), ("w_act_reg", C.c_float), ("w_penalty", C.c_float),
                 ("w_reach", C.c_float),
-                ("target_lo", C.POINTER(C.c_float)), ("target_hi", C.POINTER(C.c_float)), ("init_qpos", C.POINTER(C.c_float))]
+                ("target_lo", C.POINTER(C.c_float)), ("target_hi", C.POINTER(C.c_float)), ("init_qpos", C.POINTER(C.c_float)),
+                ("reset_noise_lo", C.POINTER(C.c_float)), ("reset_noise_hi", C.POINTER(C.c_float)),
+                ("reset_clip_lo", C.POINTER(C.c_float)), ("reset_clip_hi", C.POINTER(C.c_float)),
+                ("init_qvel", C.POINTER(C.c_float)), ("tip_lpos", C.c_float * 3)]
 
 
 class WalkConfig(C.Structure):
@@ -168,7 +172,8 @@ class HipBatch:
 
     def configure(self, task=TASK_NONE, frame_skip=1, reset_random=0, target_generate=0, target_lo=None, target_hi=None,
                   init_qpos=None, tip_sites=(), pose_thd=0.35, far_th=2 * np.pi, near_th=0.0,
-                  w_pose=1.0, w_bonus=4.0, w_act_reg=1.0, w_penalty=50.0, w_reach=1.0):
+                  w_pose=1.0, w_bonus=4.0, w_act_reg=1.0, w_penalty=50.0, w_reach=1.0, reset_noise=None, reset_clip=None, init_qvel=None,
+                  tip_lpos=(0.0, 0.0, 0.0)):
         c = TaskConfig()
         c.task, c.frame_skip, c.reset_random, c.target_generate = task, frame_skip, int(reset_random), int(target_generate)
         lo = np.ascontiguousarray(target_lo if target_lo is not None else [], np.float32)
@@ -180,7 +185,14 @@ class HipBatch:
         c.pose_thd, c.far_th, c.near_th = pose_thd, far_th, near_th
         c.w_pose, c.w_bonus, c.w_act_reg, c.w_penalty, c.w_reach = w_pose, w_bonus, w_act_reg, w_penalty, w_reach
         iq = np.ascontiguousarray(init_qpos, np.float32) if init_qpos is not None else None
-        self._keep = (lo, hi, iq)
+        fp = lambda a: np.ascontiguousarray(a, np.float32)
+        extra = [fp(reset_noise[0]), fp(reset_noise[1]), fp(reset_clip[0]), fp(reset_clip[1])] if reset_noise is not None else [None] * 4
+        iv = fp(init_qvel) if init_qvel is not None else None
+        self._keep = (lo, hi, iq, extra, iv)
+        ptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_float)) if a is not None else None
+        c.reset_noise_lo, c.reset_noise_hi, c.reset_clip_lo, c.reset_clip_hi = [ptr(a) for a in extra]
+        c.init_qvel = ptr(iv)
+        c.tip_lpos = (C.c_float * 3)(*[float(x) for x in tip_lpos])
         c.target_lo = lo.ctypes.data_as(C.POINTER(C.c_float)) if lo.size else None
         c.target_hi = hi.ctypes.data_as(C.POINTER(C.c_float)) if hi.size else None
         c.init_qpos = iq.ctypes.data_as(C.POINTER(C.c_float)) if iq is not None else None

@@ -89,6 +89,8 @@ struct TaskDev {
   float pose_thd, far_th, near_th, w_pose, w_bonus, w_act_reg, w_penalty, w_reach;
   const float *target_lo, *target_hi, *init_qpos, *jnt_lo, *jnt_hi;
   const float* init_qvel;   // walk task: reset velocity (NULL = zero)
+  const float* rnd;         // [4][nq] reset noise lo | hi and clip lo | hi per qpos entry (NULL: none)
+  float tip_lpos[3];        // stand task: tip site in the root link's frame
   int terrain, hf_n;        // terrain walk: myo_terrain kind and cells of the elevation grid re-drawn at reset (0: none)
   float terrain_lo, terrain_hi;
 };

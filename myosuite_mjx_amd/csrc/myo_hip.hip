@@ -60,7 +60,7 @@ struct myo_batch {
   TaskDev task{};
   int ntarget_alloc = 0, obs_alloc = 0, env_offset = 0;
   std::vector<void*> dev_allocs;
-  float *d_tlo = nullptr, *d_thi = nullptr, *d_init = nullptr, *d_jlo = nullptr, *d_jhi = nullptr, *d_action = nullptr;
+  float *d_tlo = nullptr, *d_thi = nullptr, *d_init = nullptr, *d_jlo = nullptr, *d_jhi = nullptr, *d_action = nullptr, *d_rnd = nullptr;
   float* d_initv = nullptr;
   DevWalk* d_walk = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -340,7 +340,7 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   BA(d.time, B) BA(d.target, (size_t)B * b->ntarget_alloc) BA(d.obs, (size_t)B * b->obs_alloc) BA(d.reward, B) BA(d.done, B)
   BA(d.solved, B) BA(d.qacc, (size_t)B * nv) BA(d.tenlen, (size_t)B * nu) BA(d.actforce, (size_t)B * nu) BA(d.sitexpos, (size_t)B * 24)
   BA(d.flags, B) BA(d.diag, (size_t)B * 8) BA(d.elapsed, B) BA(d.episode, B) BA(d.mprw, (size_t)B * 64)
-  BA(b->d_tlo, b->ntarget_alloc) BA(b->d_thi, b->ntarget_alloc) BA(b->d_init, nq) BA(b->d_jlo, nv) BA(b->d_jhi, nv)
+  BA(b->d_tlo, b->ntarget_alloc) BA(b->d_thi, b->ntarget_alloc) BA(b->d_init, nq) BA(b->d_jlo, nv) BA(b->d_jhi, nv) BA(b->d_rnd, 4 * (size_t)nq)
   BA(b->d_action, (size_t)B * nu)
   BA(d.fatigue, (size_t)B * 3 * nu)
   d.hfield = nullptr;
@@ -393,8 +393,16 @@ int myo_batch_configure(myo_batch* b, const myo_task_config* c) {
   int nv = dm.nv, nu = dm.nu;
   if (c->ntarget > b->ntarget_alloc || c->ntip > 8) return fail(MYO_E_ARG, "myo_batch_configure: ntarget/ntip too large");
   if (c->task == MYO_TASK_WALK) return fail(MYO_E_ARG, "use myo_batch_configure_walk for the walk task");
-  T.init_qvel = nullptr;
+  T.init_qvel = nullptr; T.rnd = nullptr;
   T.terrain = 0; T.hf_n = 0;
+  for (int k = 0; k < 3; k++) T.tip_lpos[k] = c->tip_lpos[k];
+  if (c->reset_noise_lo || c->reset_noise_hi || c->reset_clip_lo || c->reset_clip_hi) {
+    if (!(c->reset_noise_lo && c->reset_noise_hi && c->reset_clip_lo && c->reset_clip_hi)) return fail(MYO_E_ARG, "reset noise: all four arrays or none");
+    const float* src[4] = {c->reset_noise_lo, c->reset_noise_hi, c->reset_clip_lo, c->reset_clip_hi};
+    for (int k = 0; k < 4; k++) HIPCHK(hipMemcpy(b->d_rnd + (size_t)k * b->model->nq, src[k], (size_t)b->model->nq * 4, hipMemcpyHostToDevice));
+    T.rnd = b->d_rnd;
+  }
+  if (c->init_qvel) { HIPCHK(hipMemcpy(b->d_initv, c->init_qvel, (size_t)nv * 4, hipMemcpyHostToDevice)); T.init_qvel = b->d_initv; }
   T.task = c->task; T.frame_skip = c->frame_skip; T.reset_random = c->reset_random; T.target_generate = c->target_generate;
   T.ntarget = c->ntarget; T.ntip = c->ntip;
   for (int i = 0; i < 8; i++) T.tip_site[i] = c->tip_site[i];
@@ -402,6 +410,11 @@ int myo_batch_configure(myo_batch* b, const myo_task_config* c) {
   T.w_pose = c->w_pose; T.w_bonus = c->w_bonus; T.w_act_reg = c->w_act_reg; T.w_penalty = c->w_penalty; T.w_reach = c->w_reach;
   if (c->task == MYO_TASK_POSE) { if (c->ntarget != nv) return fail(MYO_E_ARG, "pose task: ntarget must equal nq"); T.obs_dim = 3 * nv + b->model->dm.na_obs; }
   else if (c->task == MYO_TASK_REACH) { if (c->ntarget != 3 * c->ntip) return fail(MYO_E_ARG, "reach task: ntarget must be 3*ntip"); T.obs_dim = 2 * nv + 6 * c->ntip + b->model->dm.na_obs; }
+  else if (c->task == MYO_TASK_STAND) {
+    if (c->ntarget != 3) return fail(MYO_E_ARG, "stand task: ntarget must be 3 (target position)");
+    if (!(b->model->wave_ok && b->model->dw.has_free && b->model->nq == nv + 1)) return fail(MYO_E_UNSUPPORTED, "stand task needs a model with a free root joint");
+    T.obs_dim = b->model->nq + nv + 6 + b->model->dm.na_obs;
+  }
   else if (c->task == MYO_TASK_HOLD) {
     if (c->ntarget != 3) return fail(MYO_E_ARG, "hold task: ntarget must be 3 (goal position)");
     if (!(b->model->wave_ok && b->model->dw.has_free && b->model->nq == nv + 1 && nv > 6)) return fail(MYO_E_UNSUPPORTED, "hold task needs a model whose last joint is one free object");
@@ -671,7 +684,7 @@ static int launch_obs(myo_batch* b, hipStream_t s, int obs_only = 0, int reset_o
   if (b->task.task == MYO_TASK_WALK) {
     // the walk observation lives in the step kernel: run it with zero substeps as an observation-only pass
     return launch_step(b, nullptr, MYO_ACTMAP_NONE, 0, s, KF_AUX | (obs_only ? KF_OBS_ONLY : 0) | (reset_only ? KF_RESET_ONLY : 0));
-  } else if (b->task.task == MYO_TASK_POSE || b->task.task == MYO_TASK_HOLD) {
+  } else if (b->task.task == MYO_TASK_POSE || b->task.task == MYO_TASK_HOLD || b->task.task == MYO_TASK_STAND) {
     hipLaunchKernelGGL(obs_kernel, dim3(B), dim3(64), 0, s, m->dm, b->db, b->task, obs_only, reset_only);
   } else if (b->task.task == MYO_TASK_REACH) {
     const int EPW = 4;

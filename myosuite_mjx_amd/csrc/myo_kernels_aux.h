@@ -122,6 +122,10 @@ __global__ void __launch_bounds__(64) reset_kernel(DevBatch Bt, TaskDev T, int n
   for (int i = lane; i < nq; i += 64) {
     float q = T.init_qpos ? T.init_qpos[i] : qpos0[i];
     if (T.reset_random) q = T.jnt_lo[i] + (T.jnt_hi[i] - T.jnt_lo[i]) * u01(seed, ge * 4096 + i, 1);   // nq == nv checked at configure
+    else if (T.rnd) {   // init + U(noise), clipped (walk_v0.py:152-167)
+      const float nl = T.rnd[i], nh = T.rnd[nq + i];
+      q = fminf(fmaxf(q + nl + (nh - nl) * u01(seed, ge * 4096 + i, 1), T.rnd[2 * nq + i]), T.rnd[3 * nq + i]);
+    }
     Bt.qpos[(size_t)e * nq + i] = q;
   }
   for (int i = lane; i < nv; i += 64) {
@@ -196,6 +200,35 @@ __global__ void __launch_bounds__(64) obs_kernel(DevModel M, DevBatch Bt, TaskDe
       Bt.reward[e] = T.w_pose * (-dist) + T.w_bonus * bonus + T.w_act_reg * (-actn) + T.w_penalty * pen;
       Bt.solved[e] = dist < T.pose_thd ? 1.f : 0.f;
       Bt.done[e] = dist > T.far_th ? 1.f : 0.f;
+    }
+  } else if (T.task == MYO_TASK_STAND) {
+    // walk_v0.py:68-127 (ReachEnvV0 on the legs).  The tip site rides on the free root link: world position = root position + R(root quat) tip_lpos
+    const int nq = T.nq;
+    const float* qq = Bt.qpos + (size_t)e * nq;
+    float vel2 = 0.f, act2 = 0.f, err2 = 0.f;
+    for (int i = lane; i < nq; i += 64) o[i] = qq[i];
+    for (int i = lane; i < nv; i += 64) { const float vd = v[i] * dt; o[nq + i] = vd; vel2 += vd * vd; }
+    if (lane < 3) {
+      float R[9];
+      const float qn = 1.0f / sqrtf(qq[3] * qq[3] + qq[4] * qq[4] + qq[5] * qq[5] + qq[6] * qq[6]);
+      const float uq[4] = {qq[3] * qn, qq[4] * qn, qq[5] * qn, qq[6] * qn};
+      quat2mat(R, uq);
+      const float p = qq[lane] + R[3 * lane] * T.tip_lpos[0] + R[3 * lane + 1] * T.tip_lpos[1] + R[3 * lane + 2] * T.tip_lpos[2] + M.origin[lane];
+      const float er = Bt.target[(size_t)e * T.ntarget + lane] - p;
+      o[nq + nv + lane] = p; o[nq + nv + 3 + lane] = er;
+      err2 = er * er;
+    }
+    for (int i = lane; i < nu; i += 64) { float ai = a[i]; const int sl = M.act_obs[i]; if (sl >= 0) { o[nq + nv + 6 + sl] = ai; act2 += ai * ai; } }
+    if (obs_only) return;
+    const float dist = sqrtf(wave_sum(err2)), veld = sqrtf(wave_sum(vel2));
+    const float actn = sqrtf(wave_sum(act2)) / (float)(M.na_obs > 0 ? M.na_obs : 1);
+    if (lane == 0) {
+      const float far_th = Bt.time[e] > 2.f * dt ? T.far_th : 1e30f;
+      const float bonus = (dist < 2.f * T.near_th ? 1.f : 0.f) + (dist < T.near_th ? 1.f : 0.f);
+      const float pen = dist > far_th ? 1.f : 0.f;
+      Bt.reward[e] = T.w_reach * (10.0f - dist - 10.0f * veld) + T.w_bonus * bonus + T.w_act_reg * (-100.0f * actn) + T.w_penalty * (-pen);
+      Bt.solved[e] = dist < T.near_th ? 1.f : 0.f;
+      Bt.done[e] = pen;
     }
   } else if (T.task == MYO_TASK_HOLD) {
     // obj_hold_v0.py:66-118.  The object's site sits at the origin of its free body, whose world position is the free joint's qpos

@@ -115,6 +115,12 @@ REGISTRY["myoLegWalk-v0"] = dict(
     model="myolegs", task="walk", max_episode_steps=1000, frame_skip=10, normalize_act=True, reset_type="init",
     min_height=0.8, max_rot=0.8, hip_period=100, target_x_vel=0.0, target_y_vel=1.2, target_rot=None,
     weights=dict(vel_reward=5.0, done=-100.0, cyclic_hip=-10.0, ref_rot=10.0, joint_angle_rew=5.0))
+# myoLegStandRandom-v0 (envs/myo/myobase/__init__.py:424-441; walk_v0.py:13-183 ReachEnvV0): keep the pelvis site at a target drawn around its
+# position in the (randomised) start pose; joint_random_range (-0.2, 0.2) on every joint's first coordinate, clipped to the joint range
+REGISTRY["myoLegStandRandom-v0"] = dict(
+    model="myolegs", task="stand", max_episode_steps=150, frame_skip=10, normalize_act=True, reset_type="random", tip="pelvis",
+    joint_random_range=(-0.2, 0.2), target_span=((-0.05, -0.05, 0.0), (0.05, 0.05, 0.0)), far_th=0.44, near_th=0.050,
+    weights=dict(reach=1.0, bonus=4.0, penalty=50.0, act_reg=1.0))
 # myoLeg{Rough,Hilly,Stair}TerrainWalk-v0 (envs/myo/myobase/__init__.py:462-520; TerrainEnvV0, walk_v0.py:490-671): the walk task on a height
 # field re-drawn per episode; hilly / stairs are registered with variant "fixed" (height scale 0.63 / 2.5; otherwise U(0.53, 0.73) / U(1.5, 3.5))
 for _id, _kind, _sc in (("myoLegRoughTerrainWalk-v0", "rough", (0.0, 0.0)), ("myoLegHillyTerrainWalk-v0", "hilly", (0.63, 0.63)),
@@ -216,6 +222,29 @@ class BatchedMyoEnv:
                 terrain={"rough": capi.TERRAIN_ROUGH, "hilly": capi.TERRAIN_HILLY, "stairs": capi.TERRAIN_STAIRS}.get(spec.get("terrain"), capi.TERRAIN_NONE),
                 terrain_scalar=spec.get("terrain_scalar", (0.0, 0.0)))
             self.obs_dim = (m.nq - 2) + m.nv + 16 + 4 * m.nu
+        elif spec["task"] == "stand":
+            from .mjcf import quat2mat
+            key_qpos = np.asarray(m.key_qpos).reshape(-1, m.nq)
+            key_qvel = np.asarray(m.key_qvel).reshape(-1, m.nv)
+            init = key_qpos[0].astype(float)                              # walk_v0.py:63-64
+            adr = np.asarray(m.jnt_qposadr)
+            nlo, nhi = np.zeros(m.nq), np.zeros(m.nq)
+            clo, chi = np.full(m.nq, -1e30), np.full(m.nq, 1e30)
+            nlo[adr], nhi[adr] = spec["joint_random_range"]               # generate_qpos (:152-167): only each joint's first coordinate moves ...
+            clo[adr], chi[adr] = m.jnt_range[:, 0], m.jnt_range[:, 1]      # ... and is clipped to jnt_range -- (0, 0) for the unlimited free root: x = 0
+            tsid = m.name2id("site", spec["tip"])
+            if int(m.hip_site_link[tsid]) != 0:
+                raise NotImplementedError("stand task: the tip site must ride on the free root link")
+            lpos = np.asarray(m.hip_site_lpos[tsid], float)
+            q0 = np.clip(init[:7] + 0.0, np.r_[clo[:1], [-1e30] * 6], np.r_[chi[:1], [1e30] * 6])
+            p0 = q0[:3] + quat2mat(q0[3:7] / np.linalg.norm(q0[3:7])) @ lpos     # generate_targets (:140-149): the site in the first random pose
+            span = np.asarray(spec["target_span"], float)
+            self.batch.configure(task=capi.TASK_STAND, frame_skip=self.frame_skip, reset_random=0, target_generate=1,
+                                 target_lo=p0 + span[0], target_hi=p0 + span[1], init_qpos=init, init_qvel=key_qvel[0],
+                                 reset_noise=(nlo, nhi), reset_clip=(clo, chi), tip_lpos=lpos,
+                                 near_th=spec["near_th"], far_th=spec["far_th"],
+                                 w_reach=w["reach"], w_bonus=w["bonus"], w_act_reg=w["act_reg"], w_penalty=w["penalty"])
+            self.obs_dim = m.nq + m.nv + 6 + m.n_muscle
         elif spec["task"] == "hold":
             init = np.array(m.qpos0, float)
             init[:-7] = 0.0                                            # obj_hold_v0.py:63-64: fully open hand, palm up

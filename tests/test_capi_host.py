@@ -83,6 +83,9 @@ def test_registry_matches_reference_specs():
     fr = REGISTRY["myoFingerReachRandom-v0"]                     # envs/myo/myobase/__init__.py:94-105; far_th default reach_v0.py:47
     assert fr["tips"] == ("IFtip",) and fr["far_th"] == 0.35 and fr["target_lo"].tolist() == [0.1, -0.1, 0.1] and fr["target_hi"].tolist() == [0.27, 0.1, 0.3]
     assert "myoSarcElbowPose1D6MFixed-v0" in REGISTRY and "myoFatiFingerReachRandom-v0" in REGISTRY
+    ls = REGISTRY["myoLegStandRandom-v0"]                        # envs/myo/myobase/__init__.py:424-441, walk_v0.py:15-21,105
+    assert ls["max_episode_steps"] == 150 and ls["joint_random_range"] == (-0.2, 0.2) and ls["far_th"] == 0.44 and ls["near_th"] == 0.05
+    assert ls["weights"] == dict(reach=1.0, bonus=4.0, penalty=50.0, act_reg=1.0) and ls["target_span"] == ((-0.05, -0.05, 0.0), (0.05, 0.05, 0.0))
     oh = REGISTRY["myoHandObjHoldFixed-v0"]                      # envs/myo/myobase/__init__.py:596-604, obj_hold_v0.py:16-20,96-97
     assert oh["max_episode_steps"] == 75 and oh["weights"] == dict(goal_dist=100.0, bonus=4.0, penalty=10.0, act_reg=0.0) and (oh["goal_th"], oh["drop_th"]) == (0.010, 0.300)
     assert "myoHandObjHoldRandom-v0" in UNSUPPORTED and "myoElbowPose1D6MExoRandom-v0" in UNSUPPORTED

@@ -107,3 +107,41 @@ def test_walk_torch_views_and_bench_rollout(legs):
                                  torch.cuda.current_stream().cuda_stream)
     assert ms > 0
     assert torch.isfinite(env.view(capi.F_OBS)).all()
+
+
+def test_leg_stand_env(legs):
+    """myoLegStandRandom-v0 (walk_v0.py:13-183 ReachEnvV0 on the legs): reset = keyframe 0 + U(-0.2, 0.2) on each joint's first coordinate,
+    clipped to the joint range (root x clipped to its (0, 0) "range"); target = pelvis site of that family of poses + U(+-0.05, +-0.05, 0);
+    obs 155 = qpos 35, qvel*dt 34, tip 3, err 3, act 80; reward 10 - d - 10 |qvel dt| + 4 bonus - 100 |act|/80 - 50 (d > 0.44, after 2 dt)."""
+    import torch
+    import myosuite_mjx_amd as myo
+    m = legs
+    B = 64
+    env = myo.make("myoLegStandRandom-v0", num_envs=B, seed=5, autoreset=False)
+    obs = env.reset(seed=5)
+    assert obs.shape == (B, 155) and env.max_episode_steps == 150 and abs(env.dt - 0.01) < 1e-9
+    st = env.get_env_state()
+    k0 = np.asarray(m.key_qpos).reshape(-1, m.nq)[0]
+    adr = np.asarray(m.jnt_qposadr)
+    dq = st["qpos"] - k0[None, :]
+    other = np.setdiff1d(np.arange(m.nq), adr)
+    assert np.allclose(dq[:, other], 0, atol=1e-6) and np.allclose(st["qpos"][:, 0], 0, atol=1e-7)      # only first coordinates move; root x -> 0
+    lo, hi = m.jnt_range[1:, 0], m.jnt_range[1:, 1]
+    q1 = st["qpos"][:, adr[1:]]
+    assert (q1 >= lo - 1e-6).all() and (q1 <= hi + 1e-6).all() and (np.abs(dq[:, adr[1:]]) <= 0.2 + 1e-6).all() and dq[:, adr[1:]].std() > 0.05
+    tg = st["target"]
+    assert np.allclose(tg[:, 2], 0.92, atol=1e-6) and (np.abs(tg[:, :2]) <= 0.05 + 1e-6).all() and tg[:, :2].std() > 0.02
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for k in range(6):
+        obs, rwd, term, trunc, info = env.step(torch.rand((B, 80), device="cuda", generator=g) * 2 - 1)
+    st = env.get_env_state()
+    o = obs.cpu().numpy()
+    assert np.allclose(o[:, :35], st["qpos"], atol=1e-7) and np.allclose(o[:, 35:69], st["qvel"] * 0.01, atol=1e-6)
+    assert np.allclose(o[:, 69:72], st["qpos"][:, :3], atol=1e-6) and np.allclose(o[:, 72:75], st["target"] - st["qpos"][:, :3], atol=1e-6)
+    assert np.allclose(o[:, 75:], st["act"], atol=1e-7)
+    d = np.linalg.norm(o[:, 72:75], axis=1)
+    ref = (10.0 - d - 10.0 * np.linalg.norm(o[:, 35:69], axis=1)) + 4.0 * ((d < 0.1) * 1.0 + (d < 0.05) * 1.0) \
+        - 100.0 * np.linalg.norm(st["act"], axis=1) / 80 - 50.0 * (d > 0.44)
+    edge = (np.abs(d - 0.05) < 1e-5) | (np.abs(d - 0.1) < 1e-5) | (np.abs(d - 0.44) < 1e-5)
+    assert np.allclose(rwd.cpu().numpy()[~edge], ref[~edge], atol=2e-4) and np.array_equal(term.cpu().numpy()[~edge], (d > 0.44)[~edge])
+    assert (env.status() == 0).all()
