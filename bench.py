@@ -101,8 +101,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        # rehearsal on a one-GPU box (tests only): MYO_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo, so that the N > 1 control
+        # flow can be exercised without N GPUs; the numbers of such a run mean nothing and are marked in the output
+        if os.environ.get("MYO_BENCH_REHEARSAL") == "1":
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP stepper has no CPU fallback")
     torch.cuda.set_device(local)
@@ -173,7 +180,7 @@ def main():
                        "global_batch": world * B, "parallelism": f"env-shard x{world}", "lanes_per_env": 64,
                        "substeps_per_s": value * env.frame_skip},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "step_kernel_w<24,8,32,1,4,false,1>" if mm.nv <= 24 else "step_kernel_w<36,20,32,2,2,true,2>", "kernel_ms": k_ms,
+                         "traffic": traffic, "kernel": env.batch.last_kernel_name(), "kernel_ms": k_ms,
                          "alg_bytes_per_launch": b_alg * B,
                          "note": "path is FP32-VALU/latency bound, not HBM bound (SURVEY.md 8d); fp32 view alongside",
                          "fp32": {"achieved_tflops_est": F_ALG_EST * B / (k_ms * 1e-3) / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
@@ -185,6 +192,7 @@ def main():
                              "frac": valu_insts / (k_ms * 1e-3) / (N_SIMD * CLOCK_HZ / 4.0),
                              "note": "share of the chip's VALU issue slots used over the whole launch (256 CUs x 4 SIMDs, 2.4 GHz)"}},
             "event_ms_per_step_rank0": ev_ms / args.steps,
+            **({"rehearsal": "all ranks on one GPU over gloo: control-flow check only"} if os.environ.get("MYO_BENCH_REHEARSAL") == "1" else {}),
             "flagged_envs": int((flags != 0).sum()),
         }
         if not args.no_cpu_baseline and world == 1 and env_id == ENV_ID:

@@ -190,6 +190,8 @@ int myo_bench_rollout(myo_batch*, int steps, int nsubsteps, uint64_t seed, int m
  * myo_bench_last_kernel_ms: HIP-event milliseconds spent inside the step-kernel launches of the last synchronous call, or of all
  * asynchronous calls since the previous collection (waits for them); events are recorded on the launches' own stream */
 int myo_bench_last_kernel_ms(myo_batch*, float* ms_out);
+/* name of the step-kernel template instantiation the last launch used, spelled as rocprofv3 prints it */
+const char* myo_bench_last_kernel_name(const myo_batch*);
 
 /* ---- policy inference: the network family of the reference's `mjx_brax_policy` artefact (a brax PPO
  * policy: running-statistics observation normalisation, MLP with swish hidden layers, tanh-normal head; brax is third-party and

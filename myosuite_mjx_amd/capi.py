@@ -110,6 +110,8 @@ def lib():
         L.myo_sync.argtypes = [C.c_void_p]
         L.myo_bench_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
         L.myo_bench_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.myo_bench_last_kernel_name.argtypes = [C.c_void_p]
+        L.myo_bench_last_kernel_name.restype = C.c_char_p
         L.myo_obs_only.argtypes = [C.c_void_p, C.c_void_p]
         L.myo_autoreset.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
         L.myo_set_env_offset.argtypes = [C.c_void_p, C.c_int]
@@ -256,6 +258,9 @@ class HipBatch:
 
     def random_action(self, action_ptr, seed, step, env_offset=0, stream=None):
         _chk(lib().myo_random_action(self.h, action_ptr, seed, step, env_offset, stream))
+
+    def last_kernel_name(self) -> str:
+        return lib().myo_bench_last_kernel_name(self.h).decode()
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float()

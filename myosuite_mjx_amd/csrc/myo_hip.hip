@@ -62,6 +62,7 @@ struct myo_batch {
   std::vector<void*> dev_allocs;
   float *d_tlo = nullptr, *d_thi = nullptr, *d_init = nullptr, *d_jlo = nullptr, *d_jhi = nullptr, *d_action = nullptr, *d_rnd = nullptr;
   float* d_initv = nullptr;
+  const char* last_kernel = "step_kernel";   // name of the step-kernel instantiation of the last myo_step / bench launch
   DevWalk* d_walk = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint64_t bench_step = 0;
@@ -632,6 +633,10 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
       order = b->d_order;
     }
     SchedDev S{b->d_sched, b->d_sched + 32, b->sched_stride, nsub + (wk ? 1 : 0)};
+    if (!kflags)   // instantiation chosen below, as rocprofv3 prints it (bench.py reports it next to the kernel time)
+      b->last_kernel = sched ? (m->wave_cfg == 0 ? "step_kernel_w<24,8,32,1,4,true,0,false>" : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,true,2,false>" : "step_kernel_w<36,20,32,2,2,true,0,false>"))
+                             : (m->wave_cfg == 0 ? (m->hand_sizes ? "step_kernel_w<24,8,32,1,4,false,1,false>" : "step_kernel_w<24,8,32,1,4,false,0,false>")
+                                                 : (m->dw.hf.on ? "step_kernel_w<36,20,32,2,2,false,0,true>" : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,false,2,false>" : "step_kernel_w<36,20,32,2,2,false,0,false>")));
     if (sched) {
       hipLaunchKernelGGL(sched_init_kernel, dim3(1), dim3(1024), 0, s, (const int*)b->db.diag, Bn, S);
       int grid = Bn < resident ? Bn : resident;    // persistent waves: no more workgroups than the chip holds at once
@@ -801,6 +806,8 @@ int myo_bench_rollout(myo_batch* b, int steps, int nsubsteps, uint64_t seed, int
 
 /* total HIP-event milliseconds spent in the step kernel launches of the last synchronous myo_bench_rollout call, or -- after
  * asynchronous calls (ms_out == NULL) -- of all launches enqueued since the last collection (waits for them) */
+const char* myo_bench_last_kernel_name(const myo_batch* b) { return b ? b->last_kernel : ""; }
+
 int myo_bench_last_kernel_ms(myo_batch* b, float* ms_out) {
   if (!b || !ms_out) return fail(MYO_E_ARG, "null");
   if (b->kev_pending > 0) {

@@ -253,3 +253,25 @@ def test_bench_multi_gpu_loop_with_a_stand_in_collective():
     torch.cuda.synchronize()
     assert ms > 0 and 0 < kms <= ms * 1.05
     assert torch.equal(obs, ref.view(capi.F_OBS)) and torch.equal(gathered[512:], obs)
+
+
+def test_bench_two_rank_rehearsal():
+    """bench.py's N > 1 path end to end (launcher env, env_offset sharding, staging + async all-gather per step, barrier / max-over-ranks
+    timing, rank-0 JSON line) with two processes on this one GPU over gloo (MYO_BENCH_REHEARSAL=1): a control-flow check, the real
+    multi-GPU run uses RCCL on N devices."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MYO_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--batch", "512"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1                                            # rank 0 prints exactly one line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 1024 and d["steps"] == 10 and d["warmup"] == 3 and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["value"] - 1024 * 10 / (d["ms_per_step"] * 10 / 1e3)) < 1e-6 * d["value"]
+    assert d["roofline"]["kernel"].startswith("step_kernel_w<24,8,32,1,4,false") and "cpu_baseline" not in d and "rehearsal" in d
