@@ -610,6 +610,7 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       attr_w = true;
     }
     const int* order = nullptr;
@@ -625,7 +626,7 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     }
     const int resident = n_cu * (m->wave_cfg == 1 ? 8 : 16);
     const bool sched_ok = !kflags && Bn >= 64 && Bn <= SCHED_ENV_MASK && nsub + (wk ? 1 : 0) <= 15 && nsub > 0;
-    const bool sched = sched_ok && !m->dw.hf.on && (sched_mode == 1 || (sched_mode == -1 && m->wave_cfg == 1 && Bn >= 2 * resident));
+    const bool sched = sched_ok && (sched_mode == 1 || (sched_mode == -1 && m->wave_cfg == 1 && Bn >= 2 * resident));
     if (b->balance && Bn >= 1024 && Bn % 4 == 0 && !kflags && !sched) {
       static int prio_mode = -1;
       if (prio_mode < 0) { const char* e = getenv("MYO_PRIO"); prio_mode = e ? atoi(e) : 2; }
@@ -634,7 +635,7 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     }
     SchedDev S{b->d_sched, b->d_sched + 32, b->sched_stride, nsub + (wk ? 1 : 0)};
     if (!kflags)   // instantiation chosen below, as rocprofv3 prints it (bench.py reports it next to the kernel time)
-      b->last_kernel = sched ? (m->wave_cfg == 0 ? "step_kernel_w<24,8,32,1,4,true,0,false>" : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,true,2,false>" : "step_kernel_w<36,20,32,2,2,true,0,false>"))
+      b->last_kernel = sched ? (m->wave_cfg == 0 ? "step_kernel_w<24,8,32,1,4,true,0,false>" : m->dw.hf.on ? "step_kernel_w<36,20,32,2,2,true,0,true>" : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,true,2,false>" : "step_kernel_w<36,20,32,2,2,true,0,false>"))
                              : (m->wave_cfg == 0 ? (m->hand_sizes ? "step_kernel_w<24,8,32,1,4,false,1,false>" : "step_kernel_w<24,8,32,1,4,false,0,false>")
                                                  : (m->dw.hf.on ? "step_kernel_w<36,20,32,2,2,false,0,true>" : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,false,2,false>" : "step_kernel_w<36,20,32,2,2,false,0,false>")));
     if (sched) {
@@ -646,6 +647,9 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
       if (m->wave_cfg == 0)
         hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, true, 0>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                            (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, (const int*)nullptr, (const DevWalk*)nullptr, 0, S);
+      else if (m->dw.hf.on)
+        hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, true, 0, true>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+                           (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, (const int*)nullptr, wk, 0, S);
       else if (m->leg_sizes)
         hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, true, 2>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                            (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, (const int*)nullptr, wk, 0, S);

@@ -155,3 +155,29 @@ def test_config5_walk_4096_envs_keep_constraints(legs):
     assert worst < 3e-2, worst                                                       # soft equality rows (same bound the oracle test uses +50 %)
     assert st["qpos"][:, 2].min() > 0.2 and st["qpos"][:, 2].max() < 1.3             # nobody fell through the floor or took off
     assert int((env.status() & 16).sum()) == 0                                       # MYO_FLAG_SCHED_TIMEOUT never raised
+
+
+def test_terrain_4096_envs_equal_their_shards():
+    """myoLegRoughTerrainWalk-v0 at B = 4096 (substep scheduler + height-field instantiation) against 32-env shards (one wave per env): the
+    per-env terrain draw is keyed by the global env id, and scheduled / unscheduled launches compute bit-identical steps."""
+    import torch
+    from myosuite_mjx_amd import capi
+    B, K = 4096, 25
+    env = _make("myoLegRoughTerrainWalk-v0", B, seed=9)
+    env.reset(seed=9)
+    offs = [0, 1777, B - 32]
+    shards = [_make("myoLegRoughTerrainWalk-v0", 32, seed=9, env_offset=o) for o in offs]
+    for s in shards:
+        s.reset(seed=9)
+    H = env.batch.read(capi.F_HFIELD)
+    for o, s in zip(offs, shards):
+        assert np.array_equal(s.batch.read(capi.F_HFIELD), H[o:o + 32])
+    assert env.batch.last_kernel_name() == "step_kernel"                       # nothing launched yet (reset only)
+    for k in range(K):
+        a = _actions(B, 80, 9, k)
+        obs, rwd, term, trunc, info = env.step(a)
+        for o, s in zip(offs, shards):
+            so, sr, st_, _, _ = s.step(a[o:o + 32])
+            assert torch.equal(so, obs[o:o + 32]) and torch.equal(sr, rwd[o:o + 32]) and torch.equal(st_, term[o:o + 32]), (k, o)
+    assert env.batch.last_kernel_name() == "step_kernel_w<36,20,32,2,2,true,0,true>" and shards[0].batch.last_kernel_name() == "step_kernel_w<36,20,32,2,2,false,0,true>"
+    assert int((env.status() & 16).sum()) == 0
