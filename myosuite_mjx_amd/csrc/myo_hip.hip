@@ -40,7 +40,7 @@ struct myo_model {
   DevModelW* d_dw = nullptr;
   int env_lds_bytes_w = 0;
   bool wave_ok = false, generic_ok = false;
-  bool hand_sizes = false, leg_sizes = false;   // table sizes equal Sizes<1> / Sizes<2>: the size-specialised instantiations may be used
+  bool hand_sizes = false, leg_sizes = false, terrain_sizes = false;   // table sizes equal Sizes<1> / Sizes<2>: the size-specialised instantiations may be used
   int wave_cfg = 0;             // 0: step_kernel_w<24,8,32,1,4> (hand / finger), 1: step_kernel_w<36,20,48,2,2> (legs)
   int nq = 0;
   int has_tl = 0;
@@ -280,7 +280,8 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
     else { m->wave_ok = false; build_layout_w(d, w, 24, 8, 32); }
     m->hand_sizes = m->wave_ok && m->wave_cfg == 0 && sizes_match<1>(w.nq, d.nv, d.nu, d.nl, d.nlevel, d.maxnnz, d.ngt, d.nseg, d.ncg, d.npair);
     m->leg_sizes = m->wave_ok && m->wave_cfg == 1 && sizes_match<2>(w.nq, d.nv, d.nu, d.nl, d.nlevel, d.maxnnz, d.ngt, d.nseg, d.ncg, d.npair);
-    if (const char* e = getenv("MYO_NO_SPEC")) if (atoi(e) == 1) m->hand_sizes = m->leg_sizes = false;   // tests: force the run-time-sized instantiations
+    m->terrain_sizes = m->wave_ok && m->wave_cfg == 1 && w.hf.on && sizes_match<3>(w.nq, d.nv, d.nu, d.nl, d.nlevel, d.maxnnz, d.ngt, d.nseg, d.ncg, d.npair);
+    if (const char* e = getenv("MYO_NO_SPEC")) if (atoi(e) == 1) m->hand_sizes = m->leg_sizes = m->terrain_sizes = false;   // tests: force the run-time-sized instantiations
     if (!m->wave_ok && !m->generic_ok) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "model exceeds the limits of both step kernels (nv <= 36, nu <= 128, pair dofs <= 20)"); }
     m->env_lds_bytes_w = w.lay.total * 4;
     if (m->wave_ok && m->env_lds_bytes_w > 64 * 1024) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "wave kernel working set exceeds 64 KB of LDS"); }
@@ -610,7 +611,8 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       attr_w = true;
     }
     const int* order = nullptr;
@@ -626,7 +628,7 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     }
     const int resident = n_cu * (m->wave_cfg == 1 ? 8 : 16);
     const bool sched_ok = !kflags && Bn >= 64 && Bn <= SCHED_ENV_MASK && nsub + (wk ? 1 : 0) <= 15 && nsub > 0;
-    const bool sched = sched_ok && (sched_mode == 1 || (sched_mode == -1 && m->wave_cfg == 1 && Bn >= 2 * resident));
+    const bool sched = sched_ok && !(m->dw.hf.on && !m->terrain_sizes) && (sched_mode == 1 || (sched_mode == -1 && m->wave_cfg == 1 && Bn >= 2 * resident));
     if (b->balance && Bn >= 1024 && Bn % 4 == 0 && !kflags && !sched) {
       static int prio_mode = -1;
       if (prio_mode < 0) { const char* e = getenv("MYO_PRIO"); prio_mode = e ? atoi(e) : 2; }
@@ -635,9 +637,9 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     }
     SchedDev S{b->d_sched, b->d_sched + 32, b->sched_stride, nsub + (wk ? 1 : 0)};
     if (!kflags)   // instantiation chosen below, as rocprofv3 prints it (bench.py reports it next to the kernel time)
-      b->last_kernel = sched ? (m->wave_cfg == 0 ? "step_kernel_w<24,8,32,1,4,true,0,false>" : m->dw.hf.on ? "step_kernel_w<36,20,32,2,2,true,0,true>" : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,true,2,false>" : "step_kernel_w<36,20,32,2,2,true,0,false>"))
+      b->last_kernel = sched ? (m->wave_cfg == 0 ? "step_kernel_w<24,8,32,1,4,true,0,false>" : m->dw.hf.on ? "step_kernel_w<36,20,32,2,2,true,3,true>" : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,true,2,false>" : "step_kernel_w<36,20,32,2,2,true,0,false>"))
                              : (m->wave_cfg == 0 ? (m->hand_sizes ? "step_kernel_w<24,8,32,1,4,false,1,false>" : "step_kernel_w<24,8,32,1,4,false,0,false>")
-                                                 : (m->dw.hf.on ? "step_kernel_w<36,20,32,2,2,false,0,true>" : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,false,2,false>" : "step_kernel_w<36,20,32,2,2,false,0,false>")));
+                                                 : (m->dw.hf.on ? (m->terrain_sizes ? "step_kernel_w<36,20,32,2,2,false,3,true>" : "step_kernel_w<36,20,32,2,2,false,0,true>") : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,false,2,false>" : "step_kernel_w<36,20,32,2,2,false,0,false>")));
     if (sched) {
       hipLaunchKernelGGL(sched_init_kernel, dim3(1), dim3(1024), 0, s, (const int*)b->db.diag, Bn, S);
       int grid = Bn < resident ? Bn : resident;    // persistent waves: no more workgroups than the chip holds at once
@@ -648,7 +650,7 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
         hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, true, 0>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                            (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, (const int*)nullptr, (const DevWalk*)nullptr, 0, S);
       else if (m->dw.hf.on)
-        hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, true, 0, true>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+        hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, true, 3, true>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                            (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, (const int*)nullptr, wk, 0, S);
       else if (m->leg_sizes)
         hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, true, 2>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
@@ -662,7 +664,10 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     else if (m->wave_cfg == 0)
       hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, false, 0>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                          (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0, S);
-    else if (m->dw.hf.on)     // terrain models: the instantiation with the height-field narrow phase
+    else if (m->dw.hf.on && m->terrain_sizes)     // terrain models: the instantiations with the height-field narrow phase
+      hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, false, 3, true>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, wk, kflags, S);
+    else if (m->dw.hf.on)
       hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, false, 0, true>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                          (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, wk, kflags, S);
     else if (m->leg_sizes)
