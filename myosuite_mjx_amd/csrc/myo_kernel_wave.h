@@ -1037,9 +1037,10 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
               dist = margin - depth;
               normalize3(dir);
               mpr_hit = true; mpr_n[0] = dir[0]; mpr_n[1] = dir[1]; mpr_n[2] = dir[2];
-              float dw[3], pw[3];
-              matvec(dw, R1, dir);
-              matvec(pw, R1, pos);
+              float dw[3], pw[3], R1b[9];
+              geom_world_mat(M, Y, E, g1, R1b);   // recomputed (9 LDS reads + a 3x3 product) instead of kept live across the portal refinement
+              matvec(dw, R1b, dir);
+              matvec(pw, R1b, pos);
 #pragma unroll
               for (int k = 0; k < 3; k++) { cpos[k] = pw[k] + x1[k]; nrm[k] = dw[k]; }
               hit = true;
