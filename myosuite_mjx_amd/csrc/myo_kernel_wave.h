@@ -1033,7 +1033,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             for (int i = 0; i < n_mprw; i++) {
               if (((const int*)(E + Y.mprw))[4 * i] == p) { nw[0] = E[Y.mprw + 4 * i + 1]; nw[1] = E[Y.mprw + 4 * i + 2]; nw[2] = E[Y.mprw + 4 * i + 3]; have_nw = true; }
             }
-            if (mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr)) {
+            // portal witnesses in per-lane LDS scratch: the contact-jacobian area of region X, not written before the rows stage
+            if (mpr_penetration_wl(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr, E + Y.cJ + 9 * lane)) {
               dist = margin - depth;
               normalize3(dir);
               mpr_hit = true; mpr_n[0] = dir[0]; mpr_n[1] = dir[1]; mpr_n[2] = dir[2];
