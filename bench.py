@@ -146,6 +146,19 @@ def main():
         t = torch.tensor([el], device=obs.device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    # N > 1: the observation all-gather on its own ("gather time separately"), outside the timed region: in the
+    # rollout it overlaps the next step kernel, here 20 back-to-back gathers are timed with nothing else running
+    gather_ms = None
+    if dist:
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.all_gather_into_tensor(gathered, staging)
+        torch.cuda.synchronize()
+        g0.record()
+        for _ in range(20):
+            dist.all_gather_into_tensor(gathered, staging)
+        g1.record()
+        torch.cuda.synchronize()
+        gather_ms = g0.elapsed_time(g1) / 20
     # dominant kernel: average launch duration from HIP event pairs recorded around every step-kernel launch of the
     # timed region, on the stream it is launched on
     k_ms = kernel_ms_total / args.steps
@@ -192,6 +205,7 @@ def main():
                              "frac": valu_insts / (k_ms * 1e-3) / (N_SIMD * CLOCK_HZ / 4.0),
                              "note": "share of the chip's VALU issue slots used over the whole launch (256 CUs x 4 SIMDs, 2.4 GHz)"}},
             "event_ms_per_step_rank0": ev_ms / args.steps,
+            **({"allgather_ms_rank0": gather_ms, "allgather_bytes_out": int(gathered.numel() * 4)} if gather_ms is not None else {}),
             **({"rehearsal": "all ranks on one GPU over gloo: control-flow check only"} if os.environ.get("MYO_BENCH_REHEARSAL") == "1" else {}),
             "flagged_envs": int((flags != 0).sum()),
         }
