@@ -66,6 +66,7 @@ typedef enum myo_field {
   MYO_F_FATIGUE,     /* [B][3*nu] fatigue compartments MA | MR | MF (muscle condition "fatigue") */
   MYO_F_HFIELD,      /* [B][nrow*ncol] height-field elevation per env (terrain models: mjModel.hfield_data, rewritten per episode by
                         TerrainEnvV0.reset, walk_v0.py:563-622); absent (MYO_E_ARG) for models without a colliding height field */
+  MYO_F_GEOMSIZE,    /* [B][4] per-env size (3) + bounding radius of the geom named in myo_batch_set_geom_override (absent otherwise) */
   MYO_F_COUNT
 } myo_field;
 
@@ -146,6 +147,10 @@ int myo_batch_configure_walk(myo_batch*, const myo_walk_config* cfg);
 /* muscle conditions (envs/myo/base_v0.py:61-80): time step of the fatigue model (frame_skip * timestep) and the actuator ids of
  * the EIP -> EPL tendon transfer (-1: none).  Sarcopenia is a model edit (peak force of gainprm halved) made before myo_model_load. */
 int myo_batch_set_condition(myo_batch*, int frame_skip, int epl_actuator, int eip_actuator);
+/* per-env size of ONE collision geom (compiled-model geom id), as ObjHoldRandomEnvV0.reset edits model.geom_size per episode
+ * (envs/myo/myobase/obj_hold_v0.py:122-140): every reset of an env draws size ~ U(lo, hi) per axis; mass and inertia are untouched, as in
+ * the reference (the model is not recompiled).  lo == hi == NULL switches the override off.  Generic large-kernel models only. */
+int myo_batch_set_geom_override(myo_batch*, int geom_id, const float* size_lo, const float* size_hi);
 /* device pointer + pitch (elements per env row) of a field */
 int myo_batch_field(myo_batch*, int field, void** dev_ptr, size_t* pitch, size_t* width);
 /* synchronous host copies (tests / plumbing without torch); host buffers are [B][width] */

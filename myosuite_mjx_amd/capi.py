@@ -14,7 +14,7 @@ SRC_PATH = os.path.join(_HERE, "csrc", "myo_hip.hip")
 
 # field ids (myo_field)
 (F_QPOS, F_QVEL, F_ACT, F_CTRL, F_WARMSTART, F_TIME, F_TARGET, F_OBS, F_REWARD, F_DONE, F_SOLVED, F_FLAGS, F_DIAG,
- F_QACC, F_TENLEN, F_ACTFORCE, F_SITEXPOS, F_ELAPSED, F_ACTION, F_FATIGUE, F_HFIELD) = range(21)
+ F_QACC, F_TENLEN, F_ACTFORCE, F_SITEXPOS, F_ELAPSED, F_ACTION, F_FATIGUE, F_HFIELD, F_GEOMSIZE) = range(22)
 INT_FIELDS = (F_FLAGS, F_DIAG, F_ELAPSED)
 BENCH_OBS, BENCH_FRESH_ACTIONS, BENCH_AUTORESET = 1, 2, 4
 ACTMAP_NONE, ACTMAP_MUSCLE_SIGMOID, ACTMAP_SIGMOID_FATIGUE, ACTMAP_SIGMOID_REAFFERENTATION = 0, 1, 2, 3
@@ -114,6 +114,7 @@ def lib():
         L.myo_sync.argtypes = [C.c_void_p]
         L.myo_bench_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
         L.myo_bench_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.myo_batch_set_geom_override.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.myo_bench_last_kernel_name.argtypes = [C.c_void_p]
         L.myo_bench_last_kernel_name.restype = C.c_char_p
         L.myo_obs_only.argtypes = [C.c_void_p, C.c_void_p]
@@ -226,6 +227,14 @@ class HipBatch:
 
     def set_condition(self, frame_skip, epl_actuator=-1, eip_actuator=-1):
         _chk(lib().myo_batch_set_condition(self.h, int(frame_skip), int(epl_actuator), int(eip_actuator)))
+
+    def set_geom_override(self, geom_id, size_lo=None, size_hi=None):
+        """Per-env size of one collision geom, re-drawn ~ U(lo, hi) at every reset of an env (None: off)."""
+        if size_lo is None:
+            _chk(lib().myo_batch_set_geom_override(self.h, int(geom_id), None, None))
+            return
+        lo, hi = (C.c_float * 3)(*[float(x) for x in size_lo]), (C.c_float * 3)(*[float(x) for x in size_hi])
+        _chk(lib().myo_batch_set_geom_override(self.h, int(geom_id), lo, hi))
 
     def obs_reset_only(self, stream=None):
         _chk(lib().myo_obs_reset_only(self.h, stream))

@@ -81,6 +81,8 @@ struct DevBatch {
   float fat_dt;            // its time step = frame_skip * timestep
   int reaf_epl, reaf_eip;  // actuator ids of the EIP -> EPL tendon transfer (muscle condition "reafferentation")
   float* hfield;           // [B][nrow * ncol] height-field elevation per env (terrain models; NULL otherwise)
+  float* gsize;            // [B][4] per-env size (3) + bounding radius of ONE collision geom (ObjHoldRandomEnvV0 re-draws the object's size); NULL: none
+  int gsize_cg;            // its collision-geom index
 };
 
 struct TaskDev {
@@ -91,6 +93,8 @@ struct TaskDev {
   const float* init_qvel;   // walk task: reset velocity (NULL = zero)
   const float* rnd;         // [4][nq] reset noise lo | hi and clip lo | hi per qpos entry (NULL: none)
   float tip_lpos[3];        // stand task: tip site in the root link's frame
+  int gsize_type;           // per-env geom size override: geom type (0: off), size ~ U(gsize_lo, gsize_hi) per axis at every reset
+  float gsize_lo[3], gsize_hi[3];
   int terrain, hf_n;        // terrain walk: myo_terrain kind and cells of the elevation grid re-drawn at reset (0: none)
   float terrain_lo, terrain_hi;
 };

@@ -48,6 +48,7 @@ struct myo_model {
   myo_dims dims{};
   std::vector<void*> dev_allocs;
   std::vector<float> qpos0, jnt_lo, jnt_hi;
+  std::vector<int> cg_geom, cg_type_h;   // collision geom -> compiled geom id, and its type (host copies)
   std::vector<int> body_link;                       // body -> link, pose of the body inside the link frame (walk task)
   std::vector<float> body_lpos, body_lquat, mass;   // mass = [total, static bodies' mass-weighted COM xyz]
   float* d_qpos0 = nullptr;
@@ -256,6 +257,7 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
       w.has_free = fl[0]; w.nq = fl[1]; w.neq = fl[2];
       if (fl.size() < 6) { myo_model_free(m); return fail(MYO_E_BLOB, "hip_flags: blob predates the actuator-kind tables; recompile the model"); }
       w.has_j0 = fl[3]; d.na_obs = fl[4]; m->has_affine = fl[5] != 0;
+      { const int* t2; if ((rc = load_i(m, blob, "hip_cg_geom", &t2, &m->cg_geom)) || (rc = load_i(m, blob, "hip_cg_type", &t2, &m->cg_type_h))) { myo_model_free(m); return rc; } }
       {
         std::vector<int> hi; std::vector<float> hf; const float* tf2;
         if ((rc = load_i(m, blob, "hip_hf_i", &tmpi, &hi)) || (rc = load_f(m, blob, "hip_hf_f", &tf2, &hf))) { myo_model_free(m); return rc; }
@@ -345,7 +347,7 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   BA(b->d_tlo, b->ntarget_alloc) BA(b->d_thi, b->ntarget_alloc) BA(b->d_init, nq) BA(b->d_jlo, nv) BA(b->d_jhi, nv) BA(b->d_rnd, 4 * (size_t)nq)
   BA(b->d_action, (size_t)B * nu)
   BA(d.fatigue, (size_t)B * 3 * nu)
-  d.hfield = nullptr;
+  d.hfield = nullptr; d.gsize = nullptr; d.gsize_cg = -1;
   if (m->dw.hf.on) { BA(d.hfield, (size_t)B * m->dw.hf.nrow * m->dw.hf.ncol) }   // zero-filled: flat terrain at the geom's height
   BA(b->d_initv, nv)
   { void* pw = nullptr; if ((rc = balloc(b, &pw, sizeof(DevWalk)))) { myo_batch_free(b); return rc; } b->d_walk = (DevWalk*)pw; }
@@ -435,6 +437,26 @@ int myo_batch_configure(myo_batch* b, const myo_task_config* c) {
   return MYO_OK;
 }
 
+int myo_batch_set_geom_override(myo_batch* b, int geom_id, const float* lo, const float* hi) {
+  if (!b) return fail(MYO_E_ARG, "myo_batch_set_geom_override: null");
+  const myo_model* m = b->model;
+  if (!lo || !hi) { b->task.gsize_type = 0; b->db.gsize_cg = -1; return MYO_OK; }
+  if (!(m->wave_ok && m->wave_cfg == 1) || m->leg_sizes || m->dw.hf.on) return fail(MYO_E_UNSUPPORTED, "geom override: generic large-kernel models only");
+  int cg = -1;
+  for (size_t i = 0; i < m->cg_geom.size(); i++) if (m->cg_geom[i] == geom_id) cg = (int)i;
+  if (cg < 0) return fail(MYO_E_ARG, "geom override: not a collision geom of this model");
+  const int ty = m->cg_type_h[cg];
+  if (ty != GEOM_SPHERE && ty != GEOM_CAPSULE && ty != GEOM_ELLIPSOID && ty != GEOM_CYLINDER) return fail(MYO_E_UNSUPPORTED, "geom override: sphere / capsule / ellipsoid / cylinder geoms only");
+  if (!b->db.gsize) {
+    int rc = balloc(b, (void**)&b->db.gsize, (size_t)b->db.B * 4 * 4);
+    if (rc) return rc;
+  }
+  b->db.gsize_cg = cg;
+  b->task.gsize_type = ty;
+  for (int k = 0; k < 3; k++) { b->task.gsize_lo[k] = lo[k]; b->task.gsize_hi[k] = hi[k]; }
+  return MYO_OK;
+}
+
 int myo_batch_configure_walk(myo_batch* b, const myo_walk_config* c) {
   if (!b || !c) return fail(MYO_E_ARG, "myo_batch_configure_walk: null");
   const myo_model* m = b->model;
@@ -503,6 +525,9 @@ static int field_info(myo_batch* b, int f, void** p, size_t* pitch, size_t* widt
     case MYO_F_ELAPSED: *p = d.elapsed; *pitch = *width = 1; break;
     case MYO_F_ACTION: *p = b->d_action; *pitch = *width = nu; break;
     case MYO_F_FATIGUE: *p = d.fatigue; *pitch = *width = 3 * nu; break;
+    case MYO_F_GEOMSIZE:
+      if (!d.gsize) return fail(MYO_E_ARG, "MYO_F_GEOMSIZE: no geom override set (myo_batch_set_geom_override)");
+      *p = d.gsize; *pitch = *width = 4; break;
     case MYO_F_HFIELD:
       if (!d.hfield) return fail(MYO_E_ARG, "MYO_F_HFIELD: the model has no colliding height field");
       *p = d.hfield; *pitch = *width = b->model->dw.hf.nrow * b->model->dw.hf.ncol; break;

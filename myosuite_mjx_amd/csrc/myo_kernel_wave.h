@@ -362,6 +362,11 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     d_nefc = ldstatei<SCHED>(D); d_ncon = ldstatei<SCHED>(D + 1);   // the observation pass has no rows of its own: keep the last substep's
     d_iter = a2; f_cand = a4 & 0xFFFF; f_ncon = a4 >> 16; f_mpr = a5; f_itcon = a6 & 0xFFFF; f_iter = a6 >> 16; f_ls = a7 & 0xFFFF; f_fact = a7 >> 16;
   }
+  // per-env size of one collision geom (DevBatch.gsize), generic FULL instantiations only: the size-specialised and hand kernels keep
+  // reading the model tables unconditionally
+  constexpr bool OVR = FULL && SPEC == 0 && !HF;
+  auto cgsz = [&](int g) -> const float* { return (OVR && Bt.gsize && g == Bt.gsize_cg) ? (const float*)(Bt.gsize + 4 * (size_t)env) : M.cg_size + 3 * g; };
+  auto cgrb = [&](int g) -> float { return (OVR && Bt.gsize && g == Bt.gsize_cg) ? Bt.gsize[4 * (size_t)env + 3] : M.cg_rbound[g]; };
   bool alive = true;
   int n_mprw = 0;   // MPR warm-start table (pair id + last contact normal in geom 1's frame): entries of the previous substep
   if (SCHED && s0 > 0) {   // ... which another wave ran: the table travels through the batch like the state rows, so that a scheduled
@@ -793,26 +798,26 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             int g1 = P[0], g2 = P[1];
             const float *x1 = E + Y.gpos + 3 * g1, *x2 = E + Y.gpos + 3 * g2;
             float dif[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
-            float bound = M.cg_rbound[g1] + M.cg_rbound[g2] + M.pair_f[12 * p];
-            if (FULL && P[4] >= 2) hit = dot3(dif, E + Y.gax + 3 * g1) <= M.cg_rbound[g2] + M.pair_f[12 * p];   // plane: signed distance of the bounding sphere
+            float bound = cgrb(g1) + cgrb(g2) + M.pair_f[12 * p];
+            if (FULL && P[4] >= 2) hit = dot3(dif, E + Y.gax + 3 * g1) <= cgrb(g2) + M.pair_f[12 * p];   // plane: signed distance of the bounding sphere
             else hit = dot3(dif, dif) <= bound * bound;
             if (hit && !P[4]) {
               // conservative refinement before the expensive MPR: replace a capsule's bounding sphere by the distance
               // from the other geom's centre to the capsule's SEGMENT (a bound on the true distance, never excludes a contact)
-              float b1 = M.cg_rbound[g1], b2 = M.cg_rbound[g2];
+              float b1 = cgrb(g1), b2 = cgrb(g2);
               float c1[3] = {x1[0], x1[1], x1[2]}, c2[3] = {x2[0], x2[1], x2[2]};
               if (M.cg_type[g1] == GEOM_CAPSULE) {
                 const float* a = E + Y.gax + 3 * g1;
-                float hh = M.cg_size[3 * g1 + 1], t = clipf(dot3(dif, a), -hh, hh);
+                float hh = cgsz(g1)[1], t = clipf(dot3(dif, a), -hh, hh);
                 c1[0] += t * a[0]; c1[1] += t * a[1]; c1[2] += t * a[2];
-                b1 = M.cg_size[3 * g1];
+                b1 = cgsz(g1)[0];
               }
               if (M.cg_type[g2] == GEOM_CAPSULE) {
                 const float* a = E + Y.gax + 3 * g2;
                 float nd[3] = {c1[0] - x2[0], c1[1] - x2[1], c1[2] - x2[2]};
-                float hh = M.cg_size[3 * g2 + 1], t = clipf(dot3(nd, a), -hh, hh);
+                float hh = cgsz(g2)[1], t = clipf(dot3(nd, a), -hh, hh);
                 c2[0] += t * a[0]; c2[1] += t * a[1]; c2[2] += t * a[2];
-                b2 = M.cg_size[3 * g2];
+                b2 = cgsz(g2)[0];
               }
               float d2[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
               float bb = b1 + b2 + M.pair_f[12 * p];
@@ -827,7 +832,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
 #pragma unroll
                   for (int side = 0; side < 2; side++) {
                     const int g = side ? g2 : g1;
-                    const float* sz = M.cg_size + 3 * g;
+                    const float* sz = cgsz(g);
                     const int ty = M.cg_type[g];
                     if (ty == GEOM_CAPSULE) wsum += sz[0] + sz[1] * fabsf(dot3(E + Y.gax + 3 * g, ax));
                     else if (ty == GEOM_SPHERE) wsum += sz[0];
@@ -881,7 +886,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           int g1 = P[0], g2 = P[1];
           float margin = M.pair_f[12 * p];
           const float *x1 = E + Y.gpos + 3 * g1, *x2 = E + Y.gpos + 3 * g2;
-          const float *sz1 = M.cg_size + 3 * g1, *sz2 = M.cg_size + 3 * g2;
+          const float *sz1 = cgsz(g1), *sz2 = cgsz(g2);
           if (P[4] == 1) {
             const float *a1 = E + Y.gax + 3 * g1, *a2 = E + Y.gax + 3 * g2;
             float dif[3] = {x1[0] - x2[0], x1[1] - x2[1], x1[2] - x2[2]};

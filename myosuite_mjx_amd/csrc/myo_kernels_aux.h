@@ -141,6 +141,14 @@ __global__ void __launch_bounds__(64) reset_kernel(DevBatch Bt, TaskDev T, int n
     float lo = T.target_lo[i], hi = T.target_hi[i];
     Bt.target[(size_t)e * T.ntarget + i] = T.target_generate ? lo + (hi - lo) * u01(seed, ge * 4096 + 2048 + i, 2) : lo;
   }
+  if (T.gsize_type && Bt.gsize && lane == 0) {
+    // ObjHoldRandomEnvV0.reset (obj_hold_v0.py:133-139): a fresh size for the object's geom per episode (its mass and inertia stay)
+    float sz[3];
+    for (int k = 0; k < 3; k++) sz[k] = T.gsize_lo[k] + (T.gsize_hi[k] - T.gsize_lo[k]) * u01(seed ^ 0xD1B54A32D192ED03ull, ge * 8 + k, 5);
+    float rb = T.gsize_type == GEOM_ELLIPSOID ? fmaxf(sz[0], fmaxf(sz[1], sz[2])) : (T.gsize_type == GEOM_CAPSULE ? sz[0] + sz[1] : (T.gsize_type == GEOM_CYLINDER ? sqrtf(sz[0] * sz[0] + sz[1] * sz[1]) : sz[0]));
+    float* G = Bt.gsize + 4 * (size_t)e;
+    G[0] = sz[0]; G[1] = sz[1]; G[2] = sz[2]; G[3] = rb;
+  }
   if (T.terrain && Bt.hfield) {
     // TerrainEnvV0.reset (walk_v0.py:563-622): a fresh 100 x 100 elevation grid per episode (in units of the height field's z scale).
     // Distribution parity only for the random draws, as for every reset.

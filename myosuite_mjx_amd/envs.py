@@ -105,6 +105,9 @@ REGISTRY["myoHandObjHoldFixed-v0"] = dict(
     model="myohand_hold", task="hold", max_episode_steps=75, frame_skip=10, normalize_act=True, reset_type="init",
     goal=(-0.240, -0.520, 1.470), goal_th=0.010, drop_th=0.300,
     weights=dict(goal_dist=100.0, bonus=4.0, penalty=10.0, act_reg=0.0))
+# myoHandObjHoldRandom-v0 (:605-613, ObjHoldRandomEnvV0 obj_hold_v0.py:121-140): goal = object's initial position + U(+-0.03)^3 and the object's
+# ellipsoid semi-axes ~ U(0.02, 0.03)^3, both re-drawn per episode (the size is a per-env override of that one geom; mass / inertia stay)
+REGISTRY["myoHandObjHoldRandom-v0"] = dict(REGISTRY["myoHandObjHoldFixed-v0"], goal=None, goal_span=0.030, object_size=((0.020,) * 3, (0.030,) * 3))
 # myoFingerReach*-v0 (envs/myo/myobase/__init__.py:82-105): IFtip to an absolute target box; far_th = ReachEnvV0's default 0.35
 REGISTRY["myoFingerReachFixed-v0"] = _reach_box_spec("myofinger_v0", ("IFtip",), [(0.2, 0.05, 0.20)], [(0.2, 0.05, 0.20)], 0.35)
 REGISTRY["myoFingerReachRandom-v0"] = _reach_box_spec("myofinger_v0", ("IFtip",), [(0.1, -0.1, 0.1)], [(0.27, 0.1, 0.3)], 0.35)
@@ -137,7 +140,6 @@ for _id in [k for k in list(REGISTRY) if k.startswith("myo")]:
 UNSUPPORTED = {
     # (nothing of the walk family: the terrain envs run on the height-field instantiation of the leg kernel)
     "myoElbowPose1D6MExoRandom-v0": "re-draws the mass of body carry_weight per episode (a per-env model edit)",
-    "myoHandObjHoldRandom-v0": "re-draws the object's geom size per episode (a per-env model edit)",
 }
 
 
@@ -249,11 +251,17 @@ class BatchedMyoEnv:
             init = np.array(m.qpos0, float)
             init[:-7] = 0.0                                            # obj_hold_v0.py:63-64: fully open hand, palm up
             init[0] = -1.5
-            self.batch.configure(task=capi.TASK_HOLD, frame_skip=self.frame_skip, reset_random=0, target_generate=0,
-                                 target_lo=np.asarray(spec["goal"], float), target_hi=np.asarray(spec["goal"], float), init_qpos=init,
+            if spec["goal"] is None:                                   # Random: around the object's site at the model's initial pose (:125-131)
+                glo, ghi = np.asarray(m.qpos0[-7:-4], float) - spec["goal_span"], np.asarray(m.qpos0[-7:-4], float) + spec["goal_span"]
+            else:
+                glo = ghi = np.asarray(spec["goal"], float)
+            self.batch.configure(task=capi.TASK_HOLD, frame_skip=self.frame_skip, reset_random=0, target_generate=int(spec["goal"] is None),
+                                 target_lo=glo, target_hi=ghi, init_qpos=init,
                                  near_th=spec["goal_th"], far_th=spec["drop_th"],
                                  w_reach=w["goal_dist"], w_bonus=w["bonus"], w_act_reg=w["act_reg"], w_penalty=w["penalty"])
             self.obs_dim = (m.nq - 7) + (m.nv - 6) + 6 + m.n_muscle
+            if "object_size" in spec:
+                self.batch.set_geom_override(m.name2id("geom", "object"), *spec["object_size"])
         else:
             tips = [m.name2id("site", t) for t in spec["tips"]]
             n = len(tips)

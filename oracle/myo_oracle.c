@@ -295,6 +295,20 @@ Data* myoo_make_data(const Model* m) {
   return d;
 }
 
+/* model edit between episodes, as ObjHoldRandomEnvV0.reset does to model.geom_size (obj_hold_v0.py:133-139): size and bounding radius of one
+ * primitive geom; mass and inertia stay (the reference does not recompile either) */
+void myoo_set_geom_size(Model* m, int g, const double* size) {
+  for (int k = 0; k < 3; k++) m->geom_size[3 * g + k] = (real)size[k];
+  real a = (real)size[0], b = (real)size[1], c = (real)size[2], rb = a;
+  switch (m->geom_type[g]) {
+    case GEOM_CAPSULE: rb = a + b; break;
+    case GEOM_CYLINDER: rb = sqrt(a * a + b * b); break;
+    case GEOM_ELLIPSOID: rb = maxr(a, maxr(b, c)); break;
+    default: break;
+  }
+  m->geom_rbound[g] = rb;
+}
+
 void myoo_set_hfield(const Model* m, Data* d, const float* data) {
   memcpy(d->hfield_data, data, (size_t)m->hfield_dims[0] * m->hfield_dims[1] * sizeof(float));
 }

@@ -49,6 +49,7 @@ class Oracle:
         L.myoo_energy.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         L.myoo_set_switch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.myoo_set_hfield.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.myoo_set_geom_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
         L.myoo_step_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]
         self.real = np.float32 if L.myoo_sizeof_real() == 4 else np.float64
         self._blob = blob
@@ -82,6 +83,10 @@ class Oracle:
 
     def switches(self, disable_contact=0, disable_limit=0, disable_ellipsoid=0):
         self.lib.myoo_set_switch(self.m, disable_contact, disable_limit, disable_ellipsoid)
+
+    def set_geom_size(self, geom_id, size):
+        """model.geom_size[geom_id] = size (3 floats), bounding radius updated; this Oracle instance's model only."""
+        self.lib.myoo_set_geom_size(self.m, int(geom_id), (C.c_double * 3)(*[float(x) for x in size]))
 
     def set_hfield(self, data):
         """Elevation grid [nrow, ncol] (mjModel.hfield_data) of the colliding height field."""

@@ -88,7 +88,9 @@ def test_registry_matches_reference_specs():
     assert ls["weights"] == dict(reach=1.0, bonus=4.0, penalty=50.0, act_reg=1.0) and ls["target_span"] == ((-0.05, -0.05, 0.0), (0.05, 0.05, 0.0))
     oh = REGISTRY["myoHandObjHoldFixed-v0"]                      # envs/myo/myobase/__init__.py:596-604, obj_hold_v0.py:16-20,96-97
     assert oh["max_episode_steps"] == 75 and oh["weights"] == dict(goal_dist=100.0, bonus=4.0, penalty=10.0, act_reg=0.0) and (oh["goal_th"], oh["drop_th"]) == (0.010, 0.300)
-    assert "myoHandObjHoldRandom-v0" in UNSUPPORTED and "myoElbowPose1D6MExoRandom-v0" in UNSUPPORTED
+    ohr = REGISTRY["myoHandObjHoldRandom-v0"]                    # obj_hold_v0.py:121-140
+    assert ohr["goal"] is None and ohr["goal_span"] == 0.030 and ohr["object_size"] == ((0.020,) * 3, (0.030,) * 3)
+    assert "myoElbowPose1D6MExoRandom-v0" in UNSUPPORTED
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/myosuite"), reason="reference tree not present")

@@ -137,5 +137,56 @@ def test_obj_hold_env(hold):
         obs, rwd, term, trunc, info = env2.step(torch.rand((48, 39), device="cuda", generator=g) * 2 - 1)
         ndone += int(term.sum())
     assert trunc.all() or ndone > 0
-    with pytest.raises(NotImplementedError):
-        myo.make("myoHandObjHoldRandom-v0", num_envs=1)
+
+
+def test_per_env_object_size(hold):
+    """ObjHoldRandomEnvV0 edits model.geom_size of the object per episode (obj_hold_v0.py:133-139): per-env size of that one collision geom
+    (MYO_F_GEOMSIZE) against oracle instances whose model carries the same edit; then the env: sizes and goals re-drawn per episode."""
+    import torch
+    import myosuite_mjx_amd as myo
+    from myosuite_mjx_amd import capi
+    from oracle.oracle import Oracle
+    m = hold
+    og = m.name2id("geom", "object")
+    hm = capi.HipModel(m.blob(), 0)
+    N = 48
+    q, v, act, ctrl = _states(m, N, 7)
+    rng = np.random.default_rng(7)
+    sizes = rng.uniform(0.020, 0.030, (N, 3)).astype(np.float32)
+    b = capi.HipBatch(hm, N)
+    b.set_geom_override(og, (0.02,) * 3, (0.03,) * 3)
+    for f, a in ((capi.F_QPOS, q), (capi.F_QVEL, v), (capi.F_ACT, act), (capi.F_CTRL, ctrl),
+                 (capi.F_GEOMSIZE, np.concatenate([sizes, sizes.max(1, keepdims=True)], 1))):
+        b.write(f, a)
+    b.step(None, capi.ACTMAP_NONE, 1)
+    gq, gv, dg, fl = b.read(capi.F_QPOS), b.read(capi.F_QVEL), b.read(capi.F_DIAG), b.status()
+    eq, ev, same, differs = np.zeros(N), np.zeros(N), np.zeros(N, bool), 0
+    for e in range(N):
+        o = Oracle(m.blob())
+        o.set_geom_size(og, sizes[e])
+        o.reset()
+        o.set_state(qpos=q[e], qvel=v[e], act=act[e], ctrl=ctrl[e])
+        assert o.step(1) == 0
+        eq[e], ev[e] = np.abs(gq[e] - o.field("qpos")).max(), np.abs(gv[e] - o.field("qvel")).max()
+        same[e] = fl[e] == 0 and dg[e, 1] == o.ncon
+        o0 = Oracle(m.blob())                       # the unedited model gives a different answer: the override is really in effect
+        o0.reset()
+        o0.set_state(qpos=q[e], qvel=v[e], act=act[e], ctrl=ctrl[e])
+        o0.step(1)
+        differs += int(np.abs(o0.field("qvel") - o.field("qvel")).max() > 1e-3)
+    assert same.mean() > 0.9 and differs > N // 3
+    assert eq[same].max() < 2e-5 and ev[same].max() < 2e-2, (eq[same].max(), ev[same].max())
+    env = myo.make("myoHandObjHoldRandom-v0", num_envs=64, seed=2)
+    obs = env.reset(seed=2)
+    assert obs.shape == (64, 91)
+    g0 = env.batch.read(capi.F_GEOMSIZE)
+    st = env.get_env_state()
+    assert (g0[:, :3] >= 0.02 - 1e-7).all() and (g0[:, :3] <= 0.03 + 1e-7).all() and np.allclose(g0[:, 3], g0[:, :3].max(1)) and g0[:, :3].std() > 0.002
+    c = np.asarray(m.qpos0[-7:-4])
+    assert (np.abs(st["target"] - c[None, :]) <= 0.03 + 1e-6).all() and st["target"].std(0).min() > 0.01
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    for k in range(76):                                         # one whole 75-step episode: every env is reset at least once
+        env.step(torch.rand((64, 39), device="cuda", generator=gen) * 2 - 1)
+    g1 = env.batch.read(capi.F_GEOMSIZE)
+    assert (np.abs(g1[:, :3] - g0[:, :3]).max(1) > 1e-4).all() and (g1[:, :3] >= 0.02 - 1e-7).all() and (g1[:, :3] <= 0.03 + 1e-7).all()
+    assert (env.status() == 0).all()
