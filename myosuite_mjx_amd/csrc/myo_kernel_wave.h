@@ -501,7 +501,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             matmul3(gmat, E + Y.lmat + 9 * gl, M.wg_lmat + 9 * g);
           }
           if (S[3] >= 0) site_world_w(M, Y, E, S[3], side);
-          wlen = wrap_geom(wp, p0, p1, gpos, gmat, M.wg_radius[g], S[10] != 0, side, S[3] >= 0);
+          if constexpr (FULL) wlen = wrap_geom_inl(wp, p0, p1, gpos, gmat, M.wg_radius[g], S[10] != 0, side, S[3] >= 0);
+          else wlen = wrap_geom(wp, p0, p1, gpos, gmat, M.wg_radius[g], S[10] != 0, side, S[3] >= 0);
         }
         SUB(7);
         bool wr = wlen >= 0;

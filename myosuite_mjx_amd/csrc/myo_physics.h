@@ -99,73 +99,83 @@ __device__ float wrap_inside(float* pnt, const float* d, float rad) {
   return 0;
 }
 
-// returns wrap length (<0: no wrap); wpnt = two world points
+// returns wrap length (<0: no wrap); wpnt = two world points.  Two copies of one body: the 24-dof (hand / finger) kernels call the
+// out-of-line wrap_geom, the 36-dof kernels inline wrap_geom_inl (+4 %: an out-of-line call passes its array arguments through scratch
+// memory) -- inlining it into the hand kernel as well, or even routing the out-of-line copy through the inline one, costs that
+// kernel 0.6 % (register allocation again), so the two are kept textually separate
+#define MYO_WRAP_GEOM_BODY  \
+  float p[6], s[3] = {0, 0, 0}, tmp[3], axis[6], d[4], sd[2] = {0, 0}, pnt[4], res[6];  \
+  tmp[0] = x0[0] - xpos[0]; tmp[1] = x0[1] - xpos[1]; tmp[2] = x0[2] - xpos[2];  \
+  matTvec(p, xmat, tmp);  \
+  tmp[0] = x1[0] - xpos[0]; tmp[1] = x1[1] - xpos[1]; tmp[2] = x1[2] - xpos[2];  \
+  matTvec(p + 3, xmat, tmp);  \
+  if (norm3(p) < MINVALF || norm3(p + 3) < MINVALF) return -1;  \
+  if (has_side) {  \
+    tmp[0] = side[0] - xpos[0]; tmp[1] = side[1] - xpos[1]; tmp[2] = side[2] - xpos[2];  \
+    matTvec(s, xmat, tmp);  \
+  }  \
+  if (!cylinder) {  \
+    axis[0] = p[0]; axis[1] = p[1]; axis[2] = p[2];  \
+    normalize3(axis);  \
+    float nrmv[3];  \
+    cross3(nrmv, p, p + 3);  \
+    float nrm = norm3(nrmv);  \
+    if (nrm < MINVALF) {  \
+      int i = 0;  \
+      if (fabsf(axis[1]) > fabsf(axis[0]) && fabsf(axis[1]) > fabsf(axis[2])) i = 1;  \
+      if (fabsf(axis[2]) > fabsf(axis[0]) && fabsf(axis[2]) > fabsf(axis[1])) i = 2;  \
+      float t[3] = {i == 0 ? 0.f : 1.f, i == 1 ? 0.f : 1.f, i == 2 ? 0.f : 1.f};  \
+      cross3(nrmv, axis, t);  \
+      nrm = norm3(nrmv);  \
+    }  \
+    float inv = 1.0f / nrm;  \
+    nrmv[0] *= inv; nrmv[1] *= inv; nrmv[2] *= inv;  \
+    cross3(axis + 3, nrmv, axis);  \
+    normalize3(axis + 3);  \
+    d[0] = dot3(p, axis); d[1] = dot3(p, axis + 3); d[2] = dot3(p + 3, axis); d[3] = dot3(p + 3, axis + 3);  \
+    if (has_side) { sd[0] = dot3(s, axis); sd[1] = dot3(s, axis + 3); }  \
+  } else {  \
+    d[0] = p[0]; d[1] = p[1]; d[2] = p[3]; d[3] = p[4];  \
+    if (has_side) { sd[0] = s[0]; sd[1] = s[1]; }  \
+  }  \
+  float wlen;  \
+  float sdn = sqrtf(sd[0] * sd[0] + sd[1] * sd[1]);  \
+  if (has_side && sdn < radius) {  \
+    wlen = wrap_inside(pnt, d, radius);  \
+  } else {  \
+    if (has_side && sdn > MINVALF) { sd[0] /= sdn; sd[1] /= sdn; }  \
+    wlen = wrap_circle(pnt, d, sd, has_side, radius);  \
+  }  \
+  if (wlen < 0) return -1;  \
+  if (!cylinder) {  \
+_Pragma("unroll")  \
+    for (int k = 0; k < 3; k++) {  \
+      res[k] = axis[k] * pnt[0] + axis[3 + k] * pnt[1];  \
+      res[3 + k] = axis[k] * pnt[2] + axis[3 + k] * pnt[3];  \
+    }  \
+  } else {  \
+    float L0 = sqrtf((p[0] - pnt[0]) * (p[0] - pnt[0]) + (p[1] - pnt[1]) * (p[1] - pnt[1]));  \
+    float L1 = sqrtf((p[3] - pnt[2]) * (p[3] - pnt[2]) + (p[4] - pnt[3]) * (p[4] - pnt[3]));  \
+    float tot = L0 + wlen + L1;  \
+    res[0] = pnt[0]; res[1] = pnt[1]; res[3] = pnt[2]; res[4] = pnt[3];  \
+    res[2] = p[2] + (p[5] - p[2]) * L0 / tot;  \
+    res[5] = p[2] + (p[5] - p[2]) * (L0 + wlen) / tot;  \
+    float h = res[5] - res[2];  \
+    wlen = sqrtf(wlen * wlen + h * h);  \
+  }  \
+  matvec(wpnt, xmat, res);  \
+  matvec(wpnt + 3, xmat, res + 3);  \
+_Pragma("unroll")  \
+  for (int k = 0; k < 3; k++) { wpnt[k] += xpos[k]; wpnt[3 + k] += xpos[k]; }  \
+  return wlen;
+
 __device__ float wrap_geom(float* wpnt, const float* x0, const float* x1, const float* xpos, const float* xmat, float radius,
                            bool cylinder, const float* side, bool has_side) {
-  float p[6], s[3] = {0, 0, 0}, tmp[3], axis[6], d[4], sd[2] = {0, 0}, pnt[4], res[6];
-  tmp[0] = x0[0] - xpos[0]; tmp[1] = x0[1] - xpos[1]; tmp[2] = x0[2] - xpos[2];
-  matTvec(p, xmat, tmp);
-  tmp[0] = x1[0] - xpos[0]; tmp[1] = x1[1] - xpos[1]; tmp[2] = x1[2] - xpos[2];
-  matTvec(p + 3, xmat, tmp);
-  if (norm3(p) < MINVALF || norm3(p + 3) < MINVALF) return -1;
-  if (has_side) {
-    tmp[0] = side[0] - xpos[0]; tmp[1] = side[1] - xpos[1]; tmp[2] = side[2] - xpos[2];
-    matTvec(s, xmat, tmp);
-  }
-  if (!cylinder) {
-    axis[0] = p[0]; axis[1] = p[1]; axis[2] = p[2];
-    normalize3(axis);
-    float nrmv[3];
-    cross3(nrmv, p, p + 3);
-    float nrm = norm3(nrmv);
-    if (nrm < MINVALF) {
-      int i = 0;
-      if (fabsf(axis[1]) > fabsf(axis[0]) && fabsf(axis[1]) > fabsf(axis[2])) i = 1;
-      if (fabsf(axis[2]) > fabsf(axis[0]) && fabsf(axis[2]) > fabsf(axis[1])) i = 2;
-      float t[3] = {i == 0 ? 0.f : 1.f, i == 1 ? 0.f : 1.f, i == 2 ? 0.f : 1.f};
-      cross3(nrmv, axis, t);
-      nrm = norm3(nrmv);
-    }
-    float inv = 1.0f / nrm;
-    nrmv[0] *= inv; nrmv[1] *= inv; nrmv[2] *= inv;
-    cross3(axis + 3, nrmv, axis);
-    normalize3(axis + 3);
-    d[0] = dot3(p, axis); d[1] = dot3(p, axis + 3); d[2] = dot3(p + 3, axis); d[3] = dot3(p + 3, axis + 3);
-    if (has_side) { sd[0] = dot3(s, axis); sd[1] = dot3(s, axis + 3); }
-  } else {
-    d[0] = p[0]; d[1] = p[1]; d[2] = p[3]; d[3] = p[4];
-    if (has_side) { sd[0] = s[0]; sd[1] = s[1]; }
-  }
-  float wlen;
-  float sdn = sqrtf(sd[0] * sd[0] + sd[1] * sd[1]);
-  if (has_side && sdn < radius) {
-    wlen = wrap_inside(pnt, d, radius);
-  } else {
-    if (has_side && sdn > MINVALF) { sd[0] /= sdn; sd[1] /= sdn; }
-    wlen = wrap_circle(pnt, d, sd, has_side, radius);
-  }
-  if (wlen < 0) return -1;
-  if (!cylinder) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      res[k] = axis[k] * pnt[0] + axis[3 + k] * pnt[1];
-      res[3 + k] = axis[k] * pnt[2] + axis[3 + k] * pnt[3];
-    }
-  } else {
-    float L0 = sqrtf((p[0] - pnt[0]) * (p[0] - pnt[0]) + (p[1] - pnt[1]) * (p[1] - pnt[1]));
-    float L1 = sqrtf((p[3] - pnt[2]) * (p[3] - pnt[2]) + (p[4] - pnt[3]) * (p[4] - pnt[3]));
-    float tot = L0 + wlen + L1;
-    res[0] = pnt[0]; res[1] = pnt[1]; res[3] = pnt[2]; res[4] = pnt[3];
-    res[2] = p[2] + (p[5] - p[2]) * L0 / tot;
-    res[5] = p[2] + (p[5] - p[2]) * (L0 + wlen) / tot;
-    float h = res[5] - res[2];
-    wlen = sqrtf(wlen * wlen + h * h);
-  }
-  matvec(wpnt, xmat, res);
-  matvec(wpnt + 3, xmat, res + 3);
-#pragma unroll
-  for (int k = 0; k < 3; k++) { wpnt[k] += xpos[k]; wpnt[3 + k] += xpos[k]; }
-  return wlen;
+  MYO_WRAP_GEOM_BODY
+}
+__device__ __forceinline__ float wrap_geom_inl(float* wpnt, const float* x0, const float* x1, const float* xpos, const float* xmat, float radius,
+                                               bool cylinder, const float* side, bool has_side) {
+  MYO_WRAP_GEOM_BODY
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -340,7 +350,7 @@ __device__ __forceinline__ void expand_portal(Sup* p, const Sup& v4) {
 #define MPR_WARM_EPS 0.05f
 #endif
 template <bool HF>
-__device__ bool mpr_penetration_t(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup = nullptr,
+__device__ __forceinline__ bool mpr_penetration_t(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup = nullptr,
                                   const float* nwarm = nullptr) {
   Sup p[4];
   float dir[3], va[3], vb[3];
@@ -485,7 +495,7 @@ __device__ __forceinline__ void portal_dir_v(const V3* p, float* dir) {
   cross3(dir, a, b);
   normalize3(dir);
 }
-__device__ bool mpr_penetration_wl(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup,
+__device__ __forceinline__ bool mpr_penetration_wl(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup,
                                    const float* nwarm, float* wl) {
   V3 p[4];
   Sup s;
