@@ -1,0 +1,35 @@
+"""Soak run on the GPU box: long rollouts of the main envs at full batch with U(-1,1) actions and auto-reset, counting every per-env fault
+flag (bad state / bad qacc resets, contact or candidate table overflows, scheduler time-outs) and checking the final states.
+Writes gpurun_out/r1_soak.json (copy to profiles/)."""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from myosuite_mjx_amd import capi
+from myosuite_mjx_amd.envs import BatchedMyoEnv
+
+PLAN = [("myoHandPoseRandom-v0", 4096, 20000), ("myoHandReachRandom-v0", 4096, 5000), ("myoLegWalk-v0", 4096, 10000),
+        ("myoLegRoughTerrainWalk-v0", 4096, 5000), ("myoLegStairTerrainWalk-v0", 4096, 3000), ("myoHandObjHoldRandom-v0", 4096, 5000),
+        ("myoFingerPoseRandom-v0", 4096, 10000), ("myoElbowPose1D6MExoFixed-v0", 4096, 10000)]
+out = []
+mode = capi.BENCH_OBS | capi.BENCH_FRESH_ACTIONS | capi.BENCH_AUTORESET
+for env_id, B, steps in PLAN:
+    env = BatchedMyoEnv(env_id, num_envs=B, as_torch=False, seed=1)
+    env.reset(seed=1)
+    counts = np.zeros(5, np.int64)
+    t0 = time.time()
+    chunk = 500
+    for k in range(0, steps, chunk):
+        env.batch.bench_rollout(min(chunk, steps - k), env.frame_skip, 1, mode, env.max_episode_steps, None)
+        fl = env.status()                                  # flags accumulated since the last call, per env
+        for b in range(5):
+            counts[b] += int(((fl >> b) & 1).sum())
+    st = env.get_env_state()
+    rec = {"env": env_id, "envs": B, "env_steps": int(B) * int(steps), "seconds": round(time.time() - t0, 2),
+           "envs_flagged_per_500_step_window": {"bad_state_reset": int(counts[0]), "bad_qacc_reset": int(counts[1]), "contact_overflow": int(counts[2]),
+                                                "candidate_overflow": int(counts[3]), "sched_timeout": int(counts[4])},
+           "final_state_finite": bool(all(np.isfinite(v).all() for v in st.values())),
+           "final_act_in_01": bool((st["act"] >= 0).all() and (st["act"] <= 1).all())}
+    print(json.dumps(rec), flush=True)
+    out.append(rec)
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open(os.path.join("gpurun_out", "r1_soak.json"), "w"), indent=1)
