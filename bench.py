@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=B_PER_GPU, help="envs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=1, help="repeat the timed region R times and report the median run (SURVEY 8d config 2: 5); default 1 = the plain contract")
     ap.add_argument("--env", default=ENV_ID, help="env id (default: the BASELINE.json headline workload); other ids are extra measurements")
     args = ap.parse_args()
     env_id = args.env
@@ -135,17 +136,21 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev_ms, kernel_ms_total = run(args.steps)
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([el], device=obs.device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    runs = []
+    for _ in range(max(1, args.repeats)):
+        t0 = time.perf_counter()
+        ev_ms, kernel_ms_total = run(args.steps)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([el], device=obs.device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        runs.append((el, ev_ms, kernel_ms_total))
+    el, ev_ms, kernel_ms_total = sorted(runs)[len(runs) // 2]            # median run (the only run when --repeats 1)
     # N > 1: the observation all-gather on its own ("gather time separately"), outside the timed region: in the
     # rollout it overlaps the next step kernel, here 20 back-to-back gathers are timed with nothing else running
     gather_ms = None
@@ -205,6 +210,7 @@ def main():
                              "frac": valu_insts / (k_ms * 1e-3) / (N_SIMD * CLOCK_HZ / 4.0),
                              "note": "share of the chip's VALU issue slots used over the whole launch (256 CUs x 4 SIMDs, 2.4 GHz)"}},
             "event_ms_per_step_rank0": ev_ms / args.steps,
+            **({"repeats": len(runs), "value_per_repeat": [world * B * args.steps / r[0] for r in runs]} if len(runs) > 1 else {}),
             **({"allgather_ms_rank0": gather_ms, "allgather_bytes_out": int(gathered.numel() * 4)} if gather_ms is not None else {}),
             **({"rehearsal": "all ranks on one GPU over gloo: control-flow check only"} if os.environ.get("MYO_BENCH_REHEARSAL") == "1" else {}),
             "flagged_envs": int((flags != 0).sum()),

@@ -10,7 +10,7 @@ MYO_SCHED=0 ENV=myoLegWalk-v0 python tools/gpu_stamps.py > gpurun_out/r1_g_stage
 python bench.py > gpurun_out/r1_f_bench_line.json 2> gpurun_out/bench_err.log
 python bench.py --batch 32768 --steps 50 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_f_bench_line_B32768.json
 python bench.py --env myoLegWalk-v0 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_g_bench_line_legs.json
-python bench.py --env myoHandPoseFixed-v0 --steps 1000 --warmup 50 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_f_bench_line_config2_posefixed_1000steps.json
+python bench.py --env myoHandPoseFixed-v0 --steps 1000 --warmup 50 --repeats 5 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_f_bench_line_config2_posefixed_1000steps.json
 python bench.py --env myoHandReachRandom-v0 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_f_bench_line_reach.json
 python bench.py --env myoLegRoughTerrainWalk-v0 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_h_bench_line_terrain.json
 python bench.py --env myoHandObjHoldFixed-v0 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/r1_h_bench_line_objhold.json
