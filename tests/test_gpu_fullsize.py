@@ -179,5 +179,7 @@ def test_terrain_4096_envs_equal_their_shards():
         for o, s in zip(offs, shards):
             so, sr, st_, _, _ = s.step(a[o:o + 32])
             assert torch.equal(so, obs[o:o + 32]) and torch.equal(sr, rwd[o:o + 32]) and torch.equal(st_, term[o:o + 32]), (k, o)
-    assert env.batch.last_kernel_name() == "step_kernel_w<36,20,32,2,2,true,3,true>" and shards[0].batch.last_kernel_name() == "step_kernel_w<36,20,32,2,2,false,3,true>"
+    import os
+    if not (os.environ.get("MYO_NO_SPEC") or os.environ.get("MYO_SCHED")):     # default selection: scheduled full batch, one wave per env for the shards
+        assert env.batch.last_kernel_name() == "step_kernel_w<36,20,32,2,2,true,3,true>" and shards[0].batch.last_kernel_name() == "step_kernel_w<36,20,32,2,2,false,3,true>"
     assert int((env.status() & 16).sum()) == 0
