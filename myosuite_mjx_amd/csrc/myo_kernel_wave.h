@@ -998,7 +998,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
               if (((const int*)(E + Y.mprw))[4 * i] == p) { nw[0] = E[Y.mprw + 4 * i + 1]; nw[1] = E[Y.mprw + 4 * i + 2]; nw[2] = E[Y.mprw + 4 * i + 3]; have_nw = true; }
             }
             bool pen;
-            if constexpr (HF) pen = mpr_penetration_t<true>(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr);
+            if constexpr (HF) pen = mpr_penetration_wl<true>(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr, E + Y.cJ + 9 * lane);
             else pen = mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr);
             if (pen) {
               dist = margin - depth;

@@ -478,143 +478,141 @@ __device__ __forceinline__ void wl_swap(float* wl, int a, int b) {
 #pragma unroll
   for (int k = 0; k < 3; k++) { const float t = wl[3 * (a - 1) + k]; wl[3 * (a - 1) + k] = wl[3 * (b - 1) + k]; wl[3 * (b - 1) + k] = t; }
 }
-struct V3 { float v[3]; };
-__device__ __forceinline__ int expand_portal_v(V3* p, const float* v4) {
-  float va[3];
-  cross3(va, v4, p[0].v);
-  int idx;
-  if (dot3(p[1].v, va) > 0) idx = dot3(p[2].v, va) > 0 ? 1 : 3;
-  else idx = dot3(p[3].v, va) > 0 ? 2 : 1;
-#pragma unroll
-  for (int k = 0; k < 3; k++) { if (idx == 1) p[1].v[k] = v4[k]; else if (idx == 2) p[2].v[k] = v4[k]; else p[3].v[k] = v4[k]; }
-  return idx;
-}
-__device__ __forceinline__ void portal_dir_v(const V3* p, float* dir) {
-  float a[3] = {p[2].v[0] - p[1].v[0], p[2].v[1] - p[1].v[1], p[2].v[2] - p[1].v[2]};
-  float b[3] = {p[3].v[0] - p[1].v[0], p[3].v[1] - p[1].v[1], p[3].v[2] - p[1].v[2]};
-  cross3(dir, a, b);
-  normalize3(dir);
-}
+// (portal vertices as four separate 3-vectors and component-wise swaps: an array of structs copied with struct assignments stays an
+// addressable stack object -- memcpy between allocas -- and then lives in scratch memory instead of registers)
+#define V3SWAP(a, b) { float t0_ = a[0], t1_ = a[1], t2_ = a[2]; a[0] = b[0]; a[1] = b[1]; a[2] = b[2]; b[0] = t0_; b[1] = t1_; b[2] = t2_; }
+#define V3COPY(a, b) { a[0] = b[0]; a[1] = b[1]; a[2] = b[2]; }
+template <bool HF = false>
 __device__ __forceinline__ bool mpr_penetration_wl(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup,
-                                   const float* nwarm, float* wl) {
-  V3 p[4];
+                                                   const float* nwarm, float* wl) {
+  float p0[3], p1[3], p2[3], p3[3];
   Sup s;
   float dir[3], va[3], vb[3];
 #pragma unroll
-  for (int k = 0; k < 3; k++) p[0].v[k] = -o2.pos[k];
-  if (norm3(p[0].v) < MINVALF) p[0].v[0] += 1e-5f;
+  for (int k = 0; k < 3; k++) p0[k] = -o2.pos[k];
+  if (norm3(p0) < MINVALF) p0[0] += 1e-5f;
   bool warm_ok = false;
   if (nwarm) {
     float t1[3], t2[3];
     make_frame(nwarm, t1, t2);
     bool beyond = true;
 #pragma unroll
-    for (int k = 1; k <= 3; k++) {
-      const float c = k == 1 ? 1.f : -0.5f, sn = k == 1 ? 0.f : (k == 2 ? 0.8660254f : -0.8660254f);
+    for (int i = 0; i < 3; i++) dir[i] = nwarm[i] + MPR_WARM_EPS * t1[i];
+    normalize3(dir);
+    mink_support<HF>(o1, o2, dir, s);
+    V3COPY(p1, s.v); wl_set(wl, 1, s.v1);
+    beyond = beyond && dot3(s.v, dir) >= 0;
 #pragma unroll
-      for (int i = 0; i < 3; i++) dir[i] = nwarm[i] + MPR_WARM_EPS * (c * t1[i] + sn * t2[i]);
-      normalize3(dir);
-      mink_support<false>(o1, o2, dir, s);
+    for (int i = 0; i < 3; i++) dir[i] = nwarm[i] + MPR_WARM_EPS * (-0.5f * t1[i] + 0.8660254f * t2[i]);
+    normalize3(dir);
+    mink_support<HF>(o1, o2, dir, s);
+    V3COPY(p2, s.v); wl_set(wl, 2, s.v1);
+    beyond = beyond && dot3(s.v, dir) >= 0;
 #pragma unroll
-      for (int i = 0; i < 3; i++) p[k].v[i] = s.v[i];
-      wl_set(wl, k, s.v1);
-      beyond = beyond && dot3(s.v, dir) >= 0;
-    }
+    for (int i = 0; i < 3; i++) dir[i] = nwarm[i] + MPR_WARM_EPS * (-0.5f * t1[i] - 0.8660254f * t2[i]);
+    normalize3(dir);
+    mink_support<HF>(o1, o2, dir, s);
+    V3COPY(p3, s.v); wl_set(wl, 3, s.v1);
+    beyond = beyond && dot3(s.v, dir) >= 0;
     float s12, s23, s31;
-    cross3(va, p[1].v, p[2].v); s12 = dot3(va, p[0].v);
-    cross3(va, p[2].v, p[3].v); s23 = dot3(va, p[0].v);
-    cross3(va, p[3].v, p[1].v); s31 = dot3(va, p[0].v);
-    if (beyond && s12 >= 0 && s23 >= 0 && s31 >= 0) { V3 t = p[2]; p[2] = p[3]; p[3] = t; wl_swap(wl, 2, 3); warm_ok = true; }
+    cross3(va, p1, p2); s12 = dot3(va, p0);
+    cross3(va, p2, p3); s23 = dot3(va, p0);
+    cross3(va, p3, p1); s31 = dot3(va, p0);
+    if (beyond && s12 >= 0 && s23 >= 0 && s31 >= 0) { V3SWAP(p2, p3); wl_swap(wl, 2, 3); warm_ok = true; }
     else warm_ok = beyond && s12 <= 0 && s23 <= 0 && s31 <= 0;
   }
   if (!warm_ok) {
-    dir[0] = -p[0].v[0]; dir[1] = -p[0].v[1]; dir[2] = -p[0].v[2];
+    dir[0] = -p0[0]; dir[1] = -p0[1]; dir[2] = -p0[2];
     normalize3(dir);
-    mink_support<false>(o1, o2, dir, s);
-#pragma unroll
-    for (int i = 0; i < 3; i++) p[1].v[i] = s.v[i];
-    wl_set(wl, 1, s.v1);
-    if (dot3(p[1].v, dir) < 0) return false;
-    cross3(dir, p[0].v, p[1].v);
+    mink_support<HF>(o1, o2, dir, s);
+    V3COPY(p1, s.v); wl_set(wl, 1, s.v1);
+    if (dot3(p1, dir) < 0) return false;
+    cross3(dir, p0, p1);
     if (norm3(dir) < 1e-12f) {
-      *depth = norm3(p[1].v);
+      *depth = norm3(p1);
 #pragma unroll
-      for (int k = 0; k < 3; k++) { dirout[k] = p[1].v[k]; posout[k] = s.v1[k] - 0.5f * p[1].v[k]; }
+      for (int k = 0; k < 3; k++) { dirout[k] = p1[k]; posout[k] = s.v1[k] - 0.5f * p1[k]; }
       normalize3(dirout);
       return true;
     }
     normalize3(dir);
-    mink_support<false>(o1, o2, dir, s);
+    mink_support<HF>(o1, o2, dir, s);
+    V3COPY(p2, s.v); wl_set(wl, 2, s.v1);
+    if (dot3(p2, dir) < 0) return false;
 #pragma unroll
-    for (int i = 0; i < 3; i++) p[2].v[i] = s.v[i];
-    wl_set(wl, 2, s.v1);
-    if (dot3(p[2].v, dir) < 0) return false;
-#pragma unroll
-    for (int k = 0; k < 3; k++) { va[k] = p[1].v[k] - p[0].v[k]; vb[k] = p[2].v[k] - p[0].v[k]; }
+    for (int k = 0; k < 3; k++) { va[k] = p1[k] - p0[k]; vb[k] = p2[k] - p0[k]; }
     cross3(dir, va, vb);
     normalize3(dir);
-    if (dot3(dir, p[0].v) > 0) { V3 t = p[1]; p[1] = p[2]; p[2] = t; wl_swap(wl, 1, 2); dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
+    if (dot3(dir, p0) > 0) { V3SWAP(p1, p2); wl_swap(wl, 1, 2); dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
     for (int it = 0;; it++) {
       if (it > maxit) return false;
-      mink_support<false>(o1, o2, dir, s);
-#pragma unroll
-      for (int i = 0; i < 3; i++) p[3].v[i] = s.v[i];
-      wl_set(wl, 3, s.v1);
-      if (dot3(p[3].v, dir) < 0) return false;
+      mink_support<HF>(o1, o2, dir, s);
+      V3COPY(p3, s.v); wl_set(wl, 3, s.v1);
+      if (dot3(p3, dir) < 0) return false;
       bool cont = false;
-      cross3(va, p[1].v, p[3].v);
-      if (dot3(va, p[0].v) < -MINVALF) { p[2] = p[3]; wl_copy(wl, 2, 3); cont = true; }
+      cross3(va, p1, p3);
+      if (dot3(va, p0) < -MINVALF) { V3COPY(p2, p3); wl_copy(wl, 2, 3); cont = true; }
       if (!cont) {
-        cross3(va, p[3].v, p[2].v);
-        if (dot3(va, p[0].v) < -MINVALF) { p[1] = p[3]; wl_copy(wl, 1, 3); cont = true; }
+        cross3(va, p3, p2);
+        if (dot3(va, p0) < -MINVALF) { V3COPY(p1, p3); wl_copy(wl, 1, 3); cont = true; }
       }
       if (!cont) break;
 #pragma unroll
-      for (int k = 0; k < 3; k++) { va[k] = p[1].v[k] - p[0].v[k]; vb[k] = p[2].v[k] - p[0].v[k]; }
+      for (int k = 0; k < 3; k++) { va[k] = p1[k] - p0[k]; vb[k] = p2[k] - p0[k]; }
       cross3(dir, va, vb);
       normalize3(dir);
     }
   }
+#define PORTAL_DIR() { float a_[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, b_[3] = {p3[0] - p1[0], p3[1] - p1[1], p3[2] - p1[2]}; cross3(dir, a_, b_); normalize3(dir); }
+#define EXPAND_PORTAL() { \
+    float va_[3]; cross3(va_, s.v, p0); \
+    const int idx_ = dot3(p1, va_) > 0 ? (dot3(p2, va_) > 0 ? 1 : 3) : (dot3(p3, va_) > 0 ? 2 : 1); \
+    _Pragma("unroll") for (int k = 0; k < 3; k++) { p1[k] = idx_ == 1 ? s.v[k] : p1[k]; p2[k] = idx_ == 2 ? s.v[k] : p2[k]; p3[k] = idx_ == 3 ? s.v[k] : p3[k]; } \
+    wl_set(wl, idx_, s.v1); }
   for (int it = 0;; it++) {
     if (it > maxit) return false;
-    portal_dir_v(p, dir);
-    if (dot3(dir, p[1].v) >= 0) break;
-    mink_support<false>(o1, o2, dir, s);
+    PORTAL_DIR();
+    if (dot3(dir, p1) >= 0) break;
+    mink_support<HF>(o1, o2, dir, s);
     float dv4 = dot3(s.v, dir);
-    float dmin = fminf(fminf(dv4 - dot3(p[1].v, dir), dv4 - dot3(p[2].v, dir)), dv4 - dot3(p[3].v, dir));
+    float dmin = fminf(fminf(dv4 - dot3(p1, dir), dv4 - dot3(p2, dir)), dv4 - dot3(p3, dir));
     if (dv4 < 0 || dmin <= tol) return false;
-    wl_set(wl, expand_portal_v(p, s.v), s.v1);
+    EXPAND_PORTAL();
   }
   for (int it = 0;; it++) {
-    portal_dir_v(p, dir);
-    mink_support<false>(o1, o2, dir, s);
+    PORTAL_DIR();
+    mink_support<HF>(o1, o2, dir, s);
     float dv4 = dot3(s.v, dir);
-    float dmin = fminf(fminf(dv4 - dot3(p[1].v, dir), dv4 - dot3(p[2].v, dir)), dv4 - dot3(p[3].v, dir));
+    float dmin = fminf(fminf(dv4 - dot3(p1, dir), dv4 - dot3(p2, dir)), dv4 - dot3(p3, dir));
     if (dmin <= tol || it > maxit) { if (nsup) *nsup = it; break; }
-    wl_set(wl, expand_portal_v(p, s.v), s.v1);
+    EXPAND_PORTAL();
   }
+#undef PORTAL_DIR
+#undef EXPAND_PORTAL
   *depth = dot3(s.v, dir);
   float bw[4], cr[3];
-  cross3(cr, p[1].v, p[2].v); bw[0] = dot3(cr, p[3].v);
-  cross3(cr, p[3].v, p[2].v); bw[1] = dot3(cr, p[0].v);
-  cross3(cr, p[0].v, p[1].v); bw[2] = dot3(cr, p[3].v);
-  cross3(cr, p[2].v, p[1].v); bw[3] = dot3(cr, p[0].v);
+  cross3(cr, p1, p2); bw[0] = dot3(cr, p3);
+  cross3(cr, p3, p2); bw[1] = dot3(cr, p0);
+  cross3(cr, p0, p1); bw[2] = dot3(cr, p3);
+  cross3(cr, p2, p1); bw[3] = dot3(cr, p0);
   float sum = bw[0] + bw[1] + bw[2] + bw[3];
   if (sum <= 0) {
     bw[0] = 0;
-    cross3(cr, p[2].v, p[3].v); bw[1] = dot3(cr, dir);
-    cross3(cr, p[3].v, p[1].v); bw[2] = dot3(cr, dir);
-    cross3(cr, p[1].v, p[2].v); bw[3] = dot3(cr, dir);
+    cross3(cr, p2, p3); bw[1] = dot3(cr, dir);
+    cross3(cr, p3, p1); bw[2] = dot3(cr, dir);
+    cross3(cr, p1, p2); bw[3] = dot3(cr, dir);
     sum = bw[1] + bw[2] + bw[3];
   }
   float inv = 1.0f / sum;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     dirout[k] = dir[k];
-    posout[k] = inv * (bw[0] * (0.f - 0.5f * p[0].v[k]) + bw[1] * (wl[k] - 0.5f * p[1].v[k]) +
-                       bw[2] * (wl[3 + k] - 0.5f * p[2].v[k]) + bw[3] * (wl[6 + k] - 0.5f * p[3].v[k]));
+    posout[k] = inv * (bw[0] * (0.f - 0.5f * p0[k]) + bw[1] * (wl[k] - 0.5f * p1[k]) +
+                       bw[2] * (wl[3 + k] - 0.5f * p2[k]) + bw[3] * (wl[6 + k] - 0.5f * p3[k]));
   }
   return true;
 }
+#undef V3SWAP
+#undef V3COPY
 
 #endif  // MYO_PHYSICS_H
