@@ -315,9 +315,13 @@ __device__ void mink_support(const CObj& a, const CObj& b, const float* dir, Sup
     if (top) { d0 += dir[2] * a.mat[6]; d1 += dir[2] * a.mat[7]; d2 += dir[2] * a.mat[8]; }
     int best = d1 > d0 ? 1 : 0;
     if (d2 > fmaxf(d0, d1)) best = 2;
-    s.v1[0] = best == 0 ? a.mat[0] : (best == 1 ? a.mat[1] : a.mat[2]);
-    s.v1[1] = best == 0 ? a.mat[3] : (best == 1 ? a.mat[4] : a.mat[5]);
-    s.v1[2] = top ? (best == 0 ? a.mat[6] : (best == 1 ? a.mat[7] : a.mat[8])) : a.S[0];
+    // blend by 0/1 weights rather than selecting between struct fields: a select of two loads becomes a load from a selected address,
+    // and one dynamic address is enough to push the whole CObj into scratch memory
+    const float w0 = best == 0 ? 1.f : 0.f, w1 = best == 1 ? 1.f : 0.f, w2 = best == 2 ? 1.f : 0.f;
+    s.v1[0] = w0 * a.mat[0] + w1 * a.mat[1] + w2 * a.mat[2];
+    s.v1[1] = w0 * a.mat[3] + w1 * a.mat[4] + w2 * a.mat[5];
+    const float zt = w0 * a.mat[6] + w1 * a.mat[7] + w2 * a.mat[8];
+    s.v1[2] = top ? zt : a.S[0];
   } else
   support_local(a.S, a.h, dir, s.v1);
   matTvec(dl, b.mat, nd);
