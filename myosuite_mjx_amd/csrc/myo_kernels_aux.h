@@ -25,23 +25,40 @@ __global__ void __launch_bounds__(1024) balance_kernel(const int* __restrict__ d
   if (t < 256) hist[t] = 0;
   if (t == 0) cmax_s = 1;
   __syncthreads();
+  // costs of this thread's envs: read once (the first four stay in registers, a launch of 4096 envs has exactly four per thread)
+  int c4[4] = {0, 0, 0, 0};
   int cm = 1;
-  for (int e = t; e < B; e += 1024) cm = max(cm, diag[(size_t)e * 8 + 3]);
-  atomicMax(&cmax_s, cm);
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const int e = t + 1024 * k; if (e < B) { c4[k] = diag[(size_t)e * 8 + 3]; cm = max(cm, c4[k]); } }
+  for (int e = t + 4096; e < B; e += 1024) cm = max(cm, diag[(size_t)e * 8 + 3]);
+  for (int off = 32; off > 0; off >>= 1) cm = max(cm, __shfl_xor(cm, off));
+  if ((t & 63) == 0) atomicMax(&cmax_s, cm);
   __syncthreads();
-  const int cmax = cmax_s;
-  for (int e = t; e < B; e += 1024) atomicAdd(&hist[255 - min(255, (int)(255LL * diag[(size_t)e * 8 + 3] / cmax))], 1);   // bucket 0 = heaviest
+  const float sc = 255.0f / (float)cmax_s;
+#define BUCKET(c) (255 - min(255, (int)(sc * (float)(c))))     /* bucket 0 = heaviest */
+#pragma unroll
+  for (int k = 0; k < 4; k++) if (t + 1024 * k < B) atomicAdd(&hist[BUCKET(c4[k])], 1);
+  for (int e = t + 4096; e < B; e += 1024) atomicAdd(&hist[BUCKET(diag[(size_t)e * 8 + 3])], 1);
   __syncthreads();
-  if (t == 0) { int acc = 0; for (int k = 0; k < 256; k++) { start[k] = acc; acc += hist[k]; } }
-  __syncthreads();
-  for (int e = t; e < B; e += 1024) {
-    int b = 255 - min(255, (int)(255LL * diag[(size_t)e * 8 + 3] / cmax));
-    int r = atomicAdd(&start[b], 1);                       // rank by descending cost (ties in arbitrary order)
-    int q = r / nslot, i = r - q * nslot;
-    int wg = q * nslot + ((q & 1) ? nslot - 1 - i : i);    // snake: slot i gets ranks i, 2*nslot-1-i, 2*nslot+i, ...
-    int pr = prio_mode == 2 ? (q < 3 ? 3 - q : 0) : (prio_mode == 1 ? (q == 0 ? 1 : 0) : (prio_mode == 3 ? (q < 2 ? 1 : 0) : 0));
-    order[wg < B ? wg : r] = e | (pr << 28);   // env id + issue priority of its cost quartile
+  if (t < 64) {   // exclusive prefix sum of the 256 bins by one wave: 4 bins per lane, then a wave scan of the lane totals
+    const int h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+    int tot = h0 + h1 + h2 + h3, inc = tot;
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (t >= off) inc += v; }
+    const int base = inc - tot;
+    start[4 * t] = base; start[4 * t + 1] = base + h0; start[4 * t + 2] = base + h0 + h1; start[4 * t + 3] = base + h0 + h1 + h2;
   }
+  __syncthreads();
+  auto place = [&](int e, int c) {
+    const int r = atomicAdd(&start[BUCKET(c)], 1);          // rank by descending cost (ties in arbitrary order)
+    const int q = r / nslot, i = r - q * nslot;
+    const int wg = q * nslot + ((q & 1) ? nslot - 1 - i : i);   // snake: slot i gets ranks i, 2*nslot-1-i, 2*nslot+i, ...
+    const int pr = prio_mode == 2 ? (q < 3 ? 3 - q : 0) : (prio_mode == 1 ? (q == 0 ? 1 : 0) : (prio_mode == 3 ? (q < 2 ? 1 : 0) : 0));
+    order[wg < B ? wg : r] = e | (pr << 28);                 // env id + issue priority of its cost quartile
+  };
+#pragma unroll
+  for (int k = 0; k < 4; k++) if (t + 1024 * k < B) place(t + 1024 * k, c4[k]);
+  for (int e = t + 4096; e < B; e += 1024) place(e, diag[(size_t)e * 8 + 3]);
+#undef BUCKET
 }
 
 __global__ void random_action_kernel(float* action, int B, int nu, uint64_t seed, uint64_t step, int env_offset) {
