@@ -91,9 +91,10 @@ def save(root: dict, path: str) -> None:
             pickle.dump(root, f)
 
 
-def load(path: str) -> dict:
-    """Read back what `save` wrote (own files only: the pickle branch executes pickle.load and must not be pointed at files of
-    unknown origin; reference checkpoints are never read this way)."""
+def load(path: str, allow_pickle: bool = False) -> dict:
+    """Read back what `save` wrote.  `.npz` files are read with allow_pickle=False.  The pickle layout (what the reference's Trace.load
+    reads) is only opened when the caller passes allow_pickle=True, i.e. vouches that the file is one of its own: unpickling executes
+    code from the file, and files of unknown origin -- reference checkpoints included -- must never be read this way."""
     if path.endswith(".npz"):
         z = np.load(path, allow_pickle=False)
         name = str(z["__name__"])
@@ -104,6 +105,8 @@ def load(path: str) -> dict:
             g, k = key.split("/", 1)
             trials.setdefault(g, {})[k] = z[key]
         return {name: trials}
+    if not allow_pickle:
+        raise ValueError("trace.load: pass allow_pickle=True to read a pickle written by trace.save (never for files of unknown origin)")
     with open(path, "rb") as f:
         return pickle.load(f)
 

@@ -36,7 +36,10 @@ def test_save_load_roundtrip(tmp_path, ext):
     root = {"myoHandPoseRandom-v0_rollouts": trace.split_trials(_steps(5, 3), done)}
     p = str(tmp_path / f"t.{ext}")
     trace.save(root, p)
-    back = trace.load(p)
+    if ext == "pickle":
+        with pytest.raises(ValueError):
+            trace.load(p)
+    back = trace.load(p, allow_pickle=(ext == "pickle"))
     assert list(back) == list(root)                                # Trace.load takes the first key as the trace name (grouped_datasets.py:428-431)
     for g, grp in root["myoHandPoseRandom-v0_rollouts"].items():
         for k, v in grp.items():
@@ -66,7 +69,7 @@ def test_batched_rollout_to_trace_and_back(tmp_path):
         assert np.array_equal(g["rewards"], g["env_infos/rwd_dense"])
     p = str(tmp_path / "rollouts.pickle")
     trace.save(root, p)
-    back = trace.load(p)[name]
+    back = trace.load(p, allow_pickle=True)[name]
     # replay: put every env into its logged state at row 3 and apply the logged action -> the logged row 4 (solver warm start is not part of
     # the env state, as in the reference: agreement at solver-tolerance level)
     ok = [e for e in range(B) if lens[e] > 6]
