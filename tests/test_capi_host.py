@@ -113,3 +113,16 @@ def test_host_rng_twin_is_uniform():
     v = np.array([u01(7, a, 3) for a in range(4000)])
     assert 0 <= v.min() and v.max() < 1 and abs(v.mean() - 0.5) < 0.02 and abs(v.var() - 1 / 12) < 0.01
     assert u01(7, 5, 3) == u01(7, 5, 3) and u01(7, 5, 3) != u01(8, 5, 3)
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/myo_hip.h is the drop-in boundary: it must compile as C99 (no torch / C++ types in the signatures) and as C++."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "include/myo_hip.h"\nint main(void) { myo_task_config c; myo_walk_config w; myo_dims d; (void)c; (void)w; (void)d; return MYO_F_COUNT > 0 ? 0 : 1; }\n')
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", root, "-c", str(src), "-o", str(tmp_path / "a.o")])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", root, "-x", "c++", "-c", str(src), "-o", str(tmp_path / "b.o")])
