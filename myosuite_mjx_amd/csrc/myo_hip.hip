@@ -822,6 +822,13 @@ int myo_bench_rollout(myo_batch* b, int steps, int nsubsteps, uint64_t seed, int
     rc = launch_step(b, b->d_action, MYO_ACTMAP_MUSCLE_SIGMOID, nsubsteps, s);
     if (rc) return rc;
     HIPCHK(hipEventRecord(b->kev[2 * (base + i) + 1], s));
+    const int tk = b->task.task;
+    if ((mode & MYO_BENCH_OBS) && (mode & MYO_BENCH_AUTORESET) && max_episode_steps > 0 && (tk == MYO_TASK_POSE || tk == MYO_TASK_HOLD || tk == MYO_TASK_STAND)) {
+      // state-only observations: observation + auto-reset + first observation of the new episodes in ONE launch (post_kernel)
+      hipLaunchKernelGGL(post_kernel, dim3(b->db.B), dim3(64), 0, s, b->model->dm, b->db, b->task, b->model->nq, b->model->dm.qpos0, seed, b->env_offset, max_episode_steps);
+      HIPCHK(hipGetLastError());
+      continue;
+    }
     if ((mode & MYO_BENCH_OBS) && b->task.task != MYO_TASK_NONE && b->task.task != MYO_TASK_WALK) { rc = launch_obs(b, s); if (rc) return rc; }   // walk: fused into the step launch
     if ((mode & MYO_BENCH_AUTORESET) && max_episode_steps > 0) {
       rc = myo_autoreset(b, max_episode_steps, seed, stream); if (rc) return rc;

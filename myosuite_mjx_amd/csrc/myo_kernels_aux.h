@@ -126,12 +126,10 @@ __global__ void __launch_bounds__(POL_ENVS * POL_MAXW) policy_kernel(PolicyDev P
 // auto_max > 0: gym TimeLimit / done auto-reset (reset iff done or elapsed >= auto_max); else mask-driven reset.
 // One 64-lane workgroup per env: envs that are not reset leave after one test, the others write their rows coalesced
 // (one thread per env needed ~500 serialised scattered stores per reset: 27 ms for a full reset of 4096 leg envs)
-__global__ void __launch_bounds__(64) reset_kernel(DevBatch Bt, TaskDev T, int nq, int nv, int nu, const float* qpos0, const uint8_t* mask, uint64_t seed,
-                                                  int env_offset, int auto_max) {
-  const int e = blockIdx.x, lane = threadIdx.x;
-  if (e >= Bt.B) return;
-  if (auto_max > 0) { if (!(Bt.done[e] > 0.f || Bt.elapsed[e] >= auto_max)) return; }
-  else if (mask && !mask[e]) return;
+__device__ __forceinline__ bool reset_body(const DevBatch& Bt, const TaskDev& T, int nq, int nv, int nu, const float* qpos0, const uint8_t* mask, uint64_t seed,
+                                           int env_offset, int auto_max, const int e, const int lane) {
+  if (auto_max > 0) { if (!(Bt.done[e] > 0.f || Bt.elapsed[e] >= auto_max)) return false; }
+  else if (mask && !mask[e]) return false;
   seed += 0x632BE59BD9B4E019ull * (uint64_t)Bt.episode[e];  // a fresh RNG stream per (env, episode)
   __syncthreads();                                            // every lane has read done / elapsed / episode before lane 0 updates them
   if (lane == 0) { Bt.episode[e] += 1; Bt.elapsed[e] = 0; Bt.done[e] = 0.f; Bt.time[e] = 0; }
@@ -195,13 +193,16 @@ __global__ void __launch_bounds__(64) reset_kernel(DevBatch Bt, TaskDev T, int n
       }
     }
   }
+  return true;
+}
+__global__ void __launch_bounds__(64) reset_kernel(DevBatch Bt, TaskDev T, int nq, int nv, int nu, const float* qpos0, const uint8_t* mask, uint64_t seed,
+                                                  int env_offset, int auto_max) {
+  if ((int)blockIdx.x >= Bt.B) return;
+  reset_body(Bt, T, nq, nv, nu, qpos0, mask, seed, env_offset, auto_max, blockIdx.x, threadIdx.x);
 }
 
 // observation + reward (pose_v0.py:98-138, obs_vec_dict.py:86-98); one 64-lane workgroup per env, rows written coalesced
-__global__ void __launch_bounds__(64) obs_kernel(DevModel M, DevBatch Bt, TaskDev T, int obs_only, int reset_only) {
-  const int e = blockIdx.x, lane = threadIdx.x;
-  if (e >= Bt.B) return;
-  if (reset_only && Bt.elapsed[e] != 0) return;    // refresh only the rows of envs an auto-reset just touched
+__device__ __forceinline__ void obs_body(const DevModel& M, const DevBatch& Bt, const TaskDev& T, int obs_only, const int e, const int lane) {
   const int nv = M.nv, nu = M.nu;
   float dt = (float)T.frame_skip * M.timestep;
   float* o = Bt.obs + (size_t)e * T.obs_dim;
@@ -279,6 +280,25 @@ __global__ void __launch_bounds__(64) obs_kernel(DevModel M, DevBatch Bt, TaskDe
       Bt.solved[e] = dist < T.near_th ? 1.f : 0.f;
       Bt.done[e] = drop;
     }
+  }
+}
+__global__ void __launch_bounds__(64) obs_kernel(DevModel M, DevBatch Bt, TaskDev T, int obs_only, int reset_only) {
+  const int e = blockIdx.x;
+  if (e >= Bt.B) return;
+  if (reset_only && Bt.elapsed[e] != 0) return;    // refresh only the rows of envs an auto-reset just touched
+  obs_body(M, Bt, T, obs_only, e, threadIdx.x);
+}
+// observation / reward / done of the stepped state, gym TimeLimit + done auto-reset, and the first observation of the new episode for the
+// envs that were reset: the three launches of the per-step epilogue (obs_kernel, reset_kernel, obs_kernel(reset_only)) in one -- on
+// the critical path between two step kernels every launch costs a few microseconds of dispatch gap
+__global__ void __launch_bounds__(64) post_kernel(DevModel M, DevBatch Bt, TaskDev T, int nq, const float* qpos0, uint64_t seed, int env_offset, int auto_max) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (e >= Bt.B) return;
+  obs_body(M, Bt, T, 0, e, lane);
+  __syncthreads();                       // reward / done of this env written (lane 0) before every lane tests them
+  if (reset_body(Bt, T, nq, M.nv, M.nu, qpos0, nullptr, seed, env_offset, auto_max, e, lane)) {
+    __syncthreads();                     // the new state rows are complete before they are read back
+    obs_body(M, Bt, T, 1, e, lane);
   }
 }
 

@@ -276,3 +276,28 @@ def test_bench_two_rank_rehearsal():
     assert d["value"] > 0 and abs(d["value"] - 1024 * 10 / (d["ms_per_step"] * 10 / 1e3)) < 1e-6 * d["value"]
     assert d["roofline"]["kernel"].startswith("step_kernel_w<24,8,32,1,4," + ("true" if os.environ.get("MYO_SCHED") == "1" else "false")) and "cpu_baseline" not in d and "rehearsal" in d
     assert d["allgather_ms_rank0"] > 0 and d["allgather_bytes_out"] == 1024 * 108 * 4          # gather time reported separately
+
+
+@pytest.mark.parametrize("env_id", ["myoHandPoseRandom-v0", "myoHandObjHoldFixed-v0"])
+def test_fused_epilogue_equals_the_three_launches(env_id):
+    """myo_bench_rollout's per-step epilogue for state-only tasks is one launch (post_kernel: observation + reward + done, TimeLimit / done
+    auto-reset, first observation of the new episodes); it must leave exactly what the separate calls myo_obs, myo_autoreset,
+    myo_obs_reset_only leave -- state, observation, episode counters -- over episodes that end by time limit and by done."""
+    from myosuite_mjx_amd import capi
+    B, K, seed, tl = 256, 60, 5, 25
+    a = _make(env_id, B, seed=3, as_torch=False)
+    m = _make(env_id, B, seed=3, as_torch=False)
+    for e in (a, m):
+        e.reset(seed=3)
+    mode = capi.BENCH_OBS | capi.BENCH_FRESH_ACTIONS | capi.BENCH_AUTORESET
+    a.batch.bench_rollout(K, a.frame_skip, seed, mode, tl)
+    act_ptr = m.batch.field_ptr(capi.F_ACTION)[0]
+    for k in range(K):
+        m.batch.random_action(act_ptr, seed, k)
+        m.batch.step(act_ptr, capi.ACTMAP_MUSCLE_SIGMOID, m.frame_skip)
+        m.batch.obs()
+        m.batch.autoreset(tl, seed)
+        m.batch.obs_reset_only()
+    for f in (capi.F_QPOS, capi.F_QVEL, capi.F_ACT, capi.F_TIME, capi.F_TARGET, capi.F_OBS, capi.F_ELAPSED):
+        assert np.array_equal(a.batch.read(f), m.batch.read(f)), f
+    assert a.batch.read(capi.F_ELAPSED).max() < tl and a.batch.read(capi.F_ELAPSED).min() >= 0
