@@ -145,7 +145,10 @@ __device__ __forceinline__ float straight_w(const DevModel& M, const LayW& Y, fl
   float dist = norm3(dif);
   float inv = dist > MINVALF ? 1.0f / dist : 0.f;
   dif[0] *= inv; dif[1] *= inv; dif[2] *= inv;
-  for (int k = 0; k < n; k++) {
+  // a lane that does not keep this piece (wrapping segment vs direct piece, or the reverse) runs zero iterations: the wave's trip count is
+  // the longest dof list among the lanes that DO keep it, and zero when none does
+  const int nn = active ? n : 0;
+  for (int k = 0; k < nn; k++) {
     const int* e = M.dl + 3 * (adr + k);
     int d = e[0];
     const float* ax = E + Y.axis + 3 * d;
@@ -156,7 +159,7 @@ __device__ __forceinline__ float straight_w(const DevModel& M, const LayW& Y, fl
       cross3(c, ax, r);
       col = dot3(dif, c);
     } else col = dot3(dif, ax);
-    if (active) atomicAdd(&Jt[e[2]], (float)e[1] * col * invdiv);
+    atomicAdd(&Jt[e[2]], (float)e[1] * col * invdiv);
   }
   return active ? dist * invdiv : 0.f;
 }
