@@ -76,6 +76,7 @@ typedef struct {
   int neq, *eq_obj1id, *eq_obj2id;
   real *eq_data, *eq_solref, *eq_solimp;
   int disable_contact, disable_limit, disable_ellipsoid; /* test switches */
+  int disable_passive, disable_gravity, disable_actuation; /* mjDSBL_PASSIVE / GRAVITY / ACTUATION, used by the length-range simulation */
   void* storage[256];
   int nstorage;
 } Model;
@@ -99,7 +100,7 @@ typedef struct {
   /* velocity stage */
   real *cvel, *cdof_dot, *ten_velocity, *actuator_velocity, *qfrc_bias, *qfrc_passive;
   /* acceleration stage */
-  real *actuator_force, *act_dot, *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qfrc_constraint, *qacc;
+  real *actuator_force, *act_dot, *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qfrc_constraint, *qacc, *qfrc_applied;
   /* constraints */
   int nefc, nefc_max;
   int *efc_type, *efc_id, *efc_state;
@@ -281,7 +282,7 @@ Data* myoo_make_data(const Model* m) {
   AL(cvel, 6 * nb); AL(cdof_dot, 6 * nv); AL(ten_velocity, m->ntendon); AL(actuator_velocity, m->nu);
   AL(qfrc_bias, nv); AL(qfrc_passive, nv);
   AL(actuator_force, m->nu); AL(act_dot, m->na); AL(qfrc_actuator, nv); AL(qfrc_smooth, nv); AL(qacc_smooth, nv);
-  AL(qfrc_constraint, nv); AL(qacc, nv);
+  AL(qfrc_constraint, nv); AL(qacc, nv); AL(qfrc_applied, nv);
   d->nefc_max = m->neq + 2 * m->njnt + 2 * m->ntendon + 6 * NCON_MAX;
   int ne = d->nefc_max;
   d->efc_type = (int*)calloc(ne, sizeof(int)); d->efc_id = (int*)calloc(ne, sizeof(int));
@@ -324,7 +325,7 @@ void myoo_free_data(Data* d) {
   free(d->ten_length); free(d->ten_J); free(d->qM); free(d->qLD); free(d->qLDiagInv); free(d->actuator_length);
   free(d->actuator_moment); free(d->cvel); free(d->cdof_dot); free(d->ten_velocity); free(d->actuator_velocity);
   free(d->qfrc_bias); free(d->qfrc_passive); free(d->actuator_force); free(d->act_dot); free(d->qfrc_actuator);
-  free(d->qfrc_smooth); free(d->qacc_smooth); free(d->qfrc_constraint); free(d->qacc); free(d->efc_type);
+  free(d->qfrc_smooth); free(d->qacc_smooth); free(d->qfrc_constraint); free(d->qacc); free(d->qfrc_applied); free(d->efc_type);
   free(d->efc_id); free(d->efc_state); free(d->efc_J); free(d->efc_pos); free(d->efc_margin);
   free(d->efc_diagApprox); free(d->efc_R); free(d->efc_D); free(d->efc_aref); free(d->efc_vel); free(d->efc_force);
   free(d->efc_b); free(d->wk);
@@ -337,6 +338,7 @@ void myoo_reset(const Model* m, Data* d) { /* mj_resetData: robot.py:976 -> sim_
   memset(d->act, 0, m->na * sizeof(real));
   memset(d->ctrl, 0, m->nu * sizeof(real));
   memset(d->qacc_warmstart, 0, m->nv * sizeof(real));
+  memset(d->qfrc_applied, 0, m->nv * sizeof(real));
   d->time = 0;
 }
 
@@ -1532,6 +1534,7 @@ static void com_vel(const Model* m, Data* d) { /* mj_comVel [3P] */
 
 static void passive(const Model* m, Data* d) { /* mj_passive: joint springs + dampers, tendon springs + dampers */
   int nv = m->nv;
+  if (m->disable_passive) { memset(d->qfrc_passive, 0, nv * sizeof(real)); return; }
   for (int i = 0; i < nv; i++) d->qfrc_passive[i] = -m->dof_damping[i] * d->qvel[i];
   for (int j = 0; j < m->njnt; j++) {
     if (m->jnt_stiffness[j] == 0) continue;
@@ -1552,7 +1555,7 @@ static void rne(const Model* m, Data* d) { /* mj_rne with flg_acc = 0 [3P] */
   real* cacc = d->wk;           /* 6*nb */
   real* cfrc = d->wk + 6 * nb;  /* 6*nb */
   cacc[0] = cacc[1] = cacc[2] = 0;
-  for (int k = 0; k < 3; k++) cacc[3 + k] = -m->gravity[k];
+  for (int k = 0; k < 3; k++) cacc[3 + k] = m->disable_gravity ? 0 : -m->gravity[k];
   memset(cfrc, 0, 6 * sizeof(real));
   for (int i = 1; i < nb; i++) {
     memcpy(cacc + 6 * i, cacc + 6 * m->body_parentid[i], 6 * sizeof(real));
@@ -1661,6 +1664,7 @@ static void fwd_velocity(const Model* m, Data* d) {
 static void fwd_actuation(const Model* m, Data* d) { /* mj_fwdActuation, muscle actuators */
   int nv = m->nv;
   memset(d->qfrc_actuator, 0, nv * sizeof(real));
+  if (m->disable_actuation) { memset(d->actuator_force, 0, m->nu * sizeof(real)); memset(d->act_dot, 0, m->na * sizeof(real)); return; }
   for (int i = 0; i < m->nu; i++) {
     real ctrl = d->ctrl[i];
     if (m->actuator_ctrllimited[i]) ctrl = clipr(ctrl, m->actuator_ctrlrange[2 * i], m->actuator_ctrlrange[2 * i + 1]);
@@ -1690,7 +1694,7 @@ static void fwd_actuation(const Model* m, Data* d) { /* mj_fwdActuation, muscle 
 
 static void fwd_acceleration(const Model* m, Data* d) {
   for (int i = 0; i < m->nv; i++) {
-    d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i];
+    d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i] + d->qfrc_applied[i];
     d->qacc_smooth[i] = d->qfrc_smooth[i];
   }
   solve_ld(m, d->qacc_smooth, d->qLD, d->qLDiagInv);
@@ -1970,6 +1974,68 @@ int myoo_step(const Model* m, Data* d, int nsub) {
     if (r) return r;
   }
   return 0;
+}
+
+/* ------------------------------------------------------------------ muscle length ranges: mj_setLengthRange / evalAct [3P]
+ * MuJoCo's compiler computes `lengthrange` by simulating the model with contacts, passive forces, gravity and actuation disabled while a
+ * force of fixed acceleration magnitude pulls along the actuator's moment arm (side 0: shorten, side 1: lengthen), velocities damped by
+ * exp(-dt / timeconst) per step; the range is the min (max) length over the last `interval` seconds of `inttotal`.  Defaults (mjLROpt):
+ * accel 20, maxforce 0, timeconst 1, timestep 0.01, inttotal 10, interval 2, tolrange 0.05.  The reference's model files store the numbers
+ * MuJoCo produced this way (myohand_assets.xml:501-539, myolegs_assets.xml:606-685): restating the procedure on top of this oracle's own
+ * position / velocity / constraint / Euler stages turns every stored pair into a golden vector for those stages (tests/test_oracle.py).
+ * out = {range lo, range hi, spread of side 0 over the interval, spread of side 1}; returns 0, or 1 if the state went bad. */
+int myoo_lengthrange(Model* m, Data* d, int actuator, double accel, double maxforce, double timeconst, double timestep,
+                     double inttotal, double interval, double* out) {
+  int nv = m->nv, rc = 0;
+  real save_dt = m->timestep;
+  int sc = m->disable_contact, sp = m->disable_passive, sg = m->disable_gravity, sa = m->disable_actuation;
+  m->timestep = (real)timestep;
+  m->disable_contact = m->disable_passive = m->disable_gravity = m->disable_actuation = 1;
+  real* moment = (real*)calloc(nv, sizeof(real));
+  real* tmp = (real*)calloc(nv, sizeof(real));
+  for (int side = 0; side < 2 && !rc; side++) {
+    myoo_reset(m, d);
+    real lmin = 0, lmax = 0;
+    int updated = 0;
+    while (d->time < inttotal) {
+      myoo_fwd_position(m, d);
+      fwd_velocity(m, d);
+      memcpy(moment, d->actuator_moment + (size_t)actuator * nv, nv * sizeof(real));
+      memcpy(tmp, moment, nv * sizeof(real));
+      solve_ld(m, tmp, d->qLD, d->qLDiagInv);
+      real nrm = 0;
+      for (int i = 0; i < nv; i++) nrm += tmp[i] * moment[i];
+      nrm = sqrt(nrm);
+      real scl = (real)(2 * side - 1) * (real)accel / maxr(MINVAL, nrm);
+      for (int i = 0; i < nv; i++) d->qfrc_applied[i] = scl * moment[i];
+      if (maxforce > 0) {
+        real fn = 0;
+        for (int i = 0; i < nv; i++) fn += d->qfrc_applied[i] * d->qfrc_applied[i];
+        fn = sqrt(fn);
+        if (fn > maxforce) for (int i = 0; i < nv; i++) d->qfrc_applied[i] *= (real)maxforce / fn;
+      }
+      fwd_actuation(m, d);
+      fwd_acceleration(m, d);
+      fwd_constraint(m, d);
+      if (is_bad(d->qacc, nv)) { rc = 1; break; }
+      euler(m, d);
+      real damp = exp(-(real)timestep / maxr((real)0.01, (real)timeconst));
+      for (int i = 0; i < nv; i++) d->qvel[i] *= damp;
+      real len = d->actuator_length[actuator];
+      if (d->time > inttotal - interval) {
+        if (len < lmin || !updated) lmin = len;
+        if (len > lmax || !updated) lmax = len;
+        updated = 1;
+      }
+    }
+    out[side] = (double)(side == 0 ? lmin : lmax);
+    out[2 + side] = (double)(lmax - lmin);
+  }
+  free(moment); free(tmp);
+  m->timestep = save_dt;
+  m->disable_contact = sc; m->disable_passive = sp; m->disable_gravity = sg; m->disable_actuation = sa;
+  myoo_reset(m, d);
+  return rc;
 }
 
 /* ------------------------------------------------------------------ field access for tests */

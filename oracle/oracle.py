@@ -50,6 +50,8 @@ class Oracle:
         L.myoo_set_switch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.myoo_set_hfield.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.myoo_set_geom_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        L.myoo_lengthrange.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_double] * 6 + [C.POINTER(C.c_double)]
+        L.myoo_lengthrange.restype = C.c_int
         L.myoo_step_batch.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]
         self.real = np.float32 if L.myoo_sizeof_real() == 4 else np.float64
         self._blob = blob
@@ -138,6 +140,15 @@ class Oracle:
         out = (C.c_double * 2)()
         self.lib.myoo_energy(self.m, self.d, out)
         return out[0], out[1]
+
+    def lengthrange(self, actuator, accel=20.0, maxforce=0.0, timeconst=1.0, timestep=0.01, inttotal=10.0, interval=2.0):
+        """MuJoCo's compile-time length-range simulation (mj_setLengthRange, default mjLROpt) for one actuator:
+        returns (lo, hi, spread_lo, spread_hi).  Resets the data."""
+        out = (C.c_double * 4)()
+        rc = self.lib.myoo_lengthrange(self.m, self.d, int(actuator), accel, maxforce, timeconst, timestep, inttotal, interval, out)
+        if rc:
+            raise RuntimeError("length-range simulation went unstable")
+        return tuple(out)
 
     def step_batch(self, qpos, qvel, act, warm, time, ctrl, nsub, nthreads):
         """In-place batched stepping of env-major float64 arrays [B, n] (CPU baseline driver)."""
