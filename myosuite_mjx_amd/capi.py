@@ -115,6 +115,7 @@ def lib():
         L.myo_bench_rollout.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
         L.myo_bench_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.myo_batch_set_geom_override.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.myo_probe_valu.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.myo_bench_last_kernel_name.argtypes = [C.c_void_p]
         L.myo_bench_last_kernel_name.restype = C.c_char_p
         L.myo_obs_only.argtypes = [C.c_void_p, C.c_void_p]
@@ -318,3 +319,10 @@ def read_stamps(batch, nwg):
 
 def sync(stream=None):
     _chk(lib().myo_sync(stream))
+
+
+def probe_valu(waves_per_simd, iters=20000, device=0):
+    """Measured chip-wide issue rate of wave64 v_fma_f32 (instructions / s) with `waves_per_simd` waves resident per SIMD, and the CU count."""
+    r, n = C.c_double(0), C.c_int(0)
+    _chk(lib().myo_probe_valu(int(device), int(waves_per_simd), int(iters), C.byref(r), C.byref(n)))
+    return r.value, n.value

@@ -83,7 +83,14 @@ struct DevBatch {
   float* hfield;           // [B][nrow * ncol] height-field elevation per env (terrain models; NULL otherwise)
   float* gsize;            // [B][4] per-env size (3) + bounding radius of ONE collision geom (ObjHoldRandomEnvV0 re-draws the object's size); NULL: none
   int gsize_cg;            // its collision-geom index
+  // overflow of the LDS contact table (wave kernel): contacts NC .. NC + NCX - 1 of an env keep their point / normal / jacobian rows in
+  // HBM (L2-resident in practice; touched by ~0.4 % of myoHandPoseRandom reset poses), candidates beyond NCAND their pair ids
+  float* ovf;              // [B][NCX][ovf_row] floats: dist, pos[3], normal[3], pair id, cJ[3 * KC], dof ids (byte-packed)
+  int* ovf_cand;           // [B][NCANDX]
+  int ovf_row;             // floats per overflow row (0: no overflow storage, the LDS table is the capacity)
 };
+#define NCX 32      // overflow contact rows per env: 64 contacts in all, one per lane of the wave
+#define NCANDX 256  // overflow candidates per env (MyoHand has 289 pairs: NCAND + NCANDX covers every pair)
 
 struct TaskDev {
   int task, frame_skip, reset_random, target_generate, ntarget, ntip, obs_dim, nq;

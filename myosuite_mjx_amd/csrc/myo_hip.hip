@@ -348,6 +348,12 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   BA(b->d_action, (size_t)B * nu)
   BA(d.fatigue, (size_t)B * 3 * nu)
   d.hfield = nullptr; d.gsize = nullptr; d.gsize_cg = -1;
+  d.ovf = nullptr; d.ovf_cand = nullptr; d.ovf_row = 0;
+  if (m->wave_ok) {   // contact-table overflow rows of the wave kernel (instantiations <24,8,...> and <36,20,...>)
+    const int kc = nv > 24 ? 20 : 8;
+    d.ovf_row = 8 + 3 * kc + (kc + 3) / 4;
+    BA(d.ovf, (size_t)B * NCX * d.ovf_row) BA(d.ovf_cand, (size_t)B * NCANDX)
+  }
   if (m->dw.hf.on) { BA(d.hfield, (size_t)B * m->dw.hf.nrow * m->dw.hf.ncol) }   // zero-filled: flat terrain at the geom's height
   BA(b->d_initv, nv)
   { void* pw = nullptr; if ((rc = balloc(b, &pw, sizeof(DevWalk)))) { myo_batch_free(b); return rc; } b->d_walk = (DevWalk*)pw; }
@@ -848,6 +854,34 @@ int myo_bench_rollout(myo_batch* b, int steps, int nsubsteps, uint64_t seed, int
 /* total HIP-event milliseconds spent in the step kernel launches of the last synchronous myo_bench_rollout call, or -- after
  * asynchronous calls (ms_out == NULL) -- of all launches enqueued since the last collection (waits for them) */
 const char* myo_bench_last_kernel_name(const myo_batch* b) { return b ? b->last_kernel : ""; }
+
+/* measured VALU issue peak of the device at `waves_per_simd` resident waves per SIMD (1, 2, 4 or 8): wave64 v_fma_f32 instructions per second,
+ * chip-wide.  One workgroup of 4 * waves_per_simd waves per CU (the LDS request keeps a second workgroup off the CU). */
+int myo_probe_valu(int device, int waves_per_simd, int iters, double* wave_insts_per_s, int* n_cu_out) {
+  if (!wave_insts_per_s || waves_per_simd < 1 || waves_per_simd > 4 || iters < 1) return fail(MYO_E_ARG, "myo_probe_valu: waves_per_simd must be 1..4 (x2 workgroups per CU for 8)");
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  const int ncu = prop.multiProcessorCount;
+  const size_t lds = 60 * 1024;   // with 160 KB per CU at most two such workgroups fit: grid = ncu keeps it to one in practice, 2 * ncu gives 8 waves / SIMD
+  HIPCHK(hipFuncSetAttribute((const void*)valu_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  float* out = nullptr;
+  const int threads = 256 * waves_per_simd;
+  HIPCHK(hipMalloc(&out, (size_t)2 * ncu * threads * 4));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(valu_probe_kernel, dim3(ncu), dim3(threads), lds, 0, out, iters / 8 + 1, 1.0f);   // warm-up (clocks, code cache)
+  HIPCHK(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(valu_probe_kernel, dim3(ncu), dim3(threads), lds, 0, out, iters, 1.0f);
+  HIPCHK(hipEventRecord(e1, 0));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipFree(out); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *wave_insts_per_s = (double)ncu * 4.0 * waves_per_simd * (double)iters * 256.0 / ((double)ms * 1e-3);
+  if (n_cu_out) *n_cu_out = ncu;
+  return MYO_OK;
+}
 
 int myo_bench_last_kernel_ms(myo_batch* b, float* ms_out) {
   if (!b || !ms_out) return fail(MYO_E_ARG, "null");

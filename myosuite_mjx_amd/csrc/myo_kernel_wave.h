@@ -56,6 +56,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 #define WFOR(i, n) for (int i = lane; i < (n); i += 64)
 // dof id k (0..KC-1) of contact c from the byte-packed table (CDW = ints per contact, a constexpr of the kernel)
 #define CDOF(E_, Y_, c_, k_) ((int)((((const unsigned int*)((E_) + (Y_).cdofs))[CDW * (c_) + ((k_) >> 2)] >> (8 * ((k_) & 3))) & 255u))
+// same from a pointer to the contact's own packed words (LDS row or HBM overflow row)
+#define CDOFP(W_, k_) ((int)(((W_)[(k_) >> 2] >> (8 * ((k_) & 3))) & 255u))
 
 // in: r[k] = H[lane][k] (k <= lane). out: r[k] = L[lane][k], returns 1/L[lane][lane].  All indices are compile-time.
 template <int NVT> __device__ __forceinline__ float chol_rows(float (&r)[NVT], int lane) {
@@ -370,6 +372,13 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   constexpr bool OVR = FULL && SPEC == 0 && !HF;
   auto cgsz = [&](int g) -> const float* { return (OVR && Bt.gsize && g == Bt.gsize_cg) ? (const float*)(Bt.gsize + 4 * (size_t)env) : M.cg_size + 3 * g; };
   auto cgrb = [&](int g) -> float { return (OVR && Bt.gsize && g == Bt.gsize_cg) ? Bt.gsize[4 * (size_t)env + 3] : M.cg_rbound[g]; };
+  // contacts NC .. NC + NCX - 1 live in this env's HBM overflow rows [dist, pos3, normal3, pair, cJ[3 KC], dof words]; lane = contact still holds
+  // for all 64.  The first NC contacts (all of them for > 99.5 % of the states) never leave LDS.
+  static_assert(NC + NCX <= 64, "one lane per contact");
+  float* const ovf_env = Bt.ovf ? Bt.ovf + (size_t)env * NCX * Bt.ovf_row : nullptr;
+  const int ovf_row = Bt.ovf_row;
+  const int nct = ovf_env ? NC + NCX : NC;
+  int* const ovf_cand = (!HF && Bt.ovf_cand) ? Bt.ovf_cand + (size_t)env * NCANDX : nullptr;
   bool alive = true;
   int n_mprw = 0;   // MPR warm-start table (pair id + last contact normal in geom 1's frame): entries of the previous substep
   if (SCHED && s0 > 0) {   // ... which another wave ran: the table travels through the batch like the state rows, so that a scheduled
@@ -856,7 +865,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         }
         unsigned long long bal = __ballot(hit);
         int pos = ncand + __popcll(bal & ((1ull << lane) - 1ull));
-        if (hit && pos < NCAND) cand[pos] = p;
+        if (hit) { if (pos < NCAND) cand[pos] = p; else if (ovf_cand && pos < NCAND + NCANDX) ovf_cand[pos - NCAND] = p; }
         ncand += __popcll(bal);
         if (HF) {   // height-field pairs expand into one candidate per prism, appended in pair order
           unsigned long long hb = __ballot(nh > 0);
@@ -870,7 +879,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           if (nh > 0) hf_walk(W.hf, Bt.hfield + (size_t)env * W.hf.nrow * W.hf.ncol, hr0, hr1, hc0, hc1, hzcut, p, cand, myat, NCAND);
         }
       }
-      if (ncand > NCAND) { flags |= MYO_FLAG_CAND_OVERFLOW; ncand = NCAND; }
+      { const int candcap = ovf_cand ? NCAND + NCANDX : NCAND; if (ncand > candcap) { flags |= MYO_FLAG_CAND_OVERFLOW; ncand = candcap; } }
       f_cand += ncand;
       int n_mprw_new = 0;
       SYNC();
@@ -884,7 +893,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         float dist = 0, dist2 = 0, cpos[3] = {0, 0, 0}, cpos2[3] = {0, 0, 0}, nrm[3] = {1, 0, 0};
         int p = -1;
         if (ci < ncand) {
-          const int cw = cand[ci];
+          const int cw = (ci < NCAND) ? cand[ci] : ovf_cand[ci - NCAND];
           p = HF ? (cw & 1023) : cw;
           const int* P = M.pair_i + 6 * p;
           int g1 = P[0], g2 = P[1];
@@ -1085,6 +1094,12 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
 #pragma unroll
           for (int k = 0; k < 3; k++) { E[Y.cpos + 3 * pos + k] = cpos[k]; E[Y.cnrm + 3 * pos + k] = nrm[k]; }
           ((int*)(E + Y.cpair))[pos] = p;
+        } else if (hit && pos < nct) {
+          float* g = ovf_env + (pos - NC) * ovf_row;
+          g[0] = dist;
+#pragma unroll
+          for (int k = 0; k < 3; k++) { g[1 + k] = cpos[k]; g[4 + k] = nrm[k]; }
+          ((int*)g)[7] = p;
         }
         ncon += __popcll(bal);
         bal = FULL ? __ballot(hit2) : 0ull;
@@ -1095,11 +1110,17 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
 #pragma unroll
             for (int k = 0; k < 3; k++) { E[Y.cpos + 3 * pos + k] = cpos2[k]; E[Y.cnrm + 3 * pos + k] = nrm[k]; }
             ((int*)(E + Y.cpair))[pos] = p;
+          } else if (hit2 && pos < nct) {
+            float* g = ovf_env + (pos - NC) * ovf_row;
+            g[0] = dist2;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { g[1 + k] = cpos2[k]; g[4 + k] = nrm[k]; }
+            ((int*)g)[7] = p;
           }
           ncon += __popcll(bal);
         }
       }
-      if (ncon > NC) { flags |= MYO_FLAG_CONTACT_OVERFLOW; ncon = NC; }
+      if (ncon > nct) { flags |= MYO_FLAG_CONTACT_OVERFLOW; ncon = nct; }
       n_mprw = n_mprw_new;
       SYNC();
     } else n_mprw = 0;
@@ -1124,13 +1145,13 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     }
     float caref[4] = {0, 0, 0, 0}, cD = 0.f, cmu = 0.f;
     int ckc = 0;
-    if (lane < ncon) {
-      int c = lane;
-      int p = ((const int*)(E + Y.cpair))[c];
+    // (generic lambda: instantiated once with LDS pointers and once with the HBM overflow row, so that each copy keeps its own address space)
+    auto build_row = [&](const float* pdist, const float* ppos, const float* pnrm, const int* ppair, float* cJ, unsigned int* cdw) {
+      int p = ppair[0];
       const int* P = M.pair_i + 6 * p;
       const float* F = M.pair_f + 12 * p;
-      float n[3] = {E[Y.cnrm + 3 * c], E[Y.cnrm + 3 * c + 1], E[Y.cnrm + 3 * c + 2]}, t1[3], t2[3];
-      float cp[3] = {E[Y.cpos + 3 * c], E[Y.cpos + 3 * c + 1], E[Y.cpos + 3 * c + 2]};
+      float n[3] = {pnrm[0], pnrm[1], pnrm[2]}, t1[3], t2[3];
+      float cp[3] = {ppos[0], ppos[1], ppos[2]};
       make_frame(n, t1, t2);
       if (FULL && P[4] == 2) {   // plane - capsule: first tangent along the capsule axis (MuJoCo's frame for this pair type)
         const float* ax = E + Y.gax + 3 * P[1];
@@ -1143,7 +1164,6 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         }
       }
       float vn = 0, vt1 = 0, vt2 = 0;
-      float* cJ = E + Y.cJ + c * 3 * KC;
       unsigned int dpk[CDW];
 #pragma unroll
       for (int k = 0; k < CDW; k++) dpk[k] = 0;
@@ -1169,8 +1189,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         dpk[k >> 2] |= (unsigned int)d << (8 * (k & 3));   // padded entries: zero jacobian, dof 0
       }
 #pragma unroll
-      for (int k = 0; k < CDW; k++) ((unsigned int*)(E + Y.cdofs))[CDW * c + k] = dpk[k];
-      float dist = E[Y.cdist + c], incl = F[0] - F[1];
+      for (int k = 0; k < CDW; k++) cdw[k] = dpk[k];
+      float dist = pdist[0], incl = F[0] - F[1];
       cmu = F[2];
       float imp = impedance(F + 6, dist, incl), K, B;
       kbi(F[4], F[5], F[7], M.timestep, &K, &B);
@@ -1185,6 +1205,11 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       float pos = -K * imp * (dist - incl);
       caref[0] = -B * (vn + cmu * vt1) + pos; caref[1] = -B * (vn - cmu * vt1) + pos;
       caref[2] = -B * (vn + cmu * vt2) + pos; caref[3] = -B * (vn - cmu * vt2) + pos;
+    };
+    if (lane < ncon) {
+      if (lane < NC) build_row(E + Y.cdist + lane, E + Y.cpos + 3 * lane, E + Y.cnrm + 3 * lane, (const int*)(E + Y.cpair) + lane, E + Y.cJ + lane * 3 * KC,
+                               (unsigned int*)(E + Y.cdofs) + CDW * lane);
+      else { float* g = ovf_env + (lane - NC) * ovf_row; build_row(g, g + 1, g + 4, (const int*)g + 7, g + 8, (unsigned int*)(g + 8 + 3 * KC)); }
     }
     // efc row count as MuJoCo reports it: 4 pyramid rows per condim-3 contact, 1 per frictionless (condim-1) contact
     int nefc = __popcll(__ballot(lsign != 0.f)) + 4 * ncon - 3 * __popcll(__ballot(lane < ncon && cmu == 0.f));
@@ -1236,7 +1261,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       }
       nt += __popcll(bal);
       }
-      if (nt > NC) { flags |= MYO_FLAG_CONTACT_OVERFLOW; nt = NC; }
+      if (nt > NC) { flags |= MYO_FLAG_CONTACT_OVERFLOW; nt = NC; if (ncon > NC) ncon = NC; }   // (tendon-limit rows use LDS slots only: the models that have them have < 10 geoms)
       SYNC();
       if (lane >= ncon && lane < nt) {
         float a = E[Y.cdist + lane];
@@ -1288,12 +1313,15 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       ljar = lsign * qacc - laref;
       if (lane < nv) E[Y.xv + lane] = qacc;
       SYNC();
-      if (lane < ncon) {
-        const float* cJ = E + Y.cJ + lane * 3 * KC;
+      auto row_jar = [&](const float* cJ, const unsigned int* cdw) {
         float an = 0, a1 = 0, a2 = 0;
 #pragma unroll
-        for (int k = 0; k < KC; k++) { float xv = E[Y.xv + CDOF(E, Y, lane, k)]; an += cJ[k] * xv; a1 += cJ[KC + k] * xv; a2 += cJ[2 * KC + k] * xv; }
+        for (int k = 0; k < KC; k++) { float xv = E[Y.xv + CDOFP(cdw, k)]; an += cJ[k] * xv; a1 += cJ[KC + k] * xv; a2 += cJ[2 * KC + k] * xv; }
         cjar[0] = an + cmu * a1 - caref[0]; cjar[1] = an - cmu * a1 - caref[1]; cjar[2] = an + cmu * a2 - caref[2]; cjar[3] = an - cmu * a2 - caref[3];
+      };
+      if (lane < ncon) {
+        if (lane < NC) row_jar(E + Y.cJ + lane * 3 * KC, (const unsigned int*)(E + Y.cdofs) + CDW * lane);
+        else { const float* g = ovf_env + (lane - NC) * ovf_row; row_jar(g + 8, (const unsigned int*)(g + 8 + 3 * KC)); }
       }
       if (eact) ejar = E[Y.xv + ed1] + eJ2 * E[Y.xv + ed2] - earef;
     }
@@ -1315,9 +1343,15 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         if (lane < nv) E[Y.qfc + lane] = lact ? -lsign * lD * ljar : 0.f;
         SYNC();
         if (lane < ncon) {
-          const float* cJ = E + Y.cJ + lane * 3 * KC;
           float Fn = f0 + f1 + f2 + f3, Ft1 = cmu * (f0 - f1), Ft2 = cmu * (f2 - f3);
-          for (int k = 0; k < ckc; k++) atomicAdd(&E[Y.qfc + CDOF(E, Y, lane, k)], Fn * cJ[k] + Ft1 * cJ[KC + k] + Ft2 * cJ[2 * KC + k]);
+          if (lane < NC) {
+            const float* cJ = E + Y.cJ + lane * 3 * KC;
+            for (int k = 0; k < ckc; k++) atomicAdd(&E[Y.qfc + CDOF(E, Y, lane, k)], Fn * cJ[k] + Ft1 * cJ[KC + k] + Ft2 * cJ[2 * KC + k]);
+          } else {
+            const float* cJ = ovf_env + (lane - NC) * ovf_row + 8;
+            const unsigned int* cdw = (const unsigned int*)(cJ + 3 * KC);
+            for (int k = 0; k < ckc; k++) atomicAdd(&E[Y.qfc + CDOFP(cdw, k)], Fn * cJ[k] + Ft1 * cJ[KC + k] + Ft2 * cJ[2 * KC + k]);
+          }
         }
         if (eact) { float f = -eD * ejar; atomicAdd(&E[Y.qfc + ed1], f); atomicAdd(&E[Y.qfc + ed2], eJ2 * f); }
         SYNC();
@@ -1357,15 +1391,18 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
               int kc = rdlanei(ckc, c);
               float sW = rdlane(Wn, c), sA1 = rdlane(A1, c), sA2 = rdlane(A2, c), sB1 = rdlane(B1, c), sB2 = rdlane(B2, c);
               if (sW == 0.f) continue;
-              for (int t = lane; t < kc * kc; t += 64) {
-                int a = t / kc, b = t - a * kc;
-                const float* cJ = E + Y.cJ + c * 3 * KC;
-                int da = CDOF(E, Y, c, a), db = CDOF(E, Y, c, b);
-                if (da >= db) {
-                  float na = cJ[a], nb = cJ[b], ta = cJ[KC + a], tb = cJ[KC + b], ua = cJ[2 * KC + a], ub = cJ[2 * KC + b];
-                  atomicAdd(&E[Y.sq + da * (NVT + 1) + db], sW * na * nb + sA1 * (na * tb + ta * nb) + sA2 * (na * ub + ua * nb) + sB1 * ta * tb + sB2 * ua * ub);
+              auto hblock = [&](const float* cJ, const unsigned int* cdw) {
+                for (int t = lane; t < kc * kc; t += 64) {
+                  int a = t / kc, b = t - a * kc;
+                  int da = CDOFP(cdw, a), db = CDOFP(cdw, b);
+                  if (da >= db) {
+                    float na = cJ[a], nb = cJ[b], ta = cJ[KC + a], tb = cJ[KC + b], ua = cJ[2 * KC + a], ub = cJ[2 * KC + b];
+                    atomicAdd(&E[Y.sq + da * (NVT + 1) + db], sW * na * nb + sA1 * (na * tb + ta * nb) + sA2 * (na * ub + ua * nb) + sB1 * ta * tb + sB2 * ua * ub);
+                  }
                 }
-              }
+              };
+              if (c < NC) hblock(E + Y.cJ + c * 3 * KC, (const unsigned int*)(E + Y.cdofs) + CDW * c);
+              else { const float* g = ovf_env + (c - NC) * ovf_row; hblock(g + 8, (const unsigned int*)(g + 8 + 3 * KC)); }
             }
             if (eact) {
               atomicAdd(&E[Y.sq + ed1 * (NVT + 1) + ed1], eD);
@@ -1414,12 +1451,15 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       ljv = lsign * search;
       if (lane < nv) E[Y.xv + lane] = search;
       SYNC();
-      if (lane < ncon) {
-        const float* cJ = E + Y.cJ + lane * 3 * KC;
+      auto row_jv = [&](const float* cJ, const unsigned int* cdw) {
         float an = 0, a1 = 0, a2 = 0;
 #pragma unroll
-        for (int k = 0; k < KC; k++) { float xv = E[Y.xv + CDOF(E, Y, lane, k)]; an += cJ[k] * xv; a1 += cJ[KC + k] * xv; a2 += cJ[2 * KC + k] * xv; }
+        for (int k = 0; k < KC; k++) { float xv = E[Y.xv + CDOFP(cdw, k)]; an += cJ[k] * xv; a1 += cJ[KC + k] * xv; a2 += cJ[2 * KC + k] * xv; }
         cjv[0] = an + cmu * a1; cjv[1] = an - cmu * a1; cjv[2] = an + cmu * a2; cjv[3] = an - cmu * a2;
+      };
+      if (lane < ncon) {
+        if (lane < NC) row_jv(E + Y.cJ + lane * 3 * KC, (const unsigned int*)(E + Y.cdofs) + CDW * lane);
+        else { const float* g = ovf_env + (lane - NC) * ovf_row; row_jv(g + 8, (const unsigned int*)(g + 8 + 3 * KC)); }
       }
       if (eact) ejv = E[Y.xv + ed1] + eJ2 * E[Y.xv + ed2];
       float g1 = wave_sum(search * (Ma - smooth)), g2 = wave_sum(0.5f * search * Mv), sn = sqrtf(wave_sum(search * search));

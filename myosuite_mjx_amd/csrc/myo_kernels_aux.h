@@ -352,4 +352,24 @@ __global__ void __launch_bounds__(64) reach_obs_kernel(DevModel M, DevBatch Bt, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// VALU issue-rate probe (bench.py roofline): every wave runs `iters` x 256 independent v_fma_f32 (8 accumulator chains, so that a wave's
+// own dependent-issue latency is not the limit), with W waves resident on every SIMD (workgroup = 4 W waves, one workgroup per CU forced
+// by its LDS request).  wave-instructions / elapsed time = what the chip's VALUs can issue at that occupancy, at the clock the chip
+// actually holds under this load.
+__global__ void __launch_bounds__(1024) valu_probe_kernel(float* out, int iters, float seed) {
+  extern __shared__ float lds_dummy[];
+  float a0 = seed, a1 = seed + 1.f, a2 = seed + 2.f, a3 = seed + 3.f, a4 = seed + 4.f, a5 = seed + 5.f, a6 = seed + 6.f, a7 = seed + 7.f;
+  const float m = 1.0000001f, c = 1e-9f * (float)threadIdx.x;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int u = 0; u < 32; u++) {
+      asm volatile("v_fma_f32 %0, %0, %8, %9\n\tv_fma_f32 %1, %1, %8, %9\n\tv_fma_f32 %2, %2, %8, %9\n\tv_fma_f32 %3, %3, %8, %9\n\t"
+                   "v_fma_f32 %4, %4, %8, %9\n\tv_fma_f32 %5, %5, %8, %9\n\tv_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %8, %9"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+    }
+  }
+  if (out) out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)) + (threadIdx.x == 4096 ? lds_dummy[0] : 0.f);
+}
+
 #endif  // MYO_KERNELS_AUX_H

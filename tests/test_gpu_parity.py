@@ -34,10 +34,14 @@ def _run_pair(hand, hm, oracle, qpos, qvel, act, ctrl, nsub, switches, lanes=64)
     g["flags"] = b.status()
     r = {k: np.zeros_like(g[k], dtype=np.float64) for k in ("qpos", "qvel", "act", "qacc", "tenlen", "force")}
     r["ncon"] = np.zeros(N, int)
+    r["ncon_sum"] = np.zeros(N, int)          # contacts summed over the substeps: the env's contact HISTORY (HIP: diag word 4, high half)
+    g["ncon_sum"] = g["diag"][:, 4] >> 16
     for e in range(N):
         oracle.reset()
         oracle.set_state(qpos=qpos[e], qvel=qvel[e], act=act[e], ctrl=ctrl[e])
-        oracle.step(nsub)
+        for _ in range(nsub):
+            oracle.step(1)
+            r["ncon_sum"][e] += oracle.ncon
         for k, f in (("qpos", "qpos"), ("qvel", "qvel"), ("act", "act"), ("qacc", "qacc"), ("tenlen", "actuator_length"), ("force", "actuator_force")):
             r[k][e] = oracle.field(f)
         r["ncon"][e] = oracle.ncon
@@ -82,20 +86,66 @@ def test_joint_limits_newton(hand, hipmodel, oracle64, nsub, tq, tv):
 @pytest.mark.parametrize("switches,nsub,tq,tv", [((0, 0, 1), 1, 5e-6, 2e-3), ((0, 0, 1), 10, 5e-5, 5e-3),
                                                  ((0, 0, 0), 1, 2e-5, 1e-2), ((0, 0, 0), 10, 1e-4, 2e-2)])
 def test_contacts(hand, hipmodel, oracle64, switches, nsub, tq, tv):
-    """capsule-capsule (analytic) and, with switches (0,0,0), ellipsoid pads (margin-inflated MPR)."""
-    g, r = _run_pair(hand, hipmodel, oracle64, *_states(hand, 256, 13), nsub, switches)
-    same = (g["flags"] == 0) & (g["diag"][:, 1] == r["ncon"])
+    """capsule-capsule (analytic) and, with switches (0,0,0), ellipsoid pads (margin-inflated MPR).  N = 1024.
+    Strict bounds on the envs whose contact HISTORY (count in every substep) agrees with the oracle's.  A contact that crosses its margin
+    one substep earlier in float than in double switches its damping term on one substep earlier (measured: 12 vs 11 contacts in substep 4
+    of one env in 1024 => 5e-4 rad after the env step, tools/gpu_parity_probe.py).  Those envs
+    are not dropped from the test: no env may be flagged, every env obeys a looser bound, and the 99th percentile over ALL envs obeys the
+    strict one."""
+    g, r = _run_pair(hand, hipmodel, oracle64, *_states(hand, 1024, 13), nsub, switches)
+    assert (g["flags"] == 0).all()
+    same = (g["diag"][:, 1] == r["ncon"]) & (g["ncon_sum"] == r["ncon_sum"])
     assert same.mean() > 0.97, same.mean()
     assert r["ncon"][same].max() >= 8                              # the sample really has contacts
-    assert np.abs(g["qpos"] - r["qpos"])[same].max() < tq
-    assert np.abs(g["qvel"] - r["qvel"])[same].max() < tv
+    eq, ev = np.abs(g["qpos"] - r["qpos"]).max(1), np.abs(g["qvel"] - r["qvel"]).max(1)
+    assert eq[same].max() < tq and ev[same].max() < tv
+    assert eq.max() < 5e-3 and ev.max() < 1.0, (eq.max(), ev.max())        # all envs, the count-mismatch ones included
+    assert np.percentile(eq, 99) < tq and np.percentile(ev, 99) < tv
+
+
+def _crowded_states(hand, oracle, n, seed, lo_count=33):
+    """myoHandPoseRandom-v0 reset states (every joint uniform over its range, pose_v0.py:246-251; qvel = 0, act = 0) that start with more
+    than 32 contacts -- 0.4 % of the draws; found with the oracle's collision stage."""
+    rng = np.random.default_rng(seed)
+    lo, hi = hand.jnt_range[:, 0], hand.jnt_range[:, 1]
+    out, cnt = [], []
+    while len(out) < n:
+        q = rng.uniform(lo, hi).astype(np.float32)
+        oracle.reset()
+        oracle.set_state(qpos=q)
+        oracle.fwd_position()
+        if oracle.ncon >= lo_count:
+            out.append(q)
+            cnt.append(oracle.ncon)
+    return np.stack(out), np.array(cnt)
+
+
+@pytest.mark.parametrize("nsub,tq,tv", [(1, 2e-5, 1e-2), (10, 5e-4, 5e-2)])
+def test_more_than_32_contacts(hand, hipmodel, oracle64, nsub, tq, tv):
+    """contacts 33..64 of an env live in HBM overflow rows of the wave kernel instead of being dropped.  States with
+    33..54 simultaneous contacts (up to 216 pyramid rows), HIP vs oracle: same contact count, no flag, same state after one substep and
+    after one env step.  (The float32 BUILD of the oracle is off by 1.1e-4 / 1e-2 on these states after ten substeps.)"""
+    qpos, cnt = _crowded_states(hand, oracle64, 48, 2026)
+    assert cnt.min() >= 33 and cnt.max() >= 50
+    N = len(qpos)
+    z = np.zeros((N, hand.nv), np.float32)
+    act, ctrl = np.zeros((N, hand.nu), np.float32), np.full((N, hand.nu), 0.5, np.float32)
+    g, r = _run_pair(hand, hipmodel, oracle64, qpos, z, act, ctrl, nsub, (0, 0, 0))
+    assert (g["flags"] == 0).all()
+    if nsub == 1:
+        assert (g["diag"][:, 1] == cnt).all() and (r["ncon"] == cnt).all()          # all 33..54 contacts are in the solve
+    eq, ev = np.abs(g["qpos"] - r["qpos"]).max(1), np.abs(g["qvel"] - r["qvel"]).max(1)
+    assert eq.max() < tq and ev.max() < tv, (eq.max(), ev.max())
+    assert np.median(eq) < 0.1 * tq
 
 
 @pytest.mark.parametrize("lanes", [16, 32])
 def test_lanes_per_env_variants_agree(hand, hipmodel, oracle64, lanes):
     g, r = _run_pair(hand, hipmodel, oracle64, *_states(hand, 96, 14), 10, (0, 0, 0), lanes=lanes)
-    same = (g["flags"] == 0) & (g["diag"][:, 1] == r["ncon"])
+    assert (g["flags"] == 0).all()
+    same = g["diag"][:, 1] == r["ncon"]
     assert same.mean() > 0.95
+    assert np.abs(g["qpos"] - r["qpos"]).max() < 5e-3
     assert np.abs(g["qpos"] - r["qpos"])[same].max() < 1e-4 and np.abs(g["qvel"] - r["qvel"])[same].max() < 2e-2
 
 
@@ -110,8 +160,10 @@ def test_golden_fixture(hand, hipmodel):
             b.write(f, G[k])
         b.step(None, capi.ACTMAP_NONE, nsub)
         d = b.read(capi.F_DIAG)
-        ok = (b.status() == 0) & ((d[:, 1] == G["meta"][:, 1]) | (nsub > 1))
-        assert ok.mean() > 0.9
+        assert (b.status() == 0).all()
+        ok = (d[:, 1] == G["meta"][:, 1]) | (nsub > 1)
+        assert ok.mean() > 0.97
+        assert np.abs(b.read(capi.F_QPOS) - G["qpos" + sfx]).max() < 5e-3      # every state of the fixture, count mismatches included
         assert np.abs(b.read(capi.F_QPOS) - G["qpos" + sfx])[ok].max() < tq
         assert np.abs(b.read(capi.F_QVEL) - G["qvel" + sfx])[ok].max() < tv
         assert np.abs(b.read(capi.F_ACT) - G["act" + sfx])[ok].max() < 1e-6
