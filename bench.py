@@ -21,11 +21,25 @@ sys.path.insert(0, ROOT)
 B_PER_GPU = 4096
 ENV_ID = "myoHandPoseRandom-v0"
 B_ALG = 1560.0          # algorithmic HBM bytes per env-step, MyoHand pose
-F_ALG_EST = 1.2e6       # flop per env-step: SURVEY.md 8d ESTIMATE (1.0-1.5 Mflop), not an instrumented count
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md
 FP32_PEAK_TFLOPS = 157.3
 N_SIMD = 256 * 4        # MI355X_MICROARCH.md: 256 CUs, 4 SIMDs each
 CLOCK_HZ = 2.4e9        # max engine clock
+VALU_CYCLES = 2.0       # MI355X_MICROARCH.md: a wave64 v_fma_f32 issues over 2 cycles on a SIMD-32 (4 for one wave alone)
+PMC_FILE = "profiles/r2_pmc_step_kernel_hand.json"      # committed rocprofv3 counters of the headline kernel (tools/prof_all.sh)
+FLOP_FILE = "profiles/r2_flops_oracle.json"             # committed flop count of the oracle's instrumented build (tools/count_flops.py)
+
+
+def flops_per_env_step(env_id):
+    """Algorithmic flop per env step: the count emitted by the oracle's instrumented build on this workload."""
+    try:
+        with open(os.path.join(ROOT, FLOP_FILE)) as f:
+            for r in json.load(f):
+                if r["env"] == env_id:
+                    return r["per_env_step"]["total"]
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(seconds_target=12.0):
@@ -173,13 +187,20 @@ def main():
     traffic = None
     valu_insts = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_f_pmc_step_kernel_hand.json")) as f:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
             pmc = json.load(f)
         if B == B_PER_GPU and env_id == ENV_ID:
             traffic = pmc["traffic"]["hbm_bytes_per_launch_raw"]
             valu_insts = pmc["counters"]["SQ_INSTS_VALU"]["mean_per_launch"]
     except Exception:
         pass
+    # measured VALU issue peak of THIS chip at the step kernel's occupancy (4 waves per SIMD): a 20 ms v_fma_f32 probe after the timed region
+    valu_peak = None
+    if rank == 0:
+        try:
+            valu_peak = capi.probe_valu(4, 20000, local)[0]
+        except Exception:
+            valu_peak = None
     if rank == 0:
         value = world * B * args.steps / el
         mm = env.mjmodel
@@ -188,6 +209,7 @@ def main():
         # (state + action read once, state + observation + reward/done written once; L-walk: 3 412 B)
         b_alg = B_ALG if env_id == ENV_ID else 4.0 * ((mm.nq + 2 * mm.nv + 2 * mm.nu + 1) + (mm.nq + 2 * mm.nv + mm.nu + 1) + env.obs_dim + 2)
         achieved = b_alg * B / (k_ms * 1e-3) / 1e9
+        f_alg = flops_per_env_step(env_id)
         out = {
             "metric": f"env-steps/s (whole node) {env_id} batch {B}", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
@@ -200,15 +222,21 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": env.batch.last_kernel_name(), "kernel_ms": k_ms,
                          "alg_bytes_per_launch": b_alg * B,
-                         "note": "path is FP32-VALU/latency bound, not HBM bound (SURVEY.md 8d); fp32 view alongside",
-                         "fp32": {"achieved_tflops_est": F_ALG_EST * B / (k_ms * 1e-3) / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
-                                  "frac_est": F_ALG_EST * B / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "flop_per_env_step": "SURVEY 8d estimate"},
-                         # the resource that actually binds this kernel: VALU issue slots (one wave64 VALU instruction per SIMD per 4 cycles).
-                         # instruction count = committed rocprofv3 SQ_INSTS_VALU of the same kernel / batch, time = this run's kernel time
+                         "note": "path is FP32-VALU / latency bound, not HBM bound (SURVEY.md 8d); fp32 and VALU-issue views alongside",
+                         "traffic_source": None if traffic is None else f"committed rocprofv3 profile {PMC_FILE} (separate FETCH_SIZE / WRITE_SIZE passes), not measured in this run",
+                         "fp32": None if f_alg is None else {
+                             "achieved_tflops": f_alg * B / (k_ms * 1e-3) / 1e12, "peak_tflops": FP32_PEAK_TFLOPS,
+                             "frac": f_alg * B / (k_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, "flop_per_env_step": f_alg,
+                             "flop_source": f"oracle instrumented build, {FLOP_FILE}"},
+                         # VALU issue slots: instruction count = committed rocprofv3 SQ_INSTS_VALU of the same kernel / batch; time = this run's
+                         # kernel time; peak = the v_fma_f32 issue rate measured on this chip in this run at 4 waves per SIMD (guide: 2 cycles per
+                         # wave64 instruction => 1 229 G/s at 2.4 GHz; the chip holds a lower clock under an all-VALU load)
                          "valu_issue": None if valu_insts is None else {
-                             "wave_insts_per_launch": valu_insts, "peak_wave_insts_per_s": N_SIMD * CLOCK_HZ / 4.0,
-                             "frac": valu_insts / (k_ms * 1e-3) / (N_SIMD * CLOCK_HZ / 4.0),
-                             "note": "share of the chip's VALU issue slots used over the whole launch (256 CUs x 4 SIMDs, 2.4 GHz)"}},
+                             "wave_insts_per_launch": valu_insts, "insts_source": f"committed rocprofv3 profile {PMC_FILE}",
+                             "peak_wave_insts_per_s": valu_peak if valu_peak else N_SIMD * CLOCK_HZ / VALU_CYCLES,
+                             "peak_source": "measured in this run: myo_probe_valu, 4 waves per SIMD" if valu_peak else "guide: 1024 SIMDs x 2.4 GHz / 2 cycles",
+                             "peak_guide": N_SIMD * CLOCK_HZ / VALU_CYCLES,
+                             "frac": valu_insts / (k_ms * 1e-3) / (valu_peak if valu_peak else N_SIMD * CLOCK_HZ / VALU_CYCLES)}},
             "event_ms_per_step_rank0": ev_ms / args.steps,
             **({"repeats": len(runs), "value_per_repeat": [world * B * args.steps / r[0] for r in runs]} if len(runs) > 1 else {}),
             **({"allgather_ms_rank0": gather_ms, "allgather_bytes_out": int(gathered.numel() * 4)} if gather_ms is not None else {}),

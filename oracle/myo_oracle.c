@@ -25,7 +25,11 @@
 #include <stdlib.h>
 #include <string.h>
 
-#ifdef MYOO_FLOAT
+#if defined(MYOO_COUNT_FLOPS)      /* instrumented C++ build (make flops): `real` counts its own arithmetic, see flopcount.h */
+#include "flopcount.h"
+thread_local FlopCounters g_flops;
+extern "C" {
+#elif defined(MYOO_FLOAT)
 typedef float real;
 #else
 typedef double real;
@@ -2063,8 +2067,8 @@ int myoo_solver_iter(const Data* d) { return d->solver_iter; }
 int myoo_warning(const Data* d) { return d->warning; }
 void myoo_contact(const Data* d, int i, double* out /* dist,pos3,normal3,geom1,geom2 */) {
   const Contact* c = &d->con[i];
-  out[0] = c->dist;
-  for (int k = 0; k < 3; k++) { out[1 + k] = c->pos[k]; out[4 + k] = c->frame[k]; }
+  out[0] = (double)c->dist;
+  for (int k = 0; k < 3; k++) { out[1 + k] = (double)c->pos[k]; out[4 + k] = (double)c->frame[k]; }
   out[7] = c->geom1; out[8] = c->geom2;
 }
 /* dense mass matrix for tests */
@@ -2132,3 +2136,12 @@ void myoo_step_batch(const Model* m, int B, double* qpos, double* qvel, double* 
   }
   for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
 }
+
+#if defined(MYOO_COUNT_FLOPS)
+/* counters of the calling thread: add, mul, div, sqrt, special; reset = 1 clears them after the read */
+void myoo_flops(uint64_t* out, int reset) {
+  out[0] = g_flops.add; out[1] = g_flops.mul; out[2] = g_flops.div; out[3] = g_flops.sqrt_; out[4] = g_flops.special;
+  if (reset) memset(&g_flops, 0, sizeof(g_flops));
+}
+}  /* extern "C" */
+#endif

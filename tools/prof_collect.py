@@ -35,5 +35,11 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     res["traffic"] = dict(FETCH_SIZE_KB_per_launch=fk, WRITE_SIZE_KB_per_launch=wk, hbm_bytes_per_launch_raw=(fk + wk) * 1024,
                           hbm_bytes_per_launch_fetch_x2=(2 * fk + wk) * 1024, algorithmic_bytes_per_launch=alg_bytes,
                           note="separate --pmc passes; KB units; fetch x2 = guide's gfx950 correction for wide coalesced reads, an upper bound here")
+# derived: share of the 64 lanes that are active in the VALU instructions the kernel issues (rocprof's "VALUUtilization":
+# SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64)), and the kernel's VALU instructions per second against the measured issue peak
+if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c and c["SQ_ACTIVE_INST_VALU"]["mean_per_launch"] > 0:
+    res["valu_active_lane_fraction"] = c["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]["mean_per_launch"])
+if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
+    res["wave_cycles_waiting_fraction"] = c["SQ_WAIT_ANY"]["mean_per_launch"] / c["SQ_WAVE_CYCLES"]["mean_per_launch"]
 json.dump(res, open(out_path, "w"), indent=1)
 print(json.dumps(res.get("traffic", {})), [k["name"][:40] + f" {k['avg_us']:.1f}us x{k['calls']}" for k in res.get("kernel_stats", [])[:3]])
