@@ -245,8 +245,10 @@ class CompiledModel:
 
 # --------------------------------------------------------------------------- the compiler
 class _Compiler:
-    def __init__(self, path, terrain=False):
+    def __init__(self, path, terrain=False, replace=None, convex_meshes=False):
         self.path = os.path.abspath(path)
+        self.replace = dict(replace or {})   # text substitutions applied to every file read (TrackEnv: OBJECT_NAME -> "airplane", mjx/myodm_v0.py:66-80)
+        self.convex_meshes = convex_meshes   # colliding mesh geoms carry the vertices of their convex hull (MuJoCo collides meshes as convex hulls)
         self.terrain = terrain      # True: keep the height field's pairs and raise its geom to z = 0 (TerrainEnvV0.reset, walk_v0.py:624-630)
         self.hfields = {}
         self.comp = dict(angle="degree", eulerseq="xyz", inertiafromgeom="auto", balanceinertia=False,
@@ -271,8 +273,17 @@ class _Compiler:
         self.keys = []
 
     # ---- XML loading with <include>
+    def _parse(self, path):
+        if not self.replace:
+            return ET.parse(path).getroot()
+        with open(path) as f:
+            txt = f.read()
+        for k, v in self.replace.items():
+            txt = txt.replace(k, v)
+        return ET.fromstring(txt)
+
     def _load(self, path):
-        root = ET.parse(path).getroot()
+        root = self._parse(path)
         self._expand(root, os.path.dirname(path))
         return root
 
@@ -283,7 +294,7 @@ class _Compiler:
         for ch in children:
             if ch.tag == "include":
                 p = os.path.normpath(os.path.join(base, ch.attrib["file"]))
-                sub = ET.parse(p).getroot()
+                sub = self._parse(p)
                 self._expand(sub, os.path.dirname(p))
                 for s in list(sub):
                     s.set("__dir", s.get("__dir", os.path.dirname(p)))
@@ -407,6 +418,10 @@ class _Compiler:
             tris = _read_stl(p) * m["scale"][None, None, :]
             m["props"] = mesh_mass_properties(tris)
             m["rmax"] = float(np.linalg.norm(tris.reshape(-1, 3), axis=1).max())   # sphere about the mesh origin containing it
+            if self.convex_meshes:
+                from scipy.spatial import ConvexHull
+                v = np.unique(tris.reshape(-1, 3), axis=0)
+                m["hull"] = v[np.sort(ConvexHull(v).vertices)]
         return m["props"]
 
     def _do_body(self, e, parent, childclass):
@@ -465,8 +480,8 @@ class _Compiler:
                          solref=_floats(at.get("solreflimit", "0.02 1"), 2),
                          solimp=_solimp(at.get("solimplimit")),
                          frictionloss=float(at.get("frictionloss", 0)))
-                if j["frictionloss"] != 0:
-                    raise NotImplementedError("joint frictionloss")
+                j["solref_fri"] = _floats(at.get("solreffriction", "0.02 1"), 2)
+                j["solimp_fri"] = _solimp(at.get("solimpfriction"))
                 self.joints.append(j)
                 b["jnts"].append(len(self.joints) - 1)
             elif t == "geom":
@@ -838,6 +853,9 @@ class _Compiler:
         A["qpos0"], A["qpos_spring"] = qpos0, qspring
         A["dof_bodyid"], A["dof_jntid"] = dof_bodyid, dof_jntid
         A["dof_armature"], A["dof_damping"] = dof_armature, dof_damping
+        A["dof_frictionloss"] = np.array([self.joints[dof_jntid[d]]["frictionloss"] for d in range(nv)])
+        A["dof_solref_fri"] = np.stack([self.joints[dof_jntid[d]]["solref_fri"] for d in range(nv)]) if nv else np.zeros((0, 2))
+        A["dof_solimp_fri"] = np.stack([self.joints[dof_jntid[d]]["solimp_fri"] for d in range(nv)]) if nv else np.zeros((0, 5))
         # dof parent: previous dof in the same body, else last dof of nearest ancestor with dofs
         dof_parent = np.full(nv, -1, np.int32)
         for d in range(nv):
@@ -878,6 +896,15 @@ class _Compiler:
                     self.geoms[i]["size"] = np.array([self.meshes[self.geoms[i]["mesh"]]["rmax"], 0.0, 0.0])
                 else:
                     keep.remove(i)
+        # convex_meshes: a colliding mesh geom is its convex hull (vertex list in the geom frame; support = best vertex)
+        mesh_vert, mesh_adr = [], {}
+        if self.convex_meshes:
+            for i in keep:
+                g = self.geoms[i]
+                if g["type"] == GEOM_MESH and g["mesh"] not in mesh_adr:
+                    h = self.meshes[g["mesh"]]["hull"]
+                    mesh_adr[g["mesh"]] = (sum(len(x) for x in mesh_vert), len(h))
+                    mesh_vert.append(h)
         # explicit pairs may name geoms that neither collide dynamically nor wrap: keep them too
         pair_names = {pr[k] for pr in self.pairs for k in ("geom1", "geom2")}
         keep = sorted(set(keep) | {i for i, g in enumerate(self.geoms) if g["name"] and g["name"] in pair_names})
@@ -900,6 +927,9 @@ class _Compiler:
         A["geom_solref"] = np.stack([g["solref"] for g in geoms]) if ng else np.zeros((0, 2))
         A["geom_solimp"] = np.stack([g["solimp"] for g in geoms]) if ng else np.zeros((0, 5))
         A["geom_rbound"] = np.array([geom_rbound(g["type"], g["size"]) for g in geoms])
+        A["geom_meshadr"] = np.array([mesh_adr[g["mesh"]][0] if (g["type"] == GEOM_MESH and g["mesh"] in mesh_adr) else -1 for g in geoms], np.int32)
+        A["geom_meshnum"] = np.array([mesh_adr[g["mesh"]][1] if (g["type"] == GEOM_MESH and g["mesh"] in mesh_adr) else 0 for g in geoms], np.int32)
+        A["mesh_vert"] = np.concatenate(mesh_vert) if mesh_vert else np.zeros((0, 3))
         # sites
         A["site_bodyid"] = np.array([s["body"] for s in self.sites], np.int32)
         A["site_pos"] = np.stack([s["pos"] for s in self.sites]) if self.sites else np.zeros((0, 3))
@@ -1065,7 +1095,7 @@ def _pad(v, default):
     return out
 
 
-def compile_mjcf(path, terrain=False) -> CompiledModel:
+def compile_mjcf(path, terrain=False, replace=None, convex_meshes=False) -> CompiledModel:
     """Compile an MJCF file into flat arrays (see module docstring).  terrain=True: the model variant the reference's TerrainEnvV0
     creates at reset (height-field geom raised to z = 0 and colliding); False: its pairs are dropped (myoLegWalk-v0 parks it at -10 m)."""
-    return _Compiler(path, terrain).compile()
+    return _Compiler(path, terrain, replace, convex_meshes).compile()

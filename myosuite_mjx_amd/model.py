@@ -93,12 +93,12 @@ class Model:
         return m
 
 
-def from_mjcf(path, terrain=False) -> Model:
+def from_mjcf(path, terrain=False, replace=None, convex_meshes=False) -> Model:
     """Compile an MJCF file (needs the reference tree; not available on the GPU box)."""
     from .mjcf import compile_mjcf
     from .setconst import set_constants
     from .lowering import lower
-    cm = compile_mjcf(path, terrain)
+    cm = compile_mjcf(path, terrain, replace, convex_meshes)
     set_constants(cm)
     try:
         lower(cm)

@@ -45,7 +45,7 @@ typedef double real;
 enum { GEOM_PLANE = 0, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH };
 enum { JNT_FREE = 0, JNT_BALL, JNT_SLIDE, JNT_HINGE };
 enum { WRAP_NONE = 0, WRAP_JOINT, WRAP_PULLEY, WRAP_SITE, WRAP_SPHERE, WRAP_CYLINDER };
-enum { CT_EQUALITY = 0, CT_LIMIT_JOINT, CT_LIMIT_TENDON, CT_CONTACT };
+enum { CT_EQUALITY = 0, CT_LIMIT_JOINT, CT_LIMIT_TENDON, CT_CONTACT, CT_FRICTION_DOF };
 
 /* ------------------------------------------------------------------ model */
 typedef struct {
@@ -61,6 +61,8 @@ typedef struct {
   real *qpos0, *qpos_spring;
   int *dof_bodyid, *dof_jntid, *dof_parentid, *dof_Madr;
   real *dof_armature, *dof_damping, *dof_invweight0;
+  real *dof_frictionloss, *dof_solref_fri, *dof_solimp_fri;   /* joint friction loss (mj_instantiateFriction rows); NULL-safe: zero when the blob lacks them */
+  int *geom_meshadr, *geom_meshnum; real* mesh_vert;          /* convex-hull vertices of colliding mesh geoms (geom frame) */
   int *geom_type, *geom_bodyid, *geom_contype, *geom_conaffinity, *geom_condim, *geom_priority;
   real *geom_pos, *geom_quat, *geom_size, *geom_margin, *geom_gap, *geom_solmix, *geom_friction, *geom_solref,
       *geom_solimp, *geom_rbound;
@@ -108,7 +110,7 @@ typedef struct {
   /* constraints */
   int nefc, nefc_max;
   int *efc_type, *efc_id, *efc_state;
-  real *efc_J, *efc_pos, *efc_margin, *efc_diagApprox, *efc_R, *efc_D, *efc_aref, *efc_vel, *efc_force, *efc_b;
+  real *efc_J, *efc_pos, *efc_margin, *efc_diagApprox, *efc_R, *efc_D, *efc_aref, *efc_vel, *efc_force, *efc_b, *efc_frictionloss;
   /* solver diagnostics */
   int solver_iter, warning;
   real solver_improvement, solver_gradient;
@@ -188,6 +190,10 @@ Model* myoo_load(const void* blobv, size_t nbytes) {
   LF(actuator_gear); LF(actuator_dynprm); LF(actuator_gainprm); LF(actuator_biasprm); LF(actuator_ctrlrange);
   LF(actuator_forcerange); LF(actuator_lengthrange); LF(actuator_acc0);
   LI(pair_geom); LI(pair_condim);
+  /* optional tables (models compiled before they existed simply lack them) */
+  if (blob_find(blob, "dof_frictionloss")) { LF(dof_frictionloss); LF(dof_solref_fri); LF(dof_solimp_fri); }
+  else { m->dof_frictionloss = (real*)calloc(m->nv + 1, sizeof(real)); m->storage[m->nstorage++] = m->dof_frictionloss; }
+  if (blob_find(blob, "geom_meshadr")) { LI(geom_meshadr); LI(geom_meshnum); LF(mesh_vert); }
   m->neq = sz[12];
   LI(eq_obj1id); LI(eq_obj2id); LF(eq_data); LF(eq_solref); LF(eq_solimp);
 #undef LF
@@ -287,13 +293,13 @@ Data* myoo_make_data(const Model* m) {
   AL(qfrc_bias, nv); AL(qfrc_passive, nv);
   AL(actuator_force, m->nu); AL(act_dot, m->na); AL(qfrc_actuator, nv); AL(qfrc_smooth, nv); AL(qacc_smooth, nv);
   AL(qfrc_constraint, nv); AL(qacc, nv); AL(qfrc_applied, nv);
-  d->nefc_max = m->neq + 2 * m->njnt + 2 * m->ntendon + 6 * NCON_MAX;
+  d->nefc_max = m->neq + m->nv + 2 * m->njnt + 2 * m->ntendon + 10 * NCON_MAX;
   int ne = d->nefc_max;
   d->efc_type = (int*)calloc(ne, sizeof(int)); d->efc_id = (int*)calloc(ne, sizeof(int));
   d->efc_state = (int*)calloc(ne, sizeof(int));
   AL(efc_J, ne * nv); AL(efc_pos, ne); AL(efc_margin, ne); AL(efc_diagApprox, ne); AL(efc_R, ne); AL(efc_D, ne);
-  AL(efc_aref, ne); AL(efc_vel, ne); AL(efc_force, ne); AL(efc_b, ne);
-  AL(wk, 16 * nv + 2 * nv * nv + 8 * ne + 12 * nb + 64);
+  AL(efc_aref, ne); AL(efc_vel, ne); AL(efc_force, ne); AL(efc_b, ne); AL(efc_frictionloss, ne);
+  AL(wk, 32 * nv + 2 * nv * nv + 8 * ne + 12 * nb + 64);
 #undef AL
   memcpy(d->qpos, m->qpos0, m->nq * sizeof(real));
   d->hfield_data = (float*)calloc((size_t)m->hfield_dims[0] * m->hfield_dims[1] + 1, sizeof(float));
@@ -332,7 +338,7 @@ void myoo_free_data(Data* d) {
   free(d->qfrc_smooth); free(d->qacc_smooth); free(d->qfrc_constraint); free(d->qacc); free(d->qfrc_applied); free(d->efc_type);
   free(d->efc_id); free(d->efc_state); free(d->efc_J); free(d->efc_pos); free(d->efc_margin);
   free(d->efc_diagApprox); free(d->efc_R); free(d->efc_D); free(d->efc_aref); free(d->efc_vel); free(d->efc_force);
-  free(d->efc_b); free(d->wk);
+  free(d->efc_b); free(d->efc_frictionloss); free(d->wk);
   free(d);
 }
 
@@ -501,6 +507,19 @@ static void jac_point(const Model* m, const Data* d, real* jacp, const real* poi
       for (int k = 0; k < 3; k++) col[k] += c[3 + k];
     }
     jacp[i] = col[0]; jacp[nv + i] = col[1]; jacp[2 * nv + i] = col[2];
+    i = m->dof_parentid[i];
+  }
+}
+
+/* rotational Jacobian (3 x nv) of a body: hinge -> axis, slide -> 0, free joint's rotational dofs -> body axes (cdof angular part) */
+static void jac_rot(const Model* m, const Data* d, real* jacr, int body) {
+  int nv = m->nv;
+  memset(jacr, 0, 3 * nv * sizeof(real));
+  int i = m->body_lastdof[body];
+  while (i >= 0) {
+    int j = m->dof_jntid[i];
+    if (m->jnt_type[j] == JNT_HINGE) { for (int k = 0; k < 3; k++) jacr[k * nv + i] = d->xaxis[3 * j + k]; }
+    else if (m->jnt_type[j] == JNT_FREE) { for (int k = 0; k < 3; k++) jacr[k * nv + i] = d->cdof[6 * i + k]; }
     i = m->dof_parentid[i];
   }
 }
@@ -980,10 +999,60 @@ static void collision(const Model* m, Data* d) { /* mj_collision over the compil
         d->ncon++;
       }
       continue;
-    } else if ((t1 == GEOM_CAPSULE || t1 == GEOM_ELLIPSOID || t1 == GEOM_CYLINDER || t1 == GEOM_SPHERE) &&
-               (t2 == GEOM_CAPSULE || t2 == GEOM_ELLIPSOID || t2 == GEOM_CYLINDER || t2 == GEOM_SPHERE)) {
+    } else if ((t1 == GEOM_CAPSULE || t1 == GEOM_ELLIPSOID || t1 == GEOM_CYLINDER || t1 == GEOM_SPHERE || t1 == GEOM_BOX || (t1 == GEOM_MESH && m->mesh_vert)) &&
+               (t2 == GEOM_CAPSULE || t2 == GEOM_ELLIPSOID || t2 == GEOM_CYLINDER || t2 == GEOM_SPHERE || t2 == GEOM_BOX || (t2 == GEOM_MESH && m->mesh_vert))) {
+      /* general convex pair.  Boxes and convex-hull meshes (TrackEnv: table, object) go through the same MPR as the ellipsoid pads;
+         MuJoCo uses analytic capsule-box / sphere-box routines (1-2 contacts) where this gives the single MPR contact [deviation, DESIGN 3] */
       if (m->disable_ellipsoid) continue;
       hit = convex_pair(m, d, &c, margin, g1, g2);
+    } else if (t1 == GEOM_PLANE && (t2 == GEOM_BOX || (t2 == GEOM_MESH && m->mesh_vert))) {
+      /* mjc_PlaneBox [3P]: every corner below the box centre and within the margin, at most 4.  Plane - mesh (mjc_PlaneConvex): the deepest
+         hull vertex (MuJoCo adds up to three neighbouring vertices; the planes of the TrackEnv scene lie under the table) */
+      const real* R = d->geom_xmat + 9 * g1;
+      real nrm[3] = {R[2], R[5], R[8]};
+      const real* R2 = d->geom_xmat + 9 * g2;
+      const real* sz = m->geom_size + 3 * g2;
+      real vec0[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
+      real dist0 = dot3(vec0, nrm);
+      real cdist[4], cpt[12];
+      int nc = 0;
+      if (t2 == GEOM_BOX) {
+        for (int i = 0; i < 8 && nc < 4; i++) {
+          real vec[3] = {(i & 1) ? sz[0] : -sz[0], (i & 2) ? sz[1] : -sz[1], (i & 4) ? sz[2] : -sz[2]}, corner[3];
+          mat_vec3(corner, R2, vec);
+          real ldist = dot3(nrm, corner);
+          if (dist0 + ldist > margin || ldist > 0) continue;
+          cdist[nc] = dist0 + ldist;
+          for (int k = 0; k < 3; k++) cpt[3 * nc + k] = corner[k] + x2[k] - nrm[k] * cdist[nc] * (real)0.5;
+          nc++;
+        }
+      } else {
+        real nl[3], best = 0, pw[3];
+        int bi = -1;
+        matT_vec3(nl, R2, nrm);
+        const real* V = m->mesh_vert + 3 * m->geom_meshadr[g2];
+        for (int i = 0; i < m->geom_meshnum[g2]; i++) { real t = dot3(V + 3 * i, nl); if (bi < 0 || t < best) { best = t; bi = i; } }
+        if (bi >= 0 && dist0 + best <= margin) {
+          mat_vec3(pw, R2, V + 3 * bi);
+          cdist[0] = dist0 + best;
+          for (int k = 0; k < 3; k++) cpt[k] = x2[k] + pw[k] - nrm[k] * cdist[0] * (real)0.5;
+          nc = 1;
+        }
+      }
+      for (int q = 0; q < nc; q++) {
+        if (d->ncon >= NCON_MAX) { d->ncon_dropped++; continue; }
+        Contact* cc = &d->con[d->ncon];
+        memset(cc, 0, sizeof *cc);
+        cc->dist = cdist[q];
+        memcpy(cc->pos, cpt + 3 * q, 3 * sizeof(real));
+        memcpy(cc->frame, nrm, sizeof nrm);
+        make_frame(cc->frame);
+        contact_params(m, cc, g1, g2);
+        cc->includemargin = margin - gap;
+        cc->geom1 = g1; cc->geom2 = g2;
+        d->ncon++;
+      }
+      continue;
     } else if (t1 == GEOM_PLANE && (t2 == GEOM_SPHERE || t2 == GEOM_ELLIPSOID || t2 == GEOM_CYLINDER)) {
       /* mjc_PlaneSphere / mjc_PlaneConvex (ellipsoid: deepest support point) / mjc_PlaneCylinder [3P] */
       const real* R = d->geom_xmat + 9 * g1;
@@ -1077,7 +1146,7 @@ static void collision(const Model* m, Data* d) { /* mj_collision over the compil
  * inflated by margin/2 (engine_collision_convex.c) [3P].  This is a restatement of the
  * published XenoCollide/MPR algorithm (G. Snethen, Game Programming Gems 7), with
  * tolerance 1e-6 and 50 iterations like MuJoCo's ccd_tolerance / ccd_iterations defaults. */
-typedef struct { const real *pos, *mat, *size; int type; real margin; } CObj;
+typedef struct { const real *pos, *mat, *size; int type; real margin; const real* verts; int nvert; } CObj;
 
 static void support_local(const CObj* o, const real* dl, real* out) {
   switch (o->type) {
@@ -1099,6 +1168,14 @@ static void support_local(const CObj* o, const real* dl, real* out) {
       out[0] = n > MINVAL ? dl[0] / n * o->size[0] : 0;
       out[1] = n > MINVAL ? dl[1] / n * o->size[0] : 0;
       out[2] = dl[2] >= 0 ? o->size[1] : -o->size[1];
+      break;
+    }
+    case GEOM_BOX: for (int k = 0; k < 3; k++) out[k] = dl[k] >= 0 ? o->size[k] : -o->size[k]; break;
+    case GEOM_MESH: { /* convex hull: the vertex furthest along the direction (MuJoCo climbs the hull's vertex graph to the same vertex) */
+      int best = 0;
+      real bd = dot3(o->verts, dl);
+      for (int i = 1; i < o->nvert; i++) { real t = dot3(o->verts + 3 * i, dl); if (t > bd) { bd = t; best = i; } }
+      for (int k = 0; k < 3; k++) out[k] = o->verts[3 * best + k];
       break;
     }
     case GEOM_PRISM: { /* prism_support [3P]: only the bottom (0..2) or top (3..5) triangle can be extremal, by the sign of dir_z */
@@ -1248,8 +1325,10 @@ static int convex_pair(const Model* m, const Data* d, Contact* c, real margin, i
   const real zero3[3] = {0, 0, 0};
   real rel[3];
   for (int k = 0; k < 3; k++) rel[k] = d->geom_xpos[3 * g2 + k] - d->geom_xpos[3 * g1 + k];
-  CObj o1 = {zero3, d->geom_xmat + 9 * g1, m->geom_size + 3 * g1, m->geom_type[g1], margin * (real)0.5};
-  CObj o2 = {rel, d->geom_xmat + 9 * g2, m->geom_size + 3 * g2, m->geom_type[g2], margin * (real)0.5};
+  CObj o1 = {zero3, d->geom_xmat + 9 * g1, m->geom_size + 3 * g1, m->geom_type[g1], margin * (real)0.5, NULL, 0};
+  CObj o2 = {rel, d->geom_xmat + 9 * g2, m->geom_size + 3 * g2, m->geom_type[g2], margin * (real)0.5, NULL, 0};
+  if (o1.type == GEOM_MESH) { o1.verts = m->mesh_vert + 3 * m->geom_meshadr[g1]; o1.nvert = m->geom_meshnum[g1]; }
+  if (o2.type == GEOM_MESH) { o2.verts = m->mesh_vert + 3 * m->geom_meshadr[g2]; o2.nvert = m->geom_meshnum[g2]; }
   real depth, dir[3], pos[3];
 #ifdef MYOO_FLOAT
   if (!mpr_penetration(&o1, &o2, (real)1e-8, 60, &depth, dir, pos)) return 0;
@@ -1283,7 +1362,7 @@ static void convex_hfield(const Model* m, Data* d, real margin, real gap, int g1
   for (int i = 0; i < 2; i++) if (hs[i] < pos[i] - r2 - margin || -hs[i] > pos[i] + r2 + margin) return;
   if (hs[2] < pos[2] - r2 - margin || -hs[3] > pos[2] + r2 + margin) return;
   /* AABB of geom 2 in the height field frame */
-  CObj og = {pos, d->geom_xmat + 9 * g2, m->geom_size + 3 * g2, m->geom_type[g2], 0};
+  CObj og = {pos, d->geom_xmat + 9 * g2, m->geom_size + 3 * g2, m->geom_type[g2], 0, NULL, 0};
   real lo[3], hi[3];
   for (int a = 0; a < 3; a++) {
     real dir[3] = {0, 0, 0}, s[3];
@@ -1321,8 +1400,8 @@ static void convex_hfield(const Model* m, Data* d, real margin, real gap, int g1
         for (int k = 0; k < 6; k++) for (int a = 0; a < 3; a++) cen[a] += V[3 * k + a] / 6;
         for (int k = 0; k < 6; k++) for (int a = 0; a < 3; a++) V[3 * k + a] -= cen[a];
         real rel[3] = {pos[0] - cen[0], pos[1] - cen[1], pos[2] - cen[2]};
-        CObj o1 = {zero3, ident, V, GEOM_PRISM, margin * (real)0.5};
-        CObj o2 = {rel, d->geom_xmat + 9 * g2, m->geom_size + 3 * g2, m->geom_type[g2], margin * (real)0.5};
+        CObj o1 = {zero3, ident, V, GEOM_PRISM, margin * (real)0.5, NULL, 0};
+        CObj o2 = {rel, d->geom_xmat + 9 * g2, m->geom_size + 3 * g2, m->geom_type[g2], margin * (real)0.5, NULL, 0};
         real depth, dir[3], cp[3];
 #ifdef MYOO_FLOAT
         if (!mpr_penetration(&o1, &o2, (real)1e-8, 60, &depth, dir, cp)) continue;
@@ -1394,6 +1473,12 @@ static void make_constraint(const Model* m, Data* d) { /* mj_makeConstraint: lim
       if (j2 >= 0) d->efc_J[(size_t)r * nv + m->jnt_dofadr[j2]] = -deriv;
     }
   }
+  /* dof friction loss (mj_instantiateFriction [3P]): one row per dof with frictionloss > 0, J = e_dof, pos = 0 */
+  for (int i = 0; i < nv; i++) {
+    if (!(m->dof_frictionloss[i] > 0)) continue;
+    int r = add_row(d, nv, CT_FRICTION_DOF, i, 0, 0, m->dof_invweight0[i]);
+    if (r >= 0) { d->efc_J[(size_t)r * nv + i] = 1; d->efc_frictionloss[r] = m->dof_frictionloss[i]; }
+  }
   if (!m->disable_limit) {
     for (int j = 0; j < m->njnt; j++) {
       if (!m->jnt_limited[j]) continue;
@@ -1428,21 +1513,34 @@ static void make_constraint(const Model* m, Data* d) { /* mj_makeConstraint: lim
     int b1 = m->geom_bodyid[c->geom1], b2 = m->geom_bodyid[c->geom2];
     jac_point(m, d, jac1, c->pos, b1);
     jac_point(m, d, jac2, c->pos, b2);
-    real* jf = d->wk + 6 * nv; /* 3 x nv, contact frame */
+    real* jf = d->wk + 6 * nv; /* 6 x nv, contact frame: 3 translational rows, then 3 rotational ones (condim 4 / 6) */
     for (int r = 0; r < 3; r++)
       for (int i = 0; i < nv; i++)
         jf[r * nv + i] = c->frame[3 * r] * (jac2[i] - jac1[i]) + c->frame[3 * r + 1] * (jac2[nv + i] - jac1[nv + i]) +
                          c->frame[3 * r + 2] * (jac2[2 * nv + i] - jac1[2 * nv + i]);
+    if (c->dim > 3) {
+      real* jr1 = d->wk + 12 * nv;
+      real* jr2 = d->wk + 15 * nv;
+      jac_rot(m, d, jr1, b1);
+      jac_rot(m, d, jr2, b2);
+      for (int r = 0; r < 3; r++)
+        for (int i = 0; i < nv; i++)
+          jf[(3 + r) * nv + i] = c->frame[3 * r] * (jr2[i] - jr1[i]) + c->frame[3 * r + 1] * (jr2[nv + i] - jr1[nv + i]) +
+                                 c->frame[3 * r + 2] * (jr2[2 * nv + i] - jr1[2 * nv + i]);
+    }
     real tran = m->body_invweight0[2 * b1] + m->body_invweight0[2 * b2];
+    real rot = m->body_invweight0[2 * b1 + 1] + m->body_invweight0[2 * b2 + 1];
     c->mu = c->friction[0]; /* * sqrt(impratio) with impratio = 1 */
     if (c->dim == 1) {
       int r = add_row(d, nv, CT_CONTACT, ci, c->dist, c->includemargin, tran);
       if (r >= 0) memcpy(d->efc_J + (size_t)r * nv, jf, nv * sizeof(real));
     } else {
-      for (int k = 1; k < 3; k++) { /* condim 3: two tangent directions, pyramidal */
+      /* pyramidal cone (mj_instantiateContact [3P]): 2 (dim - 1) rows J_normal +- friction[k-1] J_k; k = 1, 2 tangents, 3 torsion (spin
+         about the normal), 4, 5 rolling; diagApprox = tran + fri^2 (tran | rot) */
+      for (int k = 1; k < c->dim; k++) {
         real fri = c->friction[k - 1];
         for (int sgn = 1; sgn >= -1; sgn -= 2) {
-          int r = add_row(d, nv, CT_CONTACT, ci, c->dist, c->includemargin, tran + fri * fri * tran);
+          int r = add_row(d, nv, CT_CONTACT, ci, c->dist, c->includemargin, tran + fri * fri * (k < 3 ? tran : rot));
           if (r >= 0) for (int i = 0; i < nv; i++) d->efc_J[(size_t)r * nv + i] = jf[i] + sgn * fri * jf[k * nv + i];
         }
       }
@@ -1456,6 +1554,7 @@ static void get_solparams(const Model* m, const Data* d, int i, const real** sol
     case CT_EQUALITY: *solref = m->eq_solref + 2 * id; *solimp = m->eq_solimp + 5 * id; break;
     case CT_LIMIT_JOINT: *solref = m->jnt_solref + 2 * id; *solimp = m->jnt_solimp + 5 * id; break;
     case CT_LIMIT_TENDON: *solref = m->tendon_solref + 2 * id; *solimp = m->tendon_solimp + 5 * id; break;
+    case CT_FRICTION_DOF: *solref = m->dof_solref_fri + 2 * id; *solimp = m->dof_solimp_fri + 5 * id; break;
     default: *solref = d->con[id].solref; *solimp = d->con[id].solimp; break;
   }
 }
@@ -1710,6 +1809,20 @@ static real constraint_update(const Model* m, Data* d, const real* jar, int set_
   int nv = m->nv;
   if (set_force) memset(d->qfrc_constraint, 0, nv * sizeof(real));
   for (int i = 0; i < d->nefc; i++) {
+    if (d->efc_type[i] == CT_FRICTION_DOF) {
+      /* friction-loss row (PrimalUpdateConstraint [3P]): quadratic while |jar| < R f, linear beyond: the force saturates at +-f */
+      real f = d->efc_frictionloss[i], rf = d->efc_R[i] * f, x = jar[i], force;
+      int quad = 0;
+      if (x <= -rf) { force = f; cost += f * (-(real)0.5 * rf - x); }
+      else if (x >= rf) { force = -f; cost += f * (-(real)0.5 * rf + x); }
+      else { force = -d->efc_D[i] * x; cost += (real)0.5 * d->efc_D[i] * x * x; quad = 1; }
+      if (set_force) {
+        d->efc_state[i] = quad;        /* only the quadratic zone enters the Hessian */
+        d->efc_force[i] = force;
+        for (int k = 0; k < nv; k++) d->qfrc_constraint[k] += d->efc_J[(size_t)i * nv + k] * force;
+      }
+      continue;
+    }
     int active = d->efc_type[i] == CT_EQUALITY || jar[i] < 0;
     if (active) cost += (real)0.5 * d->efc_D[i] * jar[i] * jar[i];
     if (set_force) {
@@ -1735,12 +1848,19 @@ static long g_ls_hist[64];
 static int g_ls_last;
 void myoo_ls_hist(long* out, int reset) { for (int k = 0; k < 64; k++) { out[k] = g_ls_hist[k]; if (reset) g_ls_hist[k] = 0; } }
 
-typedef struct { real g1, g2; const real *jar, *jv, *D; const int* type; int nefc; } LSctx;
+typedef struct { real g1, g2; const real *jar, *jv, *D, *R, *floss; const int* type; int nefc; } LSctx;
 static real g_ls_mag;   /* magnitude of the terms that cancel in d1 at the last evaluation (round-off scale of the float build) */
 static void ls_eval(const LSctx* c, real alpha, real* d1, real* d2) {
   real a = c->g1 + 2 * alpha * c->g2, b = 2 * c->g2, p = 0;
   for (int i = 0; i < c->nefc; i++) {
     real x = c->jar[i] + alpha * c->jv[i];
+    if (c->type[i] == CT_FRICTION_DOF) {
+      real f = c->floss[i], rf = c->R[i] * f;
+      if (x <= -rf) p -= f * c->jv[i];
+      else if (x >= rf) p += f * c->jv[i];
+      else { p += c->D[i] * x * c->jv[i]; b += c->D[i] * c->jv[i] * c->jv[i]; }
+      continue;
+    }
     if (c->type[i] == CT_EQUALITY || x < 0) { p += c->D[i] * x * c->jv[i]; b += c->D[i] * c->jv[i] * c->jv[i]; }
   }
   g_ls_mag = fabs(c->g1) + fabs(2 * alpha * c->g2) + fabs(p);
@@ -1842,7 +1962,7 @@ static void fwd_constraint(const Model* m, Data* d) { /* mj_fwdConstraint + mj_s
     LSctx ls;
     ls.g1 = 0; ls.g2 = 0;
     for (int k = 0; k < nv; k++) { ls.g1 += search[k] * (Ma[k] - d->qfrc_smooth[k]); ls.g2 += (real)0.5 * search[k] * Mv[k]; }
-    ls.jar = jar; ls.jv = jv; ls.D = d->efc_D; ls.type = d->efc_type; ls.nefc = nefc;
+    ls.jar = jar; ls.jv = jv; ls.D = d->efc_D; ls.R = d->efc_R; ls.floss = d->efc_frictionloss; ls.type = d->efc_type; ls.nefc = nefc;
     real gtol = m->tolerance * m->ls_tolerance * snorm / scale;
     real lo = 0, hi = -1, dlo, d2lo, dhi = 0, d2hi = 0, alpha = 0, d1, d2;
     ls_eval(&ls, 0, &dlo, &d2lo);

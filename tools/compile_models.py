@@ -18,6 +18,8 @@ MODELS = {
     "motorfinger_v0": "myosuite/simhive/myo_sim/finger/motorfinger_v0.xml",
     "myohand_hold": "myosuite/envs/myo/assets/hand/myohand_hold.xml",
     "myolegs_terrain": ("myosuite/simhive/myo_sim/leg/myolegs.xml",),     # height field raised and colliding (TerrainEnvV0)
+    # MyoDM TrackEnv (mjx/myodm_v0.py:306-308): myohand_object.xml with OBJECT_NAME -> airplane; meshes collide as convex hulls
+    "myohand_object_airplane": ("myosuite/envs/myo/assets/hand/myohand_object.xml", {"OBJECT_NAME": "airplane"}),
 }
 
 if __name__ == "__main__":
@@ -25,6 +27,9 @@ if __name__ == "__main__":
     for stem, rel in MODELS.items():
         if only and stem not in only:
             continue
-        m = M.from_mjcf(os.path.join(REF, rel[0]), terrain=True) if isinstance(rel, tuple) else M.from_mjcf(os.path.join(REF, rel))
+        if isinstance(rel, tuple) and len(rel) == 2:
+            m = M.from_mjcf(os.path.join(REF, rel[0]), replace=rel[1], convex_meshes=True)
+        else:
+            m = M.from_mjcf(os.path.join(REF, rel[0]), terrain=True) if isinstance(rel, tuple) else M.from_mjcf(os.path.join(REF, rel))
         m.save(os.path.join(M.ASSET_DIR, stem))
         print(stem, dict(nq=m.nq, nv=m.nv, nu=m.nu, nbody=m.nbody, ntendon=m.ntendon, bytes=len(m.blob())))
