@@ -67,6 +67,9 @@ typedef enum myo_field {
   MYO_F_HFIELD,      /* [B][nrow*ncol] height-field elevation per env (terrain models: mjModel.hfield_data, rewritten per episode by
                         TerrainEnvV0.reset, walk_v0.py:563-622); absent (MYO_E_ARG) for models without a colliding height field */
   MYO_F_GEOMSIZE,    /* [B][4] per-env size (3) + bounding radius of the geom named in myo_batch_set_geom_override (absent otherwise) */
+  MYO_F_LINKX,       /* [B][12*nlink] world frame (pos 3 + rotation 9, row-major) of every kinematic link as the LAST substep's position stage
+                        computed it, i.e. at the state before that substep's integration: what an MJX pipeline_state holds in xpos / xmat
+                        after mjx.step (forward, then integrate; mjx/myodm_v0.py:201-232 reads it).  Models of the TrackEnv class only */
   MYO_F_COUNT
 } myo_field;
 

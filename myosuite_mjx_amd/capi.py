@@ -14,7 +14,7 @@ SRC_PATH = os.path.join(_HERE, "csrc", "myo_hip.hip")
 
 # field ids (myo_field)
 (F_QPOS, F_QVEL, F_ACT, F_CTRL, F_WARMSTART, F_TIME, F_TARGET, F_OBS, F_REWARD, F_DONE, F_SOLVED, F_FLAGS, F_DIAG,
- F_QACC, F_TENLEN, F_ACTFORCE, F_SITEXPOS, F_ELAPSED, F_ACTION, F_FATIGUE, F_HFIELD, F_GEOMSIZE) = range(22)
+ F_QACC, F_TENLEN, F_ACTFORCE, F_SITEXPOS, F_ELAPSED, F_ACTION, F_FATIGUE, F_HFIELD, F_GEOMSIZE, F_LINKX) = range(23)
 INT_FIELDS = (F_FLAGS, F_DIAG, F_ELAPSED)
 BENCH_OBS, BENCH_FRESH_ACTIONS, BENCH_AUTORESET = 1, 2, 4
 ACTMAP_NONE, ACTMAP_MUSCLE_SIGMOID, ACTMAP_SIGMOID_FATIGUE, ACTMAP_SIGMOID_REAFFERENTATION = 0, 1, 2, 3

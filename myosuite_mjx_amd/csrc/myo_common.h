@@ -5,11 +5,13 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -88,6 +90,7 @@ struct DevBatch {
   float* ovf;              // [B][NCX][ovf_row] floats: dist, pos[3], normal[3], pair id, cJ[3 * KC], dof ids (byte-packed)
   int* ovf_cand;           // [B][NCANDX]
   int ovf_row;             // floats per overflow row (0: no overflow storage, the LDS table is the capacity)
+  float* linkx;            // [B][12 * nl] link frames of the last substep's position stage (TRK models; NULL otherwise)
 };
 #define NCX 32      // overflow contact rows per env: 64 contacts in all, one per lane of the wave
 #define NCANDX 256  // overflow candidates per env (MyoHand has 289 pairs: NCAND + NCANDX covers every pair)

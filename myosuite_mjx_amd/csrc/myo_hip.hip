@@ -40,6 +40,8 @@ struct myo_model {
   DevModelW* d_dw = nullptr;
   int env_lds_bytes_w = 0;
   bool wave_ok = false, generic_ok = false;
+  int n_cu = 0;                 // compute units of the model's device (scheduler sizing)
+  bool trk = false;             // TrackEnv model class: step_kernel_w<36,20,32,2,2,false,0,false,true>
   bool hand_sizes = false, leg_sizes = false, terrain_sizes = false;   // table sizes equal Sizes<1> / Sizes<2>: the size-specialised instantiations may be used
   int wave_cfg = 0;             // 0: step_kernel_w<24,8,32,1,4> (hand / finger), 1: step_kernel_w<36,20,48,2,2> (legs)
   int nq = 0;
@@ -117,7 +119,7 @@ static int load_i(myo_model* m, const uint8_t* blob, const char* name, const int
   return upload<int>(m, v, out);
 }
 
-static void build_layout_w(const DevModel& d, DevModelW& w, int nvt, int kc, int nc) {
+static void build_layout_w(const DevModel& d, DevModelW& w, int nvt, int kc, int nc, int nj = 3) {
   LayW& Y = w.lay;
   int o = 0;
   auto take = [&](int n) { int r = o; o += n; return r; };
@@ -137,7 +139,7 @@ static void build_layout_w(const DevModel& d, DevModelW& w, int nvt, int kc, int
   Y.gpos = take(3 * d.ncg); Y.gax = take(3 * d.ncg);
   Y.cand = take(NCAND);
   if (o - Y.Mp < (nvt * (nvt + 1)) / 2) o = Y.Mp + (nvt * (nvt + 1)) / 2; Y.cdist = take(nc); Y.cpos = take(3 * nc); Y.cnrm = take(3 * nc); Y.cpair = take(nc);
-  Y.cJ = take(nc * 3 * kc); Y.cdofs = take(nc * ((kc + 3) / 4));   // kc dof ids per contact, one byte each
+  Y.cJ = take(nc * nj * kc); Y.cdofs = take(nc * ((kc + 3) / 4));   // nj jacobian rows of kc entries per contact; kc dof ids per contact, one byte each
   if (o < endT) o = endT;
   if (o < endD) o = endD;
   Y.total = o;
@@ -186,6 +188,7 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
   HIPCHK(hipSetDevice(device));
   myo_model* m = new myo_model();
   m->device = device;
+  { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->n_cu = prop.multiProcessorCount; }
   DevModel& d = m->dm;
   const BlobRec* hs = blob_find(blob, "hip_sizes");
   const BlobRec* sz = blob_find(blob, "sizes");
@@ -275,12 +278,26 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
       // the 16/32-lane generic kernel covers fixed-base models with hinge / slide joints and capsule / convex pairs only
       m->generic_ok = !w.has_free && w.neq == 0 && !plane_pairs && !condim1 && w.nq == d.nv && d.maxkc <= KCMAX && !w.has_tl && !m->has_affine;
     }
+    // TrackEnv model class (lowering: hip_trk = condim-4 pairs | friction loss | box / hull geoms): tables of the TRK instantiation
+    w.fl = nullptr; w.mesh_vert = nullptr;
+    m->trk = false;
+    if (blob_find(blob, "hip_trk")) {
+      std::vector<int> tk;
+      if ((rc = load_i(m, blob, "hip_trk", &tmpi, &tk)) || (rc = load_f(m, blob, "hip_fl", &w.fl)) || (rc = load_f(m, blob, "hip_mesh_vert", &w.mesh_vert))) { myo_model_free(m); return rc; }
+      m->trk = tk[0] || tk[1] || tk[2];
+    }
     const bool common = d.nl <= 64 && d.ncg <= 64 && w.nq <= 64 && w.neq <= 64 && d.maxnnz <= 20;
-    const bool needs_full = w.has_free || w.neq > 0 || plane_pairs || condim1;
-    if (common && !needs_full && d.nv <= 24 && d.nu <= 64 && d.ngt <= 64 && d.maxkc <= 8) { m->wave_ok = true; m->wave_cfg = 0; build_layout_w(d, w, 24, 8, 32); }
+    const bool needs_full = w.has_free || w.neq > 0 || plane_pairs || condim1 || m->trk;
+    if (m->trk) {
+      if (!(common && d.nv <= 36 && d.nu <= 128 && d.ngt <= 128 && d.maxkc <= 20 && !w.hf.on && !w.has_tl)) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "condim-4 / friction-loss / box / mesh model exceeds the limits of the TRK step kernel"); }
+      m->wave_ok = true; m->wave_cfg = 2; m->generic_ok = false;
+      build_layout_w(d, w, 36, 20, 32, 4);
+    }
+    else if (common && !needs_full && d.nv <= 24 && d.nu <= 64 && d.ngt <= 64 && d.maxkc <= 8) { m->wave_ok = true; m->wave_cfg = 0; build_layout_w(d, w, 24, 8, 32); }
     else if (common && d.nv <= 36 && d.nu <= 128 && d.ngt <= 128 && d.maxkc <= 20) { m->wave_ok = true; m->wave_cfg = 1; build_layout_w(d, w, 36, 20, 32); }
     else { m->wave_ok = false; build_layout_w(d, w, 24, 8, 32); }
     m->hand_sizes = m->wave_ok && m->wave_cfg == 0 && sizes_match<1>(w.nq, d.nv, d.nu, d.nl, d.nlevel, d.maxnnz, d.ngt, d.nseg, d.ncg, d.npair);
+    if (m->trk) m->generic_ok = false;
     m->leg_sizes = m->wave_ok && m->wave_cfg == 1 && sizes_match<2>(w.nq, d.nv, d.nu, d.nl, d.nlevel, d.maxnnz, d.ngt, d.nseg, d.ncg, d.npair);
     m->terrain_sizes = m->wave_ok && m->wave_cfg == 1 && w.hf.on && sizes_match<3>(w.nq, d.nv, d.nu, d.nl, d.nlevel, d.maxnnz, d.ngt, d.nseg, d.ncg, d.npair);
     if (const char* e = getenv("MYO_NO_SPEC")) if (atoi(e) == 1) m->hand_sizes = m->leg_sizes = m->terrain_sizes = false;   // tests: force the run-time-sized instantiations
@@ -294,7 +311,7 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
     if (hipMemcpy(p1, &d, sizeof(DevModel), hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(p2, &w, sizeof(DevModelW), hipMemcpyHostToDevice) != hipSuccess) { myo_model_free(m); return fail(MYO_E_HIP, "upload model structs"); }
   }
   m->dims = myo_dims{S[0], S[1], S[2], d.na_obs, S[4], S[8], S[7], d.nl, 0, m->wave_ok ? m->env_lds_bytes_w : m->env_lds_bytes, 64,
-                     m->wave_ok ? (m->wave_cfg == 1 ? 32 : NCONW) : NCON, d.timestep};
+                     m->wave_ok ? (m->wave_cfg >= 1 ? 32 : NCONW) : NCON, d.timestep};
   if (4 * m->env_lds_bytes > 160 * 1024) {
     if (!m->wave_ok) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "model working set exceeds 160 KB of LDS per workgroup"); }
     m->generic_ok = false;
@@ -348,10 +365,11 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   BA(b->d_action, (size_t)B * nu)
   BA(d.fatigue, (size_t)B * 3 * nu)
   d.hfield = nullptr; d.gsize = nullptr; d.gsize_cg = -1;
-  d.ovf = nullptr; d.ovf_cand = nullptr; d.ovf_row = 0;
+  d.ovf = nullptr; d.ovf_cand = nullptr; d.ovf_row = 0; d.linkx = nullptr;
+  if (m->trk) { BA(d.linkx, (size_t)B * 12 * m->dm.nl) }
   if (m->wave_ok) {   // contact-table overflow rows of the wave kernel (instantiations <24,8,...> and <36,20,...>)
-    const int kc = nv > 24 ? 20 : 8;
-    d.ovf_row = 8 + 3 * kc + (kc + 3) / 4;
+    const int kc = m->wave_cfg == 0 ? 8 : 20, nj = m->trk ? 4 : 3;
+    d.ovf_row = 8 + nj * kc + (kc + 3) / 4;
     BA(d.ovf, (size_t)B * NCX * d.ovf_row) BA(d.ovf_cand, (size_t)B * NCANDX)
   }
   if (m->dw.hf.on) { BA(d.hfield, (size_t)B * m->dw.hf.nrow * m->dw.hf.ncol) }   // zero-filled: flat terrain at the geom's height
@@ -529,6 +547,9 @@ static int field_info(myo_batch* b, int f, void** p, size_t* pitch, size_t* widt
     case MYO_F_TENLEN: *p = d.tenlen; *pitch = *width = nu; break;
     case MYO_F_ACTFORCE: *p = d.actforce; *pitch = *width = nu; break;
     case MYO_F_ELAPSED: *p = d.elapsed; *pitch = *width = 1; break;
+    case MYO_F_LINKX:
+      if (!d.linkx) return fail(MYO_E_ARG, "MYO_F_LINKX: this model's kernel does not export link frames");
+      *p = d.linkx; *pitch = *width = (size_t)12 * b->model->dm.nl; break;
     case MYO_F_ACTION: *p = b->d_action; *pitch = *width = nu; break;
     case MYO_F_FATIGUE: *p = d.fatigue; *pitch = *width = 3 * nu; break;
     case MYO_F_GEOMSIZE:
@@ -632,7 +653,11 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
   if (!(G == 64 && m->wave_ok) && !m->generic_ok)
     return fail(MYO_E_UNSUPPORTED, "this model (tendon limits / free joint / equalities / plane contacts) needs the wave-per-env kernel (lanes = 64)");
   if (G == 64 && m->wave_ok) {
-    static bool attr_w = false;
+    // kernel attributes are per device: one flag per device ordinal (a process that opens models on two GPUs)
+    static std::mutex attr_mu;
+    static bool attr_w_dev[64] = {};
+    std::lock_guard<std::mutex> attr_lock(attr_mu);
+    bool& attr_w = attr_w_dev[m->device & 63];
     if (!attr_w) {
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 4, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 4, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -644,6 +669,7 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       attr_w = true;
     }
     const int* order = nullptr;
@@ -651,31 +677,25 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     // substep scheduler: MYO_SCHED=1 forces it, 0 disables it; default (auto) uses it where it was measured to pay: when the launch
     // holds at least twice as many envs as the chip holds waves of this kernel (MyoLeg: 8 waves per CU; +6 % at 4096 envs).  With as
     // many waves as envs every wave just re-takes its own env and only the overhead is left (MyoHand at 4096 envs: -15 %)
-    static int sched_mode = -2, n_cu = 0;
-    if (sched_mode == -2) {
-      const char* e = getenv("MYO_SCHED"); sched_mode = e ? atoi(e) : -1;
-      hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, m->device) == hipSuccess) n_cu = prop.multiProcessorCount;
-      if (n_cu <= 0) n_cu = 256;
-    }
-    const int resident = n_cu * (m->wave_cfg == 1 ? 8 : 16);
+    static const int sched_mode = [] { const char* e = getenv("MYO_SCHED"); return e ? atoi(e) : -1; }();   // process-wide configuration (environment)
+    const int n_cu = m->n_cu > 0 ? m->n_cu : 256;                                                        // per model = per device
+    const int resident = n_cu * (m->wave_cfg == 0 ? 16 : (m->wave_cfg == 1 ? 8 : std::max(1, (160 * 1024) / std::max(1, m->env_lds_bytes_w))));
     const bool sched_ok = !kflags && Bn >= 64 && Bn <= SCHED_ENV_MASK && nsub + (wk ? 1 : 0) <= 15 && nsub > 0;
-    const bool sched = sched_ok && !(m->dw.hf.on && !m->terrain_sizes) && (sched_mode == 1 || (sched_mode == -1 && m->wave_cfg == 1 && Bn >= 2 * resident));
+    const bool sched = sched_ok && m->wave_cfg != 2 && !(m->dw.hf.on && !m->terrain_sizes) && (sched_mode == 1 || (sched_mode == -1 && m->wave_cfg == 1 && Bn >= 2 * resident));
     if (b->balance && Bn >= 1024 && Bn % 4 == 0 && !kflags && !sched) {
-      static int prio_mode = -1;
-      if (prio_mode < 0) { const char* e = getenv("MYO_PRIO"); prio_mode = e ? atoi(e) : 2; }
+      static const int prio_mode = [] { const char* e = getenv("MYO_PRIO"); return e ? atoi(e) : 2; }();
       hipLaunchKernelGGL(balance_kernel, dim3(1), dim3(1024), 0, s, (const int*)b->db.diag, Bn, b->d_order, Bn / 4, prio_mode);
       order = b->d_order;
     }
     SchedDev S{b->d_sched, b->d_sched + 32, b->sched_stride, nsub + (wk ? 1 : 0)};
     if (!kflags)   // instantiation chosen below, as rocprofv3 prints it (bench.py reports it next to the kernel time)
-      b->last_kernel = sched ? (m->wave_cfg == 0 ? "step_kernel_w<24,8,32,1,4,true,0,false>" : m->dw.hf.on ? "step_kernel_w<36,20,32,2,2,true,3,true>" : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,true,2,false>" : "step_kernel_w<36,20,32,2,2,true,0,false>"))
+      b->last_kernel = m->wave_cfg == 2 ? "step_kernel_w<36,20,32,2,2,false,0,false,true>" : sched ? (m->wave_cfg == 0 ? "step_kernel_w<24,8,32,1,4,true,0,false>" : m->dw.hf.on ? "step_kernel_w<36,20,32,2,2,true,3,true>" : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,true,2,false>" : "step_kernel_w<36,20,32,2,2,true,0,false>"))
                              : (m->wave_cfg == 0 ? (m->hand_sizes ? "step_kernel_w<24,8,32,1,4,false,1,false>" : "step_kernel_w<24,8,32,1,4,false,0,false>")
                                                  : (m->dw.hf.on ? (m->terrain_sizes ? "step_kernel_w<36,20,32,2,2,false,3,true>" : "step_kernel_w<36,20,32,2,2,false,0,true>") : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,false,2,false>" : "step_kernel_w<36,20,32,2,2,false,0,false>")));
     if (sched) {
       hipLaunchKernelGGL(sched_init_kernel, dim3(1), dim3(1024), 0, s, (const int*)b->db.diag, Bn, S);
       int grid = Bn < resident ? Bn : resident;    // persistent waves: no more workgroups than the chip holds at once
-      static int grid_override = -1;
-      if (grid_override < 0) { const char* e = getenv("MYO_SCHED_GRID"); grid_override = e ? atoi(e) : 0; }
+      static const int grid_override = [] { const char* e = getenv("MYO_SCHED_GRID"); return e ? atoi(e) : 0; }();
       if (grid_override > 0 && grid_override < grid) grid = grid_override;
       if (m->wave_cfg == 0)
         hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, true, 0>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
@@ -689,7 +709,10 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
       else
         hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, true, 0>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                            (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, (const int*)nullptr, wk, 0, S);
-    } else if (m->wave_cfg == 0 && m->hand_sizes)
+    } else if (m->wave_cfg == 2)   // TrackEnv model class
+      hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, false, 0, false, true>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, wk, kflags, S);
+    else if (m->wave_cfg == 0 && m->hand_sizes)
       hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, false, 1>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                          (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0, S);
     else if (m->wave_cfg == 0)

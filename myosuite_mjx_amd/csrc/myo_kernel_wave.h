@@ -38,6 +38,7 @@ struct DevModelW {
   HfDev hf;                       // (kept last: the field offsets of the tables above feed the hot loops' scalar loads)
   const int *link_free, *dof_qposadr, *eq_i, *link_chain_adr, *link_chain;
   const float* eq_f;
+  const float *fl, *mesh_vert;    // TRK models: friction-loss rows [nv][4] = loss, D, B, -; hull vertices of the mesh geoms
 };
 
 __device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
@@ -263,7 +264,9 @@ template <int SPEC> static bool sizes_match(int nq, int nv, int nu, int nl, int 
          ncg == Z::ncg && npair == Z::npair;
 }
 
-template <int NVT, int KC, int NC, int NTR, int WPE, bool SCHED, int SPEC, bool HF = false>
+// TRK (MyoDM TrackEnv model class): condim-4 contacts (6 pyramid rows, a 4th jacobian row for the spin about the normal), joint friction-loss
+// rows, box / convex-hull shapes in the narrow phase.  All of it sits behind `if constexpr (TRK)`: the other instantiations compile as before.
+template <int NVT, int KC, int NC, int NTR, int WPE, bool SCHED, int SPEC, bool HF = false, bool TRK = false>
 __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restrict__ Mp, const DevModelW* __restrict__ Wp, DevBatch Bt,
                                                         const float* __restrict__ action, int actmap, int nsub, long long* stamps,
                                                         const int* __restrict__ order, const DevWalk* __restrict__ wk, int kflags, SchedDev S) {
@@ -295,6 +298,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   const int nl_ = SPEC ? Z::nl : M.nl, nlevel_ = SPEC ? Z::nlevel : M.nlevel, maxnnz_ = SPEC ? Z::maxnnz : M.maxnnz, ngt_ = SPEC ? Z::nu : M.ngt,
             nseg_ = SPEC ? Z::nseg : M.nseg, ncg_ = SPEC ? Z::ncg : M.ncg, npair_ = SPEC ? Z::npair : M.npair;
   constexpr int CDW = (KC + 3) / 4;   // ints per contact holding its KC byte-packed dof ids
+  constexpr int NJ = TRK ? 4 : 3;     // jacobian rows per contact: normal, two tangents (, spin about the normal)
+  constexpr int NR = TRK ? 6 : 4;     // pyramid rows per contact
   // the small instantiation (hand / finger class) is compiled without the free-joint, equality, plane-contact and condim-1 code;
   // myo_model_load routes any model that needs one of those to the large instantiation
   constexpr bool FULL = NVT > 24;
@@ -468,6 +473,12 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         for (int k = 0; k < 9; k++) E[Y.lmat + 9 * l + k] = R[k];
       }
       SYNC();
+    }
+    if constexpr (TRK) {   // link frames of the last substep's position stage (MYO_F_LINKX), world coordinates
+      if (Bt.linkx && step == nsub - 1) {
+        float* o = Bt.linkx + (size_t)env * 12 * nl_;
+        for (int i = lane; i < 12 * nl_; i += 64) { const int l = i / 12, k = i - 12 * l; o[i] = k < 3 ? E[Y.lpos + 3 * l + k] + M.origin[k] : E[Y.lmat + 9 * l + (k - 3)]; }
+      }
     }
     // reference point of the spatial (6-D) quantities: fixed for fixed-base models, the root link's origin for free-floating ones
     const float c0[3] = {has_free ? E[Y.lpos] : M.c0[0], has_free ? E[Y.lpos + 1] : M.c0[1], has_free ? E[Y.lpos + 2] : M.c0[2]};
@@ -814,6 +825,20 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             float bound = cgrb(g1) + cgrb(g2) + M.pair_f[12 * p];
             if (FULL && P[4] >= 2) hit = dot3(dif, E + Y.gax + 3 * g1) <= cgrb(g2) + M.pair_f[12 * p];   // plane: signed distance of the bounding sphere
             else hit = dot3(dif, dif) <= bound * bound;
+            if constexpr (TRK) {
+              // a box (table top: bounding sphere 0.7 m) is tested as a box: distance from the other geom's centre to the box, in the box frame
+              const int t1 = M.cg_type[g1], t2 = M.cg_type[g2];
+              if (hit && (t1 == 6 || t2 == 6) && P[4] == 0) {
+                const int gb = t1 == 6 ? g1 : g2, go = t1 == 6 ? g2 : g1;
+                float Rb[9], cl[3], dd[3] = {E[Y.gpos + 3 * go] - E[Y.gpos + 3 * gb], E[Y.gpos + 3 * go + 1] - E[Y.gpos + 3 * gb + 1], E[Y.gpos + 3 * go + 2] - E[Y.gpos + 3 * gb + 2]};
+                geom_world_mat(M, Y, E, gb, Rb);
+                matTvec(cl, Rb, dd);
+                const float* sb = M.cg_size + 3 * gb;
+                const float ex = fmaxf(fabsf(cl[0]) - sb[0], 0.f), ey = fmaxf(fabsf(cl[1]) - sb[1], 0.f), ez = fmaxf(fabsf(cl[2]) - sb[2], 0.f);
+                const float lim = M.cg_rbound[go] + M.pair_f[12 * p];
+                hit = ex * ex + ey * ey + ez * ez <= lim * lim;
+              }
+            }
             if (hit && !P[4]) {
               // conservative refinement before the expensive MPR: replace a capsule's bounding sphere by the distance
               // from the other geom's centre to the capsule's SEGMENT (a bound on the true distance, never excludes a contact)
@@ -847,7 +872,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
                     const int g = side ? g2 : g1;
                     const float* sz = cgsz(g);
                     const int ty = M.cg_type[g];
-                    if (ty == GEOM_CAPSULE) wsum += sz[0] + sz[1] * fabsf(dot3(E + Y.gax + 3 * g, ax));
+                    if (TRK && ty >= 6) wsum += 1e9f;   // box / hull: no cheap support width here, the pair goes to MPR
+                    else if (ty == GEOM_CAPSULE) wsum += sz[0] + sz[1] * fabsf(dot3(E + Y.gax + 3 * g, ax));
                     else if (ty == GEOM_SPHERE) wsum += sz[0];
                     else {
                       float R[9], dl[3];
@@ -944,6 +970,26 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
               hit2 = true; dist2 = dB;
 #pragma unroll
               for (int k = 0; k < 3; k++) cpos2[k] = eB[k] + x1[k] - n[k] * (r + 0.5f * dB);
+            }
+          } else if (FULL && TRK && P[4] == 5) {   // plane - convex hull: deepest vertex along -normal (one contact)
+            const float* n = E + Y.gax + 3 * g1;
+            float R2[9], nl[3], pw[3];
+            geom_world_mat(M, Y, E, g2, R2);
+            matTvec(nl, R2, n);
+            const float* V = W.mesh_vert + 3 * (int)sz2[0];
+            const int nvx = (int)sz2[1];
+            float best = 1e30f, bx = 0.f, by = 0.f, bz = 0.f;
+            for (int i = 0; i < nvx; i++) { const float x = V[3 * i], y = V[3 * i + 1], z = V[3 * i + 2], t = x * nl[0] + y * nl[1] + z * nl[2]; if (t < best) { best = t; bx = x; by = y; bz = z; } }
+            const float sp[3] = {bx, by, bz};
+            matvec(pw, R2, sp);
+            float rel[3] = {x2[0] - x1[0] + pw[0], x2[1] - x1[1] + pw[1], x2[2] - x1[2] + pw[2]};
+            float d = dot3(rel, n);
+#pragma unroll
+            for (int k = 0; k < 3; k++) nrm[k] = n[k];
+            if (d <= margin) {
+              hit = true; dist = d;
+#pragma unroll
+              for (int k = 0; k < 3; k++) cpos[k] = x2[k] + pw[k] - n[k] * 0.5f * d;
             }
           } else if (FULL && P[4] == 3) {   // plane - ellipsoid (mjc_PlaneConvex): deepest support point along -normal
             const float* n = E + Y.gax + 3 * g1;
@@ -1044,7 +1090,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             for (int k = 0; k < 9; k++) o1.mat[k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
 #pragma unroll
             for (int k = 0; k < 3; k++) o1.pos[k] = 0.f;
-            cobj_shape(o1, M.cg_type[g1], sz1); cobj_shape(o2, M.cg_type[g2], sz2);
+            if constexpr (TRK) { cobj_shape_poly(o1, M.cg_type[g1], sz1, W.mesh_vert); cobj_shape_poly(o2, M.cg_type[g2], sz2, W.mesh_vert); }
+            else { cobj_shape(o1, M.cg_type[g1], sz1); cobj_shape(o2, M.cg_type[g2], sz2); }
             o1.margin = o2.margin = 0.5f * margin;
             float depth, dir[3], pos[3], nw[3] = {0.f, 0.f, 0.f};
             bool have_nw = false;
@@ -1052,7 +1099,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
               if (((const int*)(E + Y.mprw))[4 * i] == p) { nw[0] = E[Y.mprw + 4 * i + 1]; nw[1] = E[Y.mprw + 4 * i + 2]; nw[2] = E[Y.mprw + 4 * i + 3]; have_nw = true; }
             }
             // portal witnesses in per-lane LDS scratch: the contact-jacobian area of region X, not written before the rows stage
-            if (mpr_penetration_wl(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr, E + Y.cJ + 9 * lane)) {
+            if (mpr_penetration_wl<TRK ? 2 : 0>(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr, E + Y.cJ + 9 * lane)) {
               dist = margin - depth;
               normalize3(dir);
               mpr_hit = true; mpr_n[0] = dir[0]; mpr_n[1] = dir[1]; mpr_n[2] = dir[2];
@@ -1143,7 +1190,10 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         }
       }
     }
-    float caref[4] = {0, 0, 0, 0}, cD = 0.f, cmu = 0.f;
+    float caref[NR], cD = 0.f, cmu = 0.f;
+#pragma unroll
+    for (int k = 0; k < NR; k++) caref[k] = 0.f;
+    float cmut = 0.f, cD2 = 0.f;   // TRK: torsional coefficient and the weight of the two torsional rows (0 for a condim-3 contact)
     int ckc = 0;
     // (generic lambda: instantiated once with LDS pointers and once with the HBM overflow row, so that each copy keeps its own address space)
     auto build_row = [&](const float* pdist, const float* ppos, const float* pnrm, const int* ppair, float* cJ, unsigned int* cdw) {
@@ -1163,14 +1213,14 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           cross3(t2, n, t1);
         }
       }
-      float vn = 0, vt1 = 0, vt2 = 0;
+      float vn = 0, vt1 = 0, vt2 = 0, vs = 0;
       unsigned int dpk[CDW];
 #pragma unroll
       for (int k = 0; k < CDW; k++) dpk[k] = 0;
       ckc = P[3];
 #pragma unroll
       for (int k = 0; k < KC; k++) {
-        float jn = 0, j1 = 0, j2 = 0;
+        float jn = 0, j1 = 0, j2 = 0, js = 0;
         int d = 0;
         if (k < ckc) {
           d = M.pair_dl[2 * (P[2] + k)];
@@ -1184,8 +1234,10 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           jn = sg * dot3(n, col); j1 = sg * dot3(t1, col); j2 = sg * dot3(t2, col);
           float qv = E[Y.qvel + d];
           vn += jn * qv; vt1 += j1 * qv; vt2 += j2 * qv;
+          if constexpr (TRK) { js = M.dof_type[d] == 3 ? sg * dot3(n, ax) : 0.f; vs += js * qv; }   // relative angular velocity about the normal
         }
         cJ[k] = jn; cJ[KC + k] = j1; cJ[2 * KC + k] = j2;
+        if constexpr (TRK) cJ[3 * KC + k] = js;
         dpk[k >> 2] |= (unsigned int)d << (8 * (k & 3));   // padded entries: zero jacobian, dof 0
       }
 #pragma unroll
@@ -1205,14 +1257,28 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       float pos = -K * imp * (dist - incl);
       caref[0] = -B * (vn + cmu * vt1) + pos; caref[1] = -B * (vn - cmu * vt1) + pos;
       caref[2] = -B * (vn + cmu * vt2) + pos; caref[3] = -B * (vn - cmu * vt2) + pos;
+      if constexpr (TRK) {
+        if (P[5] == 4) { cmut = F[11]; cD2 = cD; caref[4] = -B * (vn + cmut * vs) + pos; caref[5] = -B * (vn - cmut * vs) + pos; }
+      }
     };
     if (lane < ncon) {
-      if (lane < NC) build_row(E + Y.cdist + lane, E + Y.cpos + 3 * lane, E + Y.cnrm + 3 * lane, (const int*)(E + Y.cpair) + lane, E + Y.cJ + lane * 3 * KC,
+      if (lane < NC) build_row(E + Y.cdist + lane, E + Y.cpos + 3 * lane, E + Y.cnrm + 3 * lane, (const int*)(E + Y.cpair) + lane, E + Y.cJ + lane * NJ * KC,
                                (unsigned int*)(E + Y.cdofs) + CDW * lane);
-      else { float* g = ovf_env + (lane - NC) * ovf_row; build_row(g, g + 1, g + 4, (const int*)g + 7, g + 8, (unsigned int*)(g + 8 + 3 * KC)); }
+      else { float* g = ovf_env + (lane - NC) * ovf_row; build_row(g, g + 1, g + 4, (const int*)g + 7, g + 8, (unsigned int*)(g + 8 + NJ * KC)); }
     }
     // efc row count as MuJoCo reports it: 4 pyramid rows per condim-3 contact, 1 per frictionless (condim-1) contact
     int nefc = __popcll(__ballot(lsign != 0.f)) + 4 * ncon - 3 * __popcll(__ballot(lane < ncon && cmu == 0.f));
+    // TRK: friction-loss rows (mj_instantiateFriction): lane = dof, J = e_dof, aref = -B qvel; force saturates at +-f outside |jar| < f / D
+    float flf = 0.f, flD = 0.f, flaref = 0.f, fljar = 0.f, fljv = 0.f, flrf = 0.f;
+    if constexpr (TRK) {
+      nefc += 2 * __popcll(__ballot(lane < ncon && cD2 != 0.f));
+      if (lane < nv) {
+        const float* FL = W.fl + 4 * lane;
+        flf = FL[0];
+        if (flf > 0.f) { flD = FL[1]; flaref = -FL[2] * E[Y.qvel + lane]; flrf = flf / flD; }
+      }
+      nefc += __popcll(__ballot(flf > 0.f));
+    }
     const int ncon_real = ncon;
     if (W.has_tl) {
       // an active tendon limit becomes a frictionless pseudo-contact: jacobian = +-(sparse tendon row), mu = 0 and D/4 on each
@@ -1242,7 +1308,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       unsigned long long bal = __ballot(tact);
       int slot = nt + __popcll(bal & ((1ull << lane) - 1ull));
       if (tact && slot < NC) {
-        float* cJ = E + Y.cJ + slot * 3 * KC;
+        float* cJ = E + Y.cJ + slot * NJ * KC;
         unsigned int dpk[CDW];
 #pragma unroll
         for (int k = 0; k < CDW; k++) dpk[k] = 0;
@@ -1253,6 +1319,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           float jv = d >= 0 ? t_sign * E[Y.tJp + gt * maxnnz_ + k] : 0.f;
           if (d >= 0) kc = k + 1; else d = 0;
           cJ[k] = jv; cJ[KC + k] = 0.f; cJ[2 * KC + k] = 0.f;
+          if constexpr (TRK) cJ[3 * KC + k] = 0.f;
           dpk[k >> 2] |= (unsigned int)d << (8 * (k & 3));
         }
 #pragma unroll
@@ -1265,7 +1332,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       SYNC();
       if (lane >= ncon && lane < nt) {
         float a = E[Y.cdist + lane];
-        caref[0] = caref[1] = caref[2] = caref[3] = a;
+        caref[0] = caref[1] = caref[2] = caref[3] = a;   // (TRK: cD2 stays 0 for these rows)
         cD = 0.25f * E[Y.cpos + 3 * lane]; cmu = 0.f; ckc = (int)E[Y.cpos + 3 * lane + 1];
       }
       nefc += nt - ncon;
@@ -1305,23 +1372,30 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     // ---------------------------------------------------------------- solver: Newton iterations, then the Euler solve, sharing ONE
     // instance of the unrolled register Cholesky.  phase 0 = Newton, 1 = unconstrained (nefc == 0), 2 = Euler (implicit damping)
     float Ma = 0.f, grad = 0.f, qfc = 0.f, ljar = 0.f, ljv = 0.f, cost = 0.f, qaccE = 0.f;
-    float cjar[4] = {0, 0, 0, 0}, cjv[4] = {0, 0, 0, 0};
+    float cjar[NR], cjv[NR];
+#pragma unroll
+    for (int k = 0; k < NR; k++) { cjar[k] = 0.f; cjv[k] = 0.f; }
     int phase = nefc > 0 ? 0 : 1, iters = 0;
     if (phase == 0) {  // start from the warm start (MuJoCo also tries qacc_smooth; the minimiser is the same)
       qacc = warm;
       Ma = symv_lds<NVT>(Mp, qacc, lane, nv);
       ljar = lsign * qacc - laref;
+      if constexpr (TRK) fljar = qacc - flaref;
       if (lane < nv) E[Y.xv + lane] = qacc;
       SYNC();
       auto row_jar = [&](const float* cJ, const unsigned int* cdw) {
-        float an = 0, a1 = 0, a2 = 0;
+        float an = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
-        for (int k = 0; k < KC; k++) { float xv = E[Y.xv + CDOFP(cdw, k)]; an += cJ[k] * xv; a1 += cJ[KC + k] * xv; a2 += cJ[2 * KC + k] * xv; }
+        for (int k = 0; k < KC; k++) {
+          float xv = E[Y.xv + CDOFP(cdw, k)]; an += cJ[k] * xv; a1 += cJ[KC + k] * xv; a2 += cJ[2 * KC + k] * xv;
+          if constexpr (TRK) a3 += cJ[3 * KC + k] * xv;
+        }
         cjar[0] = an + cmu * a1 - caref[0]; cjar[1] = an - cmu * a1 - caref[1]; cjar[2] = an + cmu * a2 - caref[2]; cjar[3] = an - cmu * a2 - caref[3];
+        if constexpr (TRK) { cjar[4] = an + cmut * a3 - caref[4]; cjar[5] = an - cmut * a3 - caref[5]; }
       };
       if (lane < ncon) {
-        if (lane < NC) row_jar(E + Y.cJ + lane * 3 * KC, (const unsigned int*)(E + Y.cdofs) + CDW * lane);
-        else { const float* g = ovf_env + (lane - NC) * ovf_row; row_jar(g + 8, (const unsigned int*)(g + 8 + 3 * KC)); }
+        if (lane < NC) row_jar(E + Y.cJ + lane * NJ * KC, (const unsigned int*)(E + Y.cdofs) + CDW * lane);
+        else { const float* g = ovf_env + (lane - NC) * ovf_row; row_jar(g + 8, (const unsigned int*)(g + 8 + NJ * KC)); }
       }
       if (eact) ejar = E[Y.xv + ed1] + eJ2 * E[Y.xv + ed2] - earef;
     }
@@ -1340,17 +1414,28 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         bool lact = lsign != 0.f && ljar < 0;
         float w0 = cjar[0] < 0 ? cD : 0.f, w1 = cjar[1] < 0 ? cD : 0.f, w2 = cjar[2] < 0 ? cD : 0.f, w3 = cjar[3] < 0 ? cD : 0.f;
         float f0 = -w0 * cjar[0], f1 = -w1 * cjar[1], f2 = -w2 * cjar[2], f3 = -w3 * cjar[3];
-        if (lane < nv) E[Y.qfc + lane] = lact ? -lsign * lD * ljar : 0.f;
+        float w4 = 0.f, w5 = 0.f, f4 = 0.f, f5 = 0.f, flforce = 0.f, flcost = 0.f;
+        bool flquad = false;
+        if constexpr (TRK) {
+          w4 = cjar[4] < 0 ? cD2 : 0.f; w5 = cjar[5] < 0 ? cD2 : 0.f;
+          f4 = -w4 * cjar[4]; f5 = -w5 * cjar[5];
+          if (flf > 0.f) {
+            if (fljar <= -flrf) { flforce = flf; flcost = flf * (-0.5f * flrf - fljar); }
+            else if (fljar >= flrf) { flforce = -flf; flcost = flf * (-0.5f * flrf + fljar); }
+            else { flforce = -flD * fljar; flcost = 0.5f * flD * fljar * fljar; flquad = true; }
+          }
+        }
+        if (lane < nv) E[Y.qfc + lane] = (lact ? -lsign * lD * ljar : 0.f) + flforce;
         SYNC();
         if (lane < ncon) {
-          float Fn = f0 + f1 + f2 + f3, Ft1 = cmu * (f0 - f1), Ft2 = cmu * (f2 - f3);
+          float Fn = f0 + f1 + f2 + f3 + f4 + f5, Ft1 = cmu * (f0 - f1), Ft2 = cmu * (f2 - f3), Ft3 = cmut * (f4 - f5);
           if (lane < NC) {
-            const float* cJ = E + Y.cJ + lane * 3 * KC;
-            for (int k = 0; k < ckc; k++) atomicAdd(&E[Y.qfc + CDOF(E, Y, lane, k)], Fn * cJ[k] + Ft1 * cJ[KC + k] + Ft2 * cJ[2 * KC + k]);
+            const float* cJ = E + Y.cJ + lane * NJ * KC;
+            for (int k = 0; k < ckc; k++) atomicAdd(&E[Y.qfc + CDOF(E, Y, lane, k)], Fn * cJ[k] + Ft1 * cJ[KC + k] + Ft2 * cJ[2 * KC + k] + (TRK ? Ft3 * cJ[(NJ - 1) * KC + k] : 0.f));
           } else {
             const float* cJ = ovf_env + (lane - NC) * ovf_row + 8;
-            const unsigned int* cdw = (const unsigned int*)(cJ + 3 * KC);
-            for (int k = 0; k < ckc; k++) atomicAdd(&E[Y.qfc + CDOFP(cdw, k)], Fn * cJ[k] + Ft1 * cJ[KC + k] + Ft2 * cJ[2 * KC + k]);
+            const unsigned int* cdw = (const unsigned int*)(cJ + NJ * KC);
+            for (int k = 0; k < ckc; k++) atomicAdd(&E[Y.qfc + CDOFP(cdw, k)], Fn * cJ[k] + Ft1 * cJ[KC + k] + Ft2 * cJ[2 * KC + k] + (TRK ? Ft3 * cJ[(NJ - 1) * KC + k] : 0.f));
           }
         }
         if (eact) { float f = -eD * ejar; atomicAdd(&E[Y.qfc + ed1], f); atomicAdd(&E[Y.qfc + ed2], eJ2 * f); }
@@ -1359,6 +1444,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         float cst = lact ? 0.5f * lD * ljar * ljar : 0.f;
         cst += 0.5f * eD * ejar * ejar;
         cst += 0.5f * (w0 * cjar[0] * cjar[0] + w1 * cjar[1] * cjar[1] + w2 * cjar[2] * cjar[2] + w3 * cjar[3] * cjar[3]);
+        if constexpr (TRK) cst += 0.5f * (w4 * cjar[4] * cjar[4] + w5 * cjar[5] * cjar[5]) + flcost;
         cst += 0.5f * qacc * Ma - qacc * smooth;          // Gauss term up to a constant
         float newcost = wave_sum(cst);
         grad = Ma - smooth - qfc;
@@ -1377,19 +1463,22 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         SUB(0);
         if (phase == 0) {
           // H = M + J^T D J depends on the state only through the set of active rows: same set as last time -> same factor
-          const int sig = (lact ? 1 : 0) | (w0 != 0.f ? 2 : 0) | (w1 != 0.f ? 4 : 0) | (w2 != 0.f ? 8 : 0) | (w3 != 0.f ? 16 : 0);
+          const int sig = (lact ? 1 : 0) | (w0 != 0.f ? 2 : 0) | (w1 != 0.f ? 4 : 0) | (w2 != 0.f ? 8 : 0) | (w3 != 0.f ? 16 : 0) |
+                          (TRK ? ((w4 != 0.f ? 32 : 0) | (w5 != 0.f ? 64 : 0) | (flquad ? 128 : 0)) : 0);
           refactor = first || __any(sig != sig_prev);
           sig_prev = sig;
           if (refactor) {
             f_fact++;
             WFOR(i, NVT * (NVT + 1)) E[Y.sq + i] = 0;
             SYNC();
-            if (lane < nv && lact) E[Y.sq + lane * (NVT + 1) + lane] = lD;
-            float Wn = w0 + w1 + w2 + w3, A1 = cmu * (w0 - w1), A2 = cmu * (w2 - w3), B1 = cmu * cmu * (w0 + w1), B2 = cmu * cmu * (w2 + w3);
+            if (lane < nv && (lact || flquad)) E[Y.sq + lane * (NVT + 1) + lane] = (lact ? lD : 0.f) + (flquad ? flD : 0.f);
+            float Wn = w0 + w1 + w2 + w3 + w4 + w5, A1 = cmu * (w0 - w1), A2 = cmu * (w2 - w3), B1 = cmu * cmu * (w0 + w1), B2 = cmu * cmu * (w2 + w3);
+            const float A3 = cmut * (w4 - w5), B3 = cmut * cmut * (w4 + w5);
             SYNC();
             for (int c = 0; c < ncon; c++) {   // one contact per step, lanes = entries of its kc x kc block
               int kc = rdlanei(ckc, c);
               float sW = rdlane(Wn, c), sA1 = rdlane(A1, c), sA2 = rdlane(A2, c), sB1 = rdlane(B1, c), sB2 = rdlane(B2, c);
+              const float sA3 = TRK ? rdlane(A3, c) : 0.f, sB3 = TRK ? rdlane(B3, c) : 0.f;
               if (sW == 0.f) continue;
               auto hblock = [&](const float* cJ, const unsigned int* cdw) {
                 for (int t = lane; t < kc * kc; t += 64) {
@@ -1397,12 +1486,14 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
                   int da = CDOFP(cdw, a), db = CDOFP(cdw, b);
                   if (da >= db) {
                     float na = cJ[a], nb = cJ[b], ta = cJ[KC + a], tb = cJ[KC + b], ua = cJ[2 * KC + a], ub = cJ[2 * KC + b];
-                    atomicAdd(&E[Y.sq + da * (NVT + 1) + db], sW * na * nb + sA1 * (na * tb + ta * nb) + sA2 * (na * ub + ua * nb) + sB1 * ta * tb + sB2 * ua * ub);
+                    float hv = sW * na * nb + sA1 * (na * tb + ta * nb) + sA2 * (na * ub + ua * nb) + sB1 * ta * tb + sB2 * ua * ub;
+                    if constexpr (TRK) { const float sa = cJ[3 * KC + a], sb = cJ[3 * KC + b]; hv += sA3 * (na * sb + sa * nb) + sB3 * sa * sb; }
+                    atomicAdd(&E[Y.sq + da * (NVT + 1) + db], hv);
                   }
                 }
               };
-              if (c < NC) hblock(E + Y.cJ + c * 3 * KC, (const unsigned int*)(E + Y.cdofs) + CDW * c);
-              else { const float* g = ovf_env + (c - NC) * ovf_row; hblock(g + 8, (const unsigned int*)(g + 8 + 3 * KC)); }
+              if (c < NC) hblock(E + Y.cJ + c * NJ * KC, (const unsigned int*)(E + Y.cdofs) + CDW * c);
+              else { const float* g = ovf_env + (c - NC) * ovf_row; hblock(g + 8, (const unsigned int*)(g + 8 + NJ * KC)); }
             }
             if (eact) {
               atomicAdd(&E[Y.sq + ed1 * (NVT + 1) + ed1], eD);
@@ -1449,17 +1540,22 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       float search = lane < nv ? x : 0.f;
       float Mv = symv_lds<NVT>(Mp, search, lane, nv);
       ljv = lsign * search;
+      if constexpr (TRK) fljv = search;
       if (lane < nv) E[Y.xv + lane] = search;
       SYNC();
       auto row_jv = [&](const float* cJ, const unsigned int* cdw) {
-        float an = 0, a1 = 0, a2 = 0;
+        float an = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
-        for (int k = 0; k < KC; k++) { float xv = E[Y.xv + CDOFP(cdw, k)]; an += cJ[k] * xv; a1 += cJ[KC + k] * xv; a2 += cJ[2 * KC + k] * xv; }
+        for (int k = 0; k < KC; k++) {
+          float xv = E[Y.xv + CDOFP(cdw, k)]; an += cJ[k] * xv; a1 += cJ[KC + k] * xv; a2 += cJ[2 * KC + k] * xv;
+          if constexpr (TRK) a3 += cJ[3 * KC + k] * xv;
+        }
         cjv[0] = an + cmu * a1; cjv[1] = an - cmu * a1; cjv[2] = an + cmu * a2; cjv[3] = an - cmu * a2;
+        if constexpr (TRK) { cjv[4] = an + cmut * a3; cjv[5] = an - cmut * a3; }
       };
       if (lane < ncon) {
-        if (lane < NC) row_jv(E + Y.cJ + lane * 3 * KC, (const unsigned int*)(E + Y.cdofs) + CDW * lane);
-        else { const float* g = ovf_env + (lane - NC) * ovf_row; row_jv(g + 8, (const unsigned int*)(g + 8 + 3 * KC)); }
+        if (lane < NC) row_jv(E + Y.cJ + lane * NJ * KC, (const unsigned int*)(E + Y.cdofs) + CDW * lane);
+        else { const float* g = ovf_env + (lane - NC) * ovf_row; row_jv(g + 8, (const unsigned int*)(g + 8 + NJ * KC)); }
       }
       if (eact) ejv = E[Y.xv + ed1] + eJ2 * E[Y.xv + ed2];
       float g1 = wave_sum(search * (Ma - smooth)), g2 = wave_sum(0.5f * search * Mv), sn = sqrtf(wave_sum(search * search));
@@ -1473,6 +1569,16 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         p1 += eD * (ejar + a * ejv) * ejv; p2 += eD * ejv * ejv;
 #pragma unroll
         for (int k = 0; k < 4; k++) { float xx = cjar[k] + a * cjv[k]; if (xx < 0) { p1 += cD * xx * cjv[k]; p2 += cD * cjv[k] * cjv[k]; } }
+        if constexpr (TRK) {
+#pragma unroll
+          for (int k = 4; k < 6; k++) { float xx = cjar[k] + a * cjv[k]; if (xx < 0) { p1 += cD2 * xx * cjv[k]; p2 += cD2 * cjv[k] * cjv[k]; } }
+          if (flf > 0.f) {
+            const float xx = fljar + a * fljv;
+            if (xx <= -flrf) p1 -= flf * fljv;
+            else if (xx >= flrf) p1 += flf * fljv;
+            else { p1 += flD * xx * fljv; p2 += flD * fljv * fljv; }
+          }
+        }
         const float sp1 = wave_sum(p1);
         float d1 = sp1 + g1 + 2 * a * g2;
         float d2 = wave_sum(p2) + 2 * g2;
@@ -1505,8 +1611,9 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       SUB(5);
       if (!(alpha > 0)) { phase = 2; continue; }   // no descent left: keep qacc / qfc of this iterate
       qacc += alpha * search; Ma += alpha * Mv; ljar += alpha * ljv; ejar += alpha * ejv;
+      if constexpr (TRK) fljar += alpha * fljv;
 #pragma unroll
-      for (int k = 0; k < 4; k++) cjar[k] += alpha * cjv[k];
+      for (int k = 0; k < NR; k++) cjar[k] += alpha * cjv[k];
     }
     STAMP(7);
     d_nefc = nefc; d_ncon = ncon_real; d_iter = max(d_iter, iters);

@@ -286,7 +286,7 @@ __device__ __forceinline__ void make_frame(const float* n, float* t1, float* t2)
 //   ellipsoid S = semi-axes, h = 0 | sphere S = (r,r,r), h = 0 | capsule S = (r,r,r), h = half length | cylinder S = (r,r,0), h = half length.
 // One branch-free formula instead of a per-type switch: in a wave that mixes pad / capsule pairs every lane used to walk through all
 // the type branches of both shapes at each of the ~23 support evaluations of an MPR call.
-struct CObj { float pos[3], mat[9], S[3], h, margin; };  // by value: keeps everything in registers
+struct CObj { float pos[3], mat[9], S[3], h, margin; const float* verts; };  // by value: keeps everything in registers (verts: polytope kernels only)
 __device__ __forceinline__ void cobj_shape(CObj& o, int type, const float* size) {
   if (type == GEOM_ELLIPSOID) { o.S[0] = size[0]; o.S[1] = size[1]; o.S[2] = size[2]; o.h = 0.f; }
   else if (type == GEOM_CYLINDER) { o.S[0] = size[0]; o.S[1] = size[0]; o.S[2] = 0.f; o.h = size[1]; }
@@ -299,6 +299,26 @@ __device__ __forceinline__ void support_local(const float* S, float h, const flo
   float inv = n > MINVALF ? 1.0f / n : 0.f;
   pl[0] = S[0] * s[0] * inv; pl[1] = S[1] * s[1] * inv; pl[2] = S[2] * s[2] * inv + (dl[2] >= 0 ? h : -h);
 }
+// polytope shapes (TrackEnv kernels, MPR mode 2): h = -2: box with half sizes S; h = -3: convex hull, S[0] vertices at `verts` (support = best vertex)
+__device__ __forceinline__ void cobj_shape_poly(CObj& o, int type, const float* size, const float* mesh_vert) {
+  if (type == 6) { o.S[0] = size[0]; o.S[1] = size[1]; o.S[2] = size[2]; o.h = -2.f; o.verts = nullptr; }
+  else if (type == 7) { o.S[0] = size[1]; o.S[1] = o.S[2] = 0.f; o.h = -3.f; o.verts = mesh_vert + 3 * (int)size[0]; }
+  else { cobj_shape(o, type, size); o.verts = nullptr; }
+}
+template <int MODE> __device__ __forceinline__ void support_shape(const CObj& o, const float* dl, float* pl) {
+  if (MODE == 2 && o.h == -2.f) { pl[0] = dl[0] >= 0.f ? o.S[0] : -o.S[0]; pl[1] = dl[1] >= 0.f ? o.S[1] : -o.S[1]; pl[2] = dl[2] >= 0.f ? o.S[2] : -o.S[2]; return; }
+  if (MODE == 2 && o.h == -3.f) {
+    const int n = (int)o.S[0];
+    float bd = -1e30f, bx = 0.f, by = 0.f, bz = 0.f;
+    for (int i = 0; i < n; i++) {
+      const float x = o.verts[3 * i], y = o.verts[3 * i + 1], z = o.verts[3 * i + 2], t = x * dl[0] + y * dl[1] + z * dl[2];
+      if (t > bd) { bd = t; bx = x; by = y; bz = z; }
+    }
+    pl[0] = bx; pl[1] = by; pl[2] = bz;
+    return;
+  }
+  support_local(o.S, o.h, dl, pl);
+}
 struct Sup { float v[3], v1[3]; };  // Minkowski point and its witness on obj1 (the witness on obj2 is v1 - v)
 // Minkowski-difference support of the two margin-inflated shapes.  Contract of the wave kernel's caller: obj `a` sits in the
 // identity frame at the origin (the pair is expressed in geom 1's frame) and `dir` is a unit vector, so a's support needs no
@@ -306,10 +326,11 @@ struct Sup { float v[3], v1[3]; };  // Minkowski point and its witness on obj1 (
 // HF (height-field kernels only): obj `a` may instead be a triangular prism of the height field (mjc_ConvexHField's prism_support), marked by
 // a.h < 0 and stored in a's otherwise unused frame slots: a.mat = x[3] | y[3] | z_top[3] of the three columns, a.S[0] = z of the base;
 // only the bottom or the top triangle can be extremal, by the sign of dir_z.
-template <bool HF = false>
+// HF is an int mode: 0 smooth primitives, 1 (true) height-field prisms in `a`, 2 polytopes (box / convex hull) in `a` or `b`
+template <int HF = 0>
 __device__ void mink_support(const CObj& a, const CObj& b, const float* dir, Sup& s) {
   float nd[3] = {-dir[0], -dir[1], -dir[2]}, dl[3], pl[3], w2[3];
-  if (HF && a.h < 0.f) {
+  if (HF == 1 && a.h < 0.f) {
     const bool top = dir[2] >= 0.f;
     float d0 = dir[0] * a.mat[0] + dir[1] * a.mat[3], d1 = dir[0] * a.mat[1] + dir[1] * a.mat[4], d2 = dir[0] * a.mat[2] + dir[1] * a.mat[5];
     if (top) { d0 += dir[2] * a.mat[6]; d1 += dir[2] * a.mat[7]; d2 += dir[2] * a.mat[8]; }
@@ -323,9 +344,9 @@ __device__ void mink_support(const CObj& a, const CObj& b, const float* dir, Sup
     const float zt = w0 * a.mat[6] + w1 * a.mat[7] + w2 * a.mat[8];
     s.v1[2] = top ? zt : a.S[0];
   } else
-  support_local(a.S, a.h, dir, s.v1);
+  support_shape<HF>(a, dir, s.v1);
   matTvec(dl, b.mat, nd);
-  support_local(b.S, b.h, dl, pl);
+  support_shape<HF>(b, dl, pl);
   matvec(w2, b.mat, pl);
   const float m2 = a.margin + b.margin;
 #pragma unroll
@@ -353,7 +374,7 @@ __device__ __forceinline__ void expand_portal(Sup* p, const Sup& v4) {
 #ifndef MPR_WARM_EPS
 #define MPR_WARM_EPS 0.05f
 #endif
-template <bool HF>
+template <int HF>
 __device__ __forceinline__ bool mpr_penetration_t(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup = nullptr,
                                   const float* nwarm = nullptr) {
   Sup p[4];
@@ -470,7 +491,7 @@ __device__ __forceinline__ bool mpr_penetration_t(const CObj& o1, const CObj& o2
 // allocation around this call is sensitive to how it is inlined (67 vs 93 spilled VGPRs in the MyoHand kernel)
 __device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup = nullptr,
                                 const float* nwarm = nullptr) {
-  return mpr_penetration_t<false>(o1, o2, tol, maxit, depth, dirout, posout, nsup, nwarm);
+  return mpr_penetration_t<0>(o1, o2, tol, maxit, depth, dirout, posout, nsup, nwarm);
 }
 
 // Same algorithm with the portal's obj-1 witness points kept in LDS (wl: 9 floats of per-lane scratch) instead of registers: they are only
@@ -486,7 +507,7 @@ __device__ __forceinline__ void wl_swap(float* wl, int a, int b) {
 // addressable stack object -- memcpy between allocas -- and then lives in scratch memory instead of registers)
 #define V3SWAP(a, b) { float t0_ = a[0], t1_ = a[1], t2_ = a[2]; a[0] = b[0]; a[1] = b[1]; a[2] = b[2]; b[0] = t0_; b[1] = t1_; b[2] = t2_; }
 #define V3COPY(a, b) { a[0] = b[0]; a[1] = b[1]; a[2] = b[2]; }
-template <bool HF = false>
+template <int HF = 0>
 __device__ __forceinline__ bool mpr_penetration_wl(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup,
                                                    const float* nwarm, float* wl) {
   float p0[3], p1[3], p2[3], p3[3];

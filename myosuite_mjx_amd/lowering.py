@@ -22,7 +22,7 @@ import math
 
 import numpy as np
 
-from .mjcf import (GEOM_CAPSULE, GEOM_CYLINDER, GEOM_ELLIPSOID, GEOM_HFIELD, GEOM_PLANE, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE,
+from .mjcf import (GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_ELLIPSOID, GEOM_HFIELD, GEOM_MESH, GEOM_PLANE, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE,
                    WRAP_CYLINDER, WRAP_PULLEY, WRAP_SITE, WRAP_SPHERE, mat2quat, quat2mat, quat_mul)
 from . import setconst as sc
 
@@ -393,11 +393,12 @@ def lower(cm):
                 continue
             # not provably out of reach (e.g. a free object over the scene's floor / pedestal): a plane goes to the analytic plane
             # narrow phases, a static cylinder to the generic convex one (the kernel's geom frames accept world-fixed geoms)
-            plane_ok = m.geom_type[stat] == GEOM_PLANE and stat == g1 and m.geom_type[mov] in (GEOM_CAPSULE, GEOM_ELLIPSOID)
+            plane_ok = m.geom_type[stat] == GEOM_PLANE and stat == g1 and m.geom_type[mov] in (GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_MESH)
             cyl_ok = m.geom_type[stat] == GEOM_CYLINDER and m.geom_type[mov] in (GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_SPHERE, GEOM_CYLINDER)
             if not (plane_ok or cyl_ok):
                 raise NotImplementedError(f"HIP path: cannot prune static geom {stat} against moving geom {mov}")
-        ok = (GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_SPHERE, GEOM_CYLINDER)
+        has_hull = "mesh_vert" in A and len(A["mesh_vert"]) > 0
+        ok = (GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_SPHERE, GEOM_CYLINDER) + ((GEOM_BOX, GEOM_MESH) if has_hull else ())
         plane_pair = t1 == GEOM_PLANE
         hfield_pair = t1 == GEOM_HFIELD and t2 in ok and geom_link[g1] < 0      # world-fixed height field first (the compiler orders it so)
         if not plane_pair and not hfield_pair and (t1 not in ok or t2 not in ok):
@@ -418,15 +419,19 @@ def lower(cm):
         pidx = [k for k in range(len(m.pair_geom)) if m.pair_geom[k, 0] == g1 and m.pair_geom[k, 1] == g2][-1]
         if "pair_condim" in A and A["pair_condim"][pidx] > 0:
             condim = int(A["pair_condim"][pidx])
-        if condim not in (1, 3):
-            raise NotImplementedError("HIP path: condim must be 1 or 3")
+        if condim not in (1, 3, 4):
+            raise NotImplementedError("HIP path: condim must be 1, 3 or 4")
+        if plane_pair and t2 in (GEOM_BOX, GEOM_SPHERE, GEOM_CYLINDER):
+            raise NotImplementedError("HIP path: plane against a moving box / sphere / cylinder")
         b1, b2 = m.geom_bodyid[g1], m.geom_bodyid[g2]
         invw = m.body_invweight0[b1, 0] + m.body_invweight0[b2, 0]
         # narrow-phase type: 1 capsule-capsule (analytic), 2 plane-capsule, 3 plane-ellipsoid, 0 generic convex (MPR)
-        ptype = 1 if (t1 == GEOM_CAPSULE and t2 == GEOM_CAPSULE) else (2 if (plane_pair and t2 == GEOM_CAPSULE) else (3 if plane_pair else (4 if hfield_pair else 0)))
+        # 5 plane - convex hull (deepest vertex)
+        ptype = 1 if (t1 == GEOM_CAPSULE and t2 == GEOM_CAPSULE) else (2 if (plane_pair and t2 == GEOM_CAPSULE) else (
+            5 if (plane_pair and t2 == GEOM_MESH) else (3 if plane_pair else (4 if hfield_pair else 0))))
         pairs_i.append([cg_index(g1), cg_index(g2), len(pair_dl), len(lst), ptype, condim])
         pairs_f.append([margin, max(m.geom_gap[g1], m.geom_gap[g2]), fric[0], invw, solref[0], solref[1],
-                        solimp[0], solimp[1], solimp[2], solimp[3], solimp[4], 0.0])
+                        solimp[0], solimp[1], solimp[2], solimp[3], solimp[4], fric[1] if condim >= 4 else 0.0])   # last: torsional coefficient
         pair_dl += lst
     cgs = sorted(cg_ids, key=lambda g: cg_ids[g])
     maxkc = max([p[3] for p in pairs_i] + [1])
@@ -555,7 +560,31 @@ def lower(cm):
     A["hip_cg_type"] = m.geom_type[cgs] if cgs else np.zeros(0, np.int32)
     A["hip_cg_lpos"] = geom_lpos[cgs] if cgs else np.zeros((0, 3))
     A["hip_cg_lmat"] = geom_lmat[cgs] if cgs else np.zeros((0, 9))
-    A["hip_cg_size"] = m.geom_size[cgs] if cgs else np.zeros((0, 3))
+    cg_size = np.array(m.geom_size[cgs], float) if cgs else np.zeros((0, 3))
+    for k, g in enumerate(cgs):
+        if m.geom_type[g] == GEOM_MESH and "geom_meshadr" in A and A["geom_meshadr"][g] >= 0:
+            cg_size[k] = [float(A["geom_meshadr"][g]), float(A["geom_meshnum"][g]), 0.0]     # hull: first vertex, vertex count (exact in float32)
+    A["hip_cg_size"] = cg_size
+    A["hip_mesh_vert"] = np.asarray(A["mesh_vert"], float).reshape(-1, 3) if "mesh_vert" in A else np.zeros((0, 3))
+    # joint friction loss (mj_instantiateFriction): per dof [frictionloss, D = 1 / R, B] with R = (1 - d) / d * invweight at the row's
+    # constant position 0 (impedance = solimp[0]) and aref = -B * qvel
+    fl = np.zeros((nv, 4))
+    if "dof_frictionloss" in A:
+        for d in range(nv):
+            f = float(A["dof_frictionloss"][d])
+            if f <= 0:
+                continue
+            sr, si = A["dof_solref_fri"][d], A["dof_solimp_fri"][d]
+            imp = min(max(si[0], 1e-4), 0.9999)
+            dmax = min(max(si[1], 1e-4), 0.9999)
+            R = max(1e-15, (1 - imp) / imp * m.dof_invweight0[d])
+            if sr[0] <= 0:
+                raise NotImplementedError("HIP path: direct solref on friction loss")
+            tc = max(sr[0], 2 * float(A["opt"][0]))
+            fl[d] = [f, 1.0 / R, 2.0 / max(1e-15, dmax * tc), 0.0]
+    A["hip_fl"] = fl
+    A["hip_trk"] = np.array([int(any(p[5] >= 4 for p in pairs_i)), int((fl[:, 0] > 0).any()),
+                             int(any(m.geom_type[g] in (GEOM_BOX, GEOM_MESH) for g in cgs))], np.int32)
     A["hip_cg_rbound"] = m.geom_rbound[cgs] if cgs else np.zeros(0)
     A["hip_cg_geom"] = np.array(cgs, np.int32)
     A["hip_pair_i"] = np.array(pairs_i, np.int32).reshape(-1, PAIR_INTS)
