@@ -93,6 +93,32 @@ def rollout_multi(torch, env, nsteps, mode, stream, obs, staging, gather_async):
     return e0.elapsed_time(e1), kms
 
 
+def track_bench(args):
+    """Extra measurement (not the BASELINE headline): the MJX flavour's own env, MyoDM TrackEnv (mjx/myodm_v0.py) with its module-level
+    default reference, `--batch` envs, 5 substeps per env step, U(-1,1) actions; reward / done computed on the device each step."""
+    import torch
+    from myosuite_mjx_amd import capi
+    from myosuite_mjx_amd.track import TrackEnv
+    B = args.batch
+    env = TrackEnv(num_envs=B, seed=0, autoreset=True)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    acts = [torch.rand((B, env.act_dim), device="cuda", generator=g) * 2 - 1 for _ in range(8)]
+    for i in range(args.warmup):
+        env.step(acts[i % 8])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        env.step(acts[i % 8])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(json.dumps({"metric": f"env-steps/s MyoDM TrackEnv (myohand_object.xml + airplane) batch {B}", "value": B * args.steps / el, "unit": "env-steps/s",
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+                      "dtype": "f32", "data": "synthetic", "vs_baseline": None,
+                      "config": {"workload": f"TrackEnv default RANDOM reference, {B} envs, n_frames=5 (dt=0.01), U(-1,1) actions, reward/done in torch on the device, auto-reset on done"},
+                      "kernel": env.batch.last_kernel_name(), "flagged_envs": int((env.status() != 0).sum())}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,6 +130,8 @@ def main():
     ap.add_argument("--env", default=ENV_ID, help="env id (default: the BASELINE.json headline workload); other ids are extra measurements")
     args = ap.parse_args()
     env_id = args.env
+    if env_id == "MyoDM-TrackEnv":
+        return track_bench(args)
 
     import torch
     from myosuite_mjx_amd import capi
