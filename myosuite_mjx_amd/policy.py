@@ -2,8 +2,10 @@
 artefact -- brax PPO: running-statistics observation normalisation, swish MLP, tanh-normal head -- consuming the env's
 observation buffer and writing the action buffer `myo_step` reads, so a rollout never leaves the GPU.
 
-The reference's artefact is a pickle of jax/brax objects; it is never unpickled here (untrusted, and jax/brax are absent).  A
-maintainer exports it once, where brax is installed, with `tools/export_brax_policy.py` into the plain `.npz` this module loads:
+The reference's artefact is a pickle of jax/brax objects; it is never unpickled here (untrusted, and jax/brax are absent).  Its tensors
+are read either by `tools/extract_brax_policy.py` -- a symbolic walk of the pickle's opcodes that imports and executes nothing; the result
+for the reference's own artefact is committed as tests/golden/mjx_brax_policy.npz -- or, where brax is installed, by
+`tools/export_brax_policy.py`.  Both write the plain `.npz` this module loads:
     obs_mean[obs_dim], obs_std[obs_dim], w0[obs_dim,h], b0[h], ..., w{L-1}[h, 2*act_dim], b{L-1}[2*act_dim]   (float32)
 The shapes of `mjx_brax_policy` itself (read with pickletools): obs 2 -> 32 -> 32 -> 32 -> 32 -> 12 (6 actions).
 """

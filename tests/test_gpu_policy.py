@@ -62,3 +62,44 @@ def test_closed_loop_rollout_stays_on_device():
     torch.cuda.synchronize()
     assert torch.isfinite(tot).all() and torch.isfinite(obs).all()
     assert (env.status() == 0).all()
+
+
+def test_the_real_mjx_brax_policy_weights():
+    """the reference's own artefact `mjx_brax_policy` (obs 2 -> 4 x 32 -> 12, observation statistics over 102 400 samples),
+    its tensors extracted WITHOUT unpickling (tools/extract_brax_policy.py: symbolic opcode walk, fixture tests/golden/mjx_brax_policy.npz),
+    through myo_policy_act vs the float64 statement of the brax network; then the closed loop it was trained for, obs = [qpos, qvel] of the
+    one-dof six-muscle elbow -> six muscle excitations, on myoElbowPose1D6MRandom-v0 without leaving the device."""
+    import os
+    import torch
+    import myosuite_mjx_amd as myo
+    from myosuite_mjx_amd import capi
+    from myosuite_mjx_amd.policy import BraxPolicy, reference_forward
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mjx_brax_policy.npz")
+    z = np.load(path)
+    assert z["w0"].shape == (2, 32) and z["w4"].shape == (32, 12) and float(z["obs_count"]) == 102400.0
+    pol = BraxPolicy.from_npz(path)
+    assert (pol.obs_dim, pol.act_dim) == (2, 6)
+    rng = np.random.default_rng(0)
+    B = 4096
+    obs_np = (z["obs_mean"] + 3 * z["obs_std"] * rng.normal(0, 1, (B, 2))).astype(np.float32)
+    obs = torch.as_tensor(obs_np, device="cuda")
+    act = torch.empty((B, 6), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    pol.act(obs.data_ptr(), B, act.data_ptr(), deterministic=True, stream=st)
+    torch.cuda.synchronize()
+    ks, bs = [z[f"w{i}"] for i in range(5)], [z[f"b{i}"] for i in range(5)]
+    ref, loc, scale = reference_forward(obs_np, z["obs_mean"], z["obs_std"], ks, bs)
+    assert np.abs(act.cpu().numpy() - ref).max() < 2e-5 and np.ptp(ref) > 0.5          # a trained, non-trivial map
+    env = myo.make("myoElbowPose1D6MRandom-v0", num_envs=256)
+    assert env.act_dim == 6 and env.mjmodel.nq == 1
+    env.reset(seed=0)
+    a = torch.empty((256, 6), dtype=torch.float32, device="cuda")
+    lo, hi = float(env.mjmodel.jnt_range[0, 0]), float(env.mjmodel.jnt_range[0, 1])
+    for k in range(60):
+        o2 = torch.cat((env.view(capi.F_QPOS), env.view(capi.F_QVEL)), 1).contiguous()   # the policy's observation: [qpos, qvel]
+        pol.act(o2.data_ptr(), 256, a.data_ptr(), deterministic=False, seed=3, step=k, stream=st)
+        obs_env, rew, done, trunc, info = env.step(a)
+        assert float(a.abs().max()) <= 1.0
+    torch.cuda.synchronize()
+    q = env.view(capi.F_QPOS)[:, 0]
+    assert torch.isfinite(q).all() and float(q.min()) > lo - 0.1 and float(q.max()) < hi + 0.1 and (env.status() == 0).all()
