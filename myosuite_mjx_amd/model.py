@@ -59,6 +59,21 @@ class Model:
     def name2id(self, kind, name):
         return self.names[kind].index(name)
 
+    # mujoco_py-style accessors the reference patches onto MjModel (physics/mj_sim_scene.py:110-163)
+    def _n2i(self, kind, name):
+        if kind not in self.names or name not in self.names[kind]:
+            raise ValueError('No {} with name "{}" exists.'.format(kind, name))
+        return self.names[kind].index(name)
+
+    def body_name2id(self, name): return self._n2i("body", name)
+    def geom_name2id(self, name): return self._n2i("geom", name)
+    def site_name2id(self, name): return self._n2i("site", name)
+    def joint_name2id(self, name): return self._n2i("joint", name)
+    def actuator_name2id(self, name): return self._n2i("actuator", name)
+    def tendon_name2id(self, name): return self._n2i("tendon", name)
+    def camera_name2id(self, name): return self._n2i("camera", name)      # (cameras / sensors are not compiled: always "No camera ...")
+    def sensor_name2id(self, name): return self._n2i("sensor", name)
+
     def blob(self) -> bytes:
         if self._blob is None:
             self._blob = _blob.pack(self.arrays)

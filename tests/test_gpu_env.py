@@ -142,33 +142,63 @@ def test_functional_mjx_style_api(hand):
     assert (myo.get(d, "act") > 0).all()
 
 
-def test_hip_sim_scene_mirrors_the_backend_abc(hand, oracle64):
+@pytest.mark.parametrize("as_torch", [True, False])
+def test_hip_sim_scene_mirrors_the_backend_abc(hand, oracle64, as_torch, tmp_path):
     """HipSimScene = batched `SimScene` (physics/sim_scene.py:38-209): advance / forward / reset / get_state / set_state,
-    checked like Robot.step drives it (data.ctrl[:] = ...; sim.advance(n_frames)) against the oracle."""
+    checked like Robot.step drives it (data.ctrl[:] = ...; sim.advance(n_frames)) against the oracle -- with device-resident `data`
+    (zero-copy torch views: advance is only the launch) and with host mirrors; plus the rest of the ABC (copy_model, save_binary,
+    get_mjlib / get_handle, disable_option_context, model.*_name2id of mj_sim_scene.py:110-163)."""
+    import torch
     import myosuite_mjx_amd as myo
     B = 6
-    sim = myo.HipSimScene("myohand_pose", num_envs=B)
-    assert abs(sim.step_duration - 0.002) < 1e-9 and sim.init_qpos.shape == (23,) and sim.data.qpos.shape == (B, 23)
+    sim = myo.HipSimScene("myohand_pose", num_envs=B, as_torch=as_torch)
+    assert abs(sim.step_duration - 0.002) < 1e-9 and sim.init_qpos.shape == (23,) and tuple(sim.data.qpos.shape) == (B, 23)
+    npy = (lambda t: t.cpu().numpy()) if as_torch else (lambda a: a)
     rng = np.random.default_rng(0)
     lo, hi = hand.jnt_range[:, 0], hand.jnt_range[:, 1]
     q = (0.5 * (lo + hi) + 0.4 * (hi - lo) * rng.uniform(-1, 1, (B, 23))).astype(np.float32)
     v = rng.normal(0, 0.3, (B, 23)).astype(np.float32)
     a = rng.uniform(0, 1, (B, 39)).astype(np.float32)
     sim.set_state(time=np.zeros((B, 1)), qpos=q, qvel=v, act=a)
-    sim.data.ctrl[:] = rng.uniform(0, 1, (B, 39))
+    ctrl = rng.uniform(0, 1, (B, 39)).astype(np.float32)
+    sim.data.ctrl[:] = torch.as_tensor(ctrl, device="cuda") if as_torch else ctrl
+    if as_torch:
+        p0 = sim.data.qpos.data_ptr()
     sim.advance(substeps=10)
-    assert (sim.last_flags == 0).all() and np.allclose(sim.data.time, 0.02, atol=1e-6)
+    assert (sim.status() == 0).all() and np.allclose(npy(sim.data.time), 0.02, atol=1e-6)
+    if as_torch:
+        assert sim.data.qpos.data_ptr() == p0 and sim.data.qpos.is_cuda          # the same device buffer, no copies around the step
     st = sim.get_state()
     for e in range(B):
         oracle64.reset()
-        oracle64.set_state(qpos=q[e], qvel=v[e], act=a[e], ctrl=sim.data.ctrl[e])
+        oracle64.set_state(qpos=q[e], qvel=v[e], act=a[e], ctrl=ctrl[e])
         oracle64.step(10)
-        assert np.abs(oracle64.field("qpos") - st["qpos"][e]).max() < 1e-4
-        assert np.abs(oracle64.field("qvel") - st["qvel"][e]).max() < 2e-2
-    sim.reset()
-    assert np.allclose(sim.data.qpos, hand.qpos0) and not sim.data.qvel.any() and not sim.data.time.any()
+        assert np.abs(oracle64.field("qpos") - npy(st["qpos"])[e]).max() < 1e-4
+        assert np.abs(oracle64.field("qvel") - npy(st["qvel"])[e]).max() < 2e-2
+    # disable_option_context(limits / contact) switches the model for the block only
+    sim.set_state(qpos=np.tile(hi + 0.05, (B, 1)), qvel=np.zeros((B, 23)))
+    with sim.disable_option_context(limits=True, contact=True):
+        sim.advance(1)
+        free = npy(sim.data.qacc).copy()
+    sim.set_state(qpos=np.tile(hi + 0.05, (B, 1)), qvel=np.zeros((B, 23)), time=np.zeros((B, 1)))
     sim.advance(1)
-    assert np.isfinite(sim.data.qpos).all()
+    assert np.abs(npy(sim.data.qacc) - free).max() > 10.0                        # with limits on, the violated joints are pushed back
+    sim.reset()
+    assert np.allclose(npy(sim.data.qpos), hand.qpos0) and not npy(sim.data.qvel).any() and not npy(sim.data.time).any()
+    sim.advance(1)
+    assert np.isfinite(npy(sim.data.qpos)).all()
+    # the rest of the ABC
+    m2 = sim.copy_model()
+    assert m2 is not sim.model and np.array_equal(m2.jnt_range, sim.model.jnt_range) and m2.blob() == sim.model.blob()
+    path = sim.save_binary(str(tmp_path / "hand.mjb"))
+    assert path.endswith(".myob") and open(path, "rb").read() == sim.model.blob()
+    assert sim.get_mjlib() is sim.lib and hasattr(sim.lib, "myo_step") and sim.get_handle(sim._batch) == sim._batch.h
+    assert sim.model.joint_name2id("mcp2_flexion") == hand.name2id("joint", "mcp2_flexion") and sim.model.site_name2id("IFtip") >= 0
+    assert sim.model.actuator_name2id("FDS2") == hand.name2id("actuator", "FDS2") and sim.model.body_name2id("lunate") > 0
+    with pytest.raises(ValueError):
+        sim.model.camera_name2id("hand_side_inter")
+    sim.renderer.refresh_window()
+    sim.close()
 
 
 def test_every_registered_env_id_resets_steps_and_is_deterministic():
