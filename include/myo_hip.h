@@ -130,6 +130,11 @@ typedef struct myo_walk_config {
   float knee_height;                                           /* > 0: also done when COM height - mean feet height < this (0.61, :660-671) */
   int terrain;                                                 /* myo_terrain: elevation grid re-drawn at every reset of an env (:563-622) */
   float terrain_scalar_lo, terrain_scalar_hi;                  /* hilly / stairs height scale ~ U(lo, hi); variant "fixed": lo == hi */
+  /* reset_type "random" (WalkEnvV0.get_randomized_initial_state, walk_v0.py:316-332): with probability 1/2 the alternative keyframe
+   * (init = key 2, alt = key 3), then qpos += N(0, reset_noise_std) on every coordinate except the root height and quaternion */
+  const float* init_qpos_alt;                                  /* host, nq floats or NULL (reset_type "init") */
+  const float* init_qvel_alt;                                  /* host, nv floats or NULL */
+  float reset_noise_std;                                       /* 0.02 in the reference */
 } myo_walk_config;
 typedef enum myo_terrain { MYO_TERRAIN_NONE = 0, MYO_TERRAIN_ROUGH = 1, MYO_TERRAIN_HILLY = 2, MYO_TERRAIN_STAIRS = 3 } myo_terrain;
 
@@ -150,6 +155,10 @@ int myo_batch_configure_walk(myo_batch*, const myo_walk_config* cfg);
 /* muscle conditions (envs/myo/base_v0.py:61-80): time step of the fatigue model (frame_skip * timestep) and the actuator ids of
  * the EIP -> EPL tendon transfer (-1: none).  Sarcopenia is a model edit (peak force of gainprm halved) made before myo_model_load. */
 int myo_batch_set_condition(myo_batch*, int frame_skip, int epl_actuator, int eip_actuator);
+/* fatigue state at reset (CumulativeFatigue.reset, envs/myo/fatigue.py:114-134; BaseV0 kwargs fatigue_reset_vec / fatigue_reset_random,
+ * base_v0.py:30-31,120-127): mode 0 all rested (MA 0, MR 1, MF 0); 1 random (u1, u2 ~ U(0,1): MA = u1 u2, MR = u1 (1 - u2), MF = 1 - u1);
+ * 2 a given fatigue vector (host, nu floats; MF = vec, MR = 1 - vec, MA = 0) */
+int myo_batch_set_fatigue_reset(myo_batch*, int mode, const float* fatigue_vec);
 /* per-env size of ONE collision geom (compiled-model geom id), as ObjHoldRandomEnvV0.reset edits model.geom_size per episode
  * (envs/myo/myobase/obj_hold_v0.py:122-140): every reset of an env draws size ~ U(lo, hi) per axis; mass and inertia are untouched, as in
  * the reference (the model is not recompiled).  lo == hi == NULL switches the override off.  Generic large-kernel models only. */

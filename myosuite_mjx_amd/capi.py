@@ -49,7 +49,8 @@ class WalkConfig(C.Structure):
                 ("qadr_hip_flexion_l", C.c_int), ("qadr_hip_flexion_r", C.c_int), ("qadr_joint_angle", C.c_int * 4),
                 ("w_vel_reward", C.c_float), ("w_done", C.c_float), ("w_cyclic_hip", C.c_float), ("w_ref_rot", C.c_float),
                 ("w_joint_angle_rew", C.c_float), ("init_qpos", C.POINTER(C.c_float)), ("init_qvel", C.POINTER(C.c_float)),
-                ("knee_height", C.c_float), ("terrain", C.c_int), ("terrain_scalar_lo", C.c_float), ("terrain_scalar_hi", C.c_float)]
+                ("knee_height", C.c_float), ("terrain", C.c_int), ("terrain_scalar_lo", C.c_float), ("terrain_scalar_hi", C.c_float),
+                ("init_qpos_alt", C.POINTER(C.c_float)), ("init_qvel_alt", C.POINTER(C.c_float)), ("reset_noise_std", C.c_float)]
 
 
 TERRAIN_NONE, TERRAIN_ROUGH, TERRAIN_HILLY, TERRAIN_STAIRS = 0, 1, 2, 3
@@ -127,6 +128,7 @@ def lib():
         L.myo_batch_configure_walk.argtypes = [C.c_void_p, C.POINTER(WalkConfig)]
         L.myo_obs_reset_only.argtypes = [C.c_void_p, C.c_void_p]
         L.myo_batch_set_condition.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.myo_batch_set_fatigue_reset.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -207,7 +209,8 @@ class HipBatch:
         _chk(lib().myo_batch_configure(self.h, C.byref(c)))
 
     def configure_walk(self, *, frame_skip, hip_period, min_height, max_rot, target_x_vel, target_y_vel, target_rot, bodies, qadr_hip_flexion,
-                       qadr_joint_angle, weights, init_qpos, init_qvel=None, knee_height=0.0, terrain=0, terrain_scalar=(0.0, 0.0)):
+                       qadr_joint_angle, weights, init_qpos, init_qvel=None, knee_height=0.0, terrain=0, terrain_scalar=(0.0, 0.0),
+                       init_qpos_alt=None, init_qvel_alt=None, reset_noise_std=0.0):
         """walk task (WalkEnvV0).  bodies = (talus_l, talus_r, pelvis, torso) body ids; weights = (vel_reward, done, cyclic_hip,
         ref_rot, joint_angle_rew)."""
         c = WalkConfig()
@@ -224,10 +227,20 @@ class HipBatch:
         c.init_qvel = iv.ctypes.data_as(C.POINTER(C.c_float)) if iv is not None else None
         c.knee_height, c.terrain = float(knee_height), int(terrain)
         c.terrain_scalar_lo, c.terrain_scalar_hi = float(terrain_scalar[0]), float(terrain_scalar[1])
+        iq2 = np.ascontiguousarray(init_qpos_alt, np.float32) if init_qpos_alt is not None else None
+        iv2 = np.ascontiguousarray(init_qvel_alt, np.float32) if init_qvel_alt is not None else None
+        c.init_qpos_alt = iq2.ctypes.data_as(C.POINTER(C.c_float)) if iq2 is not None else None
+        c.init_qvel_alt = iv2.ctypes.data_as(C.POINTER(C.c_float)) if iv2 is not None else None
+        c.reset_noise_std = float(reset_noise_std)
         _chk(lib().myo_batch_configure_walk(self.h, C.byref(c)))
 
     def set_condition(self, frame_skip, epl_actuator=-1, eip_actuator=-1):
         _chk(lib().myo_batch_set_condition(self.h, int(frame_skip), int(epl_actuator), int(eip_actuator)))
+
+    def set_fatigue_reset(self, mode=0, vec=None):
+        """Fatigue compartments at reset: 0 rested, 1 random (fatigue_reset_random), 2 `vec` (fatigue_reset_vec); fatigue.py:114-134."""
+        v = np.ascontiguousarray(vec, np.float32) if vec is not None else None
+        _chk(lib().myo_batch_set_fatigue_reset(self.h, int(mode), v.ctypes.data_as(C.c_void_p) if v is not None else None))
 
     def set_geom_override(self, geom_id, size_lo=None, size_hi=None):
         """Per-env size of one collision geom, re-drawn ~ U(lo, hi) at every reset of an env (None: off)."""

@@ -105,6 +105,10 @@ struct TaskDev {
   float tip_lpos[3];        // stand task: tip site in the root link's frame
   int gsize_type;           // per-env geom size override: geom type (0: off), size ~ U(gsize_lo, gsize_hi) per axis at every reset
   float gsize_lo[3], gsize_hi[3];
+  const float *init_qpos_alt, *init_qvel_alt;   // walk reset_type "random": second keyframe (NULL: off) ...
+  float reset_noise_std;                        // ... and the std of the normal noise on qpos (root height / quaternion excepted)
+  int fatigue_mode;                             // fatigue compartments at reset: 0 rested, 1 random, 2 vector
+  const float* fatigue_vec;
   int terrain, hf_n;        // terrain walk: myo_terrain kind and cells of the elevation grid re-drawn at reset (0: none)
   float terrain_lo, terrain_hi;
 };

@@ -65,6 +65,7 @@ struct myo_batch {
   std::vector<void*> dev_allocs;
   float *d_tlo = nullptr, *d_thi = nullptr, *d_init = nullptr, *d_jlo = nullptr, *d_jhi = nullptr, *d_action = nullptr, *d_rnd = nullptr;
   float* d_initv = nullptr;
+  float *d_init2 = nullptr, *d_initv2 = nullptr, *d_fatvec = nullptr;   // walk reset "random": second keyframe; fatigue reset vector
   const char* last_kernel = "step_kernel";   // name of the step-kernel instantiation of the last myo_step / bench launch
   DevWalk* d_walk = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -373,7 +374,7 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
     BA(d.ovf, (size_t)B * NCX * d.ovf_row) BA(d.ovf_cand, (size_t)B * NCANDX)
   }
   if (m->dw.hf.on) { BA(d.hfield, (size_t)B * m->dw.hf.nrow * m->dw.hf.ncol) }   // zero-filled: flat terrain at the geom's height
-  BA(b->d_initv, nv)
+  BA(b->d_initv, nv) BA(b->d_init2, nq) BA(b->d_initv2, nv) BA(b->d_fatvec, nu)
   { void* pw = nullptr; if ((rc = balloc(b, &pw, sizeof(DevWalk)))) { myo_batch_free(b); return rc; } b->d_walk = (DevWalk*)pw; }
   BA(b->d_stamps, (size_t)B * 12 * 2 * 2)      // 2 x 12 long long per workgroup (diagnostic build)
   BA(b->d_order, B)
@@ -397,6 +398,7 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   b->task.task = MYO_TASK_NONE; b->task.frame_skip = 1; b->task.obs_dim = 0; b->task.ntarget = 0;
   b->task.jnt_lo = b->d_jlo; b->task.jnt_hi = b->d_jhi; b->task.init_qpos = b->d_init; b->task.target_lo = b->d_tlo; b->task.target_hi = b->d_thi;
   b->task.init_qvel = nullptr;
+  b->task.init_qpos_alt = nullptr; b->task.init_qvel_alt = nullptr; b->task.reset_noise_std = 0.f; b->task.fatigue_mode = 0; b->task.fatigue_vec = nullptr;
   HIPCHK(hipEventCreate(&b->ev0));
   HIPCHK(hipEventCreate(&b->ev1));
   *out = b;
@@ -521,6 +523,12 @@ int myo_batch_configure_walk(myo_batch* b, const myo_walk_config* c) {
   T.task = MYO_TASK_WALK; T.frame_skip = c->frame_skip; T.reset_random = 0; T.target_generate = 0; T.ntarget = 0; T.ntip = 0;
   T.obs_dim = w.obs_dim;
   T.init_qvel = c->init_qvel ? b->d_initv : nullptr;
+  T.init_qpos_alt = nullptr; T.init_qvel_alt = nullptr; T.reset_noise_std = 0.f;
+  if (c->init_qpos_alt) {
+    HIPCHK(hipMemcpy(b->d_init2, c->init_qpos_alt, (size_t)nq * 4, hipMemcpyHostToDevice));
+    T.init_qpos_alt = b->d_init2; T.reset_noise_std = c->reset_noise_std;
+    if (c->init_qvel_alt) { HIPCHK(hipMemcpy(b->d_initv2, c->init_qvel_alt, (size_t)nv * 4, hipMemcpyHostToDevice)); T.init_qvel_alt = b->d_initv2; }
+  }
   T.terrain = c->terrain; T.hf_n = c->terrain ? m->dw.hf.nrow * m->dw.hf.ncol : 0; T.terrain_lo = c->terrain_scalar_lo; T.terrain_hi = c->terrain_scalar_hi;
   return MYO_OK;
 }
@@ -782,6 +790,14 @@ int myo_batch_set_condition(myo_batch* b, int frame_skip, int epl_actuator, int 
   if (epl_actuator >= nu || eip_actuator >= nu) return fail(MYO_E_ARG, "myo_batch_set_condition: actuator id out of range");
   b->db.fat_dt = (float)frame_skip * b->model->dm.timestep;
   b->db.reaf_epl = epl_actuator; b->db.reaf_eip = eip_actuator;
+  return MYO_OK;
+}
+
+int myo_batch_set_fatigue_reset(myo_batch* b, int mode, const float* fatigue_vec) {
+  if (!b || mode < 0 || mode > 2 || (mode == 2 && !fatigue_vec)) return fail(MYO_E_ARG, "myo_batch_set_fatigue_reset: mode 0 / 1 / 2 (+ vector)");
+  HIPCHK(hipSetDevice(b->model->device));
+  if (mode == 2) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipMemcpy(b->d_fatvec, fatigue_vec, (size_t)b->model->dm.nu * 4, hipMemcpyHostToDevice)); }
+  b->task.fatigue_mode = mode; b->task.fatigue_vec = mode == 2 ? b->d_fatvec : nullptr;
   return MYO_OK;
 }
 

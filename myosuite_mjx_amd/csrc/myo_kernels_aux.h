@@ -134,8 +134,14 @@ __device__ __forceinline__ bool reset_body(const DevBatch& Bt, const TaskDev& T,
   __syncthreads();                                            // every lane has read done / elapsed / episode before lane 0 updates them
   if (lane == 0) { Bt.episode[e] += 1; Bt.elapsed[e] = 0; Bt.done[e] = 0.f; Bt.time[e] = 0; }
   uint64_t ge = (uint64_t)(e + env_offset);
+  // walk reset_type "random" (walk_v0.py:316-332): one coin per episode picks the keyframe
+  const bool alt = T.init_qpos_alt && u01(seed ^ 0xA24BAED4963EE407ull, ge, 6) >= 0.5f;
   for (int i = lane; i < nq; i += 64) {
-    float q = T.init_qpos ? T.init_qpos[i] : qpos0[i];
+    float q = alt ? T.init_qpos_alt[i] : (T.init_qpos ? T.init_qpos[i] : qpos0[i]);
+    if (T.init_qpos_alt && T.reset_noise_std > 0.f && !(i >= 2 && i <= 6)) {   // every coordinate but the root height and quaternion
+      const float u1 = fmaxf(u01(seed ^ 0x9FB21C651E98DF25ull, ge * 4096 + i, 7), 1e-7f), u2 = u01(seed ^ 0x2545F4914F6CDD1Dull, ge * 4096 + i, 7);
+      q += T.reset_noise_std * sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+    }
     if (T.reset_random) q = T.jnt_lo[i] + (T.jnt_hi[i] - T.jnt_lo[i]) * u01(seed, ge * 4096 + i, 1);   // nq == nv checked at configure
     else if (T.rnd) {   // init + U(noise), clipped (walk_v0.py:152-167)
       const float nl = T.rnd[i], nh = T.rnd[nq + i];
@@ -144,13 +150,18 @@ __device__ __forceinline__ bool reset_body(const DevBatch& Bt, const TaskDev& T,
     Bt.qpos[(size_t)e * nq + i] = q;
   }
   for (int i = lane; i < nv; i += 64) {
-    Bt.qvel[(size_t)e * nv + i] = T.init_qvel ? T.init_qvel[i] : 0.f;
+    Bt.qvel[(size_t)e * nv + i] = (alt && T.init_qvel_alt) ? T.init_qvel_alt[i] : (T.init_qvel ? T.init_qvel[i] : 0.f);
     Bt.warm[(size_t)e * nv + i] = 0;
   }
   for (int i = lane; i < nu; i += 64) {
     Bt.act[(size_t)e * nu + i] = 0; Bt.ctrl[(size_t)e * nu + i] = 0;
     // fatigue compartments: all motor units resting (CumulativeFatigue.reset defaults, fatigue.py:130-134)
-    Bt.fatigue[(size_t)e * 3 * nu + i] = 0.f; Bt.fatigue[(size_t)e * 3 * nu + nu + i] = 1.f; Bt.fatigue[(size_t)e * 3 * nu + 2 * nu + i] = 0.f;
+    float MA = 0.f, MR = 1.f, MF = 0.f;
+    if (T.fatigue_mode == 1) {   // fatigue_reset_random (fatigue.py:115-122)
+      const float nf = u01(seed ^ 0x94D049BB133111EBull, ge * 4096 + i, 8), ap = u01(seed ^ 0xBF58476D1CE4E5B9ull, ge * 4096 + i, 8);
+      MA = nf * ap; MR = nf * (1.f - ap); MF = 1.f - nf;
+    } else if (T.fatigue_mode == 2 && T.fatigue_vec) { MF = T.fatigue_vec[i]; MR = 1.f - MF; }   // fatigue_reset_vec (:124-130)
+    Bt.fatigue[(size_t)e * 3 * nu + i] = MA; Bt.fatigue[(size_t)e * 3 * nu + nu + i] = MR; Bt.fatigue[(size_t)e * 3 * nu + 2 * nu + i] = MF;
   }
   for (int i = lane; i < T.ntarget; i += 64) {
     float lo = T.target_lo[i], hi = T.target_hi[i];

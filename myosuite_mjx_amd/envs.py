@@ -173,13 +173,20 @@ class BatchedMyoEnv:
     are reset in place and the returned obs row is the first observation of the new episode.
     """
 
-    def __init__(self, env_id, num_envs=1, device=0, seed=0, env_offset=0, autoreset=True, as_torch=True):
+    # env kwargs of the reference that gym.make forwards to the env class and that are honoured here (others raise)
+    ENV_KWARGS = ("reset_type", "fatigue_reset_random", "fatigue_reset_vec")
+
+    def __init__(self, env_id, num_envs=1, device=0, seed=0, env_offset=0, autoreset=True, as_torch=True, **env_kwargs):
         if env_id in UNSUPPORTED:
             raise NotImplementedError(f"{env_id}: {UNSUPPORTED[env_id]}")
         if env_id not in REGISTRY:
             raise KeyError(f"unknown env id {env_id!r}; known: {sorted(REGISTRY)}")
         self.id = env_id
-        self.spec = spec = REGISTRY[env_id]
+        self.spec = spec = dict(REGISTRY[env_id])
+        for k, v in env_kwargs.items():
+            if k not in self.ENV_KWARGS:
+                raise TypeError(f"{env_id}: unsupported env kwarg {k!r} (supported: {self.ENV_KWARGS})")
+            spec[k] = v
         self.num_envs = int(num_envs)
         self.device = device
         self.seed = int(seed)
@@ -208,9 +215,10 @@ class BatchedMyoEnv:
             key_qpos = np.asarray(m.key_qpos).reshape(-1, m.nq)
             key_qvel = np.asarray(m.key_qvel).reshape(-1, m.nv)
             # walk_v0.py:254 init_qpos = key_qpos[0] (the reference orientation of ref_rot); reset "init" starts from keyframe 2
-            # (walk_v0.py:339-349), "random" is host-side only in the reference and not offered here
-            if spec["reset_type"] != "init":
-                raise NotImplementedError("myoLegWalk: only reset_type='init' (keyframe 2) is implemented")
+            # (walk_v0.py:339-349), "random" from keyframe 2 or 3 with N(0, 0.02) noise (:316-332; drawn by the reset kernel)
+            if spec["reset_type"] not in ("init", "random"):
+                raise NotImplementedError("myoLegWalk: reset_type 'init' (keyframe 2) or 'random' (walk_v0.py:316-332)")
+            rnd = spec["reset_type"] == "random"
             jadr = lambda n: int(m.jnt_qposadr[m.name2id("joint", n)])
             self.batch.configure_walk(
                 frame_skip=self.frame_skip, hip_period=spec["hip_period"], min_height=spec["min_height"], max_rot=spec["max_rot"],
@@ -222,7 +230,8 @@ class BatchedMyoEnv:
                 weights=[w[k] for k in ("vel_reward", "done", "cyclic_hip", "ref_rot", "joint_angle_rew")],
                 init_qpos=key_qpos[2], init_qvel=key_qvel[2], knee_height=spec.get("knee_height", 0.0),
                 terrain={"rough": capi.TERRAIN_ROUGH, "hilly": capi.TERRAIN_HILLY, "stairs": capi.TERRAIN_STAIRS}.get(spec.get("terrain"), capi.TERRAIN_NONE),
-                terrain_scalar=spec.get("terrain_scalar", (0.0, 0.0)))
+                terrain_scalar=spec.get("terrain_scalar", (0.0, 0.0)),
+                init_qpos_alt=key_qpos[3] if rnd else None, init_qvel_alt=key_qvel[3] if rnd else None, reset_noise_std=0.02 if rnd else 0.0)
             self.obs_dim = (m.nq - 2) + m.nv + 16 + 4 * m.nu
         elif spec["task"] == "stand":
             from .mjcf import quat2mat
@@ -275,6 +284,17 @@ class BatchedMyoEnv:
         if self.muscle_condition == "fatigue":                         # base_v0.py:70-74, 100-104
             self.actmap = capi.ACTMAP_SIGMOID_FATIGUE
             self.batch.set_condition(self.frame_skip)
+            if spec.get("fatigue_reset_random"):                       # base_v0.py:30-31, 120-127 -> fatigue.py:114-134
+                if spec.get("fatigue_reset_vec") is not None:
+                    raise AssertionError("Cannot use 'fatigue_reset_vec' if fatigue_reset_random=False.")   # the reference's own (oddly worded) assertion
+                self.batch.set_fatigue_reset(1)
+            elif spec.get("fatigue_reset_vec") is not None:
+                vec = np.asarray(spec["fatigue_reset_vec"], np.float32)
+                if len(vec) != m.n_muscle:
+                    raise AssertionError(f"Invalid length of initial/reset fatigue vector (expected {m.n_muscle}, but obtained {len(vec)}).")
+                full = np.zeros(m.nu, np.float32)
+                full[np.asarray(m.actuator_kind) == 0] = vec
+                self.batch.set_fatigue_reset(2, full)
         elif self.muscle_condition == "reafferentation":               # base_v0.py:76-80, 105-109
             self.actmap = capi.ACTMAP_SIGMOID_REAFFERENTATION
             self.batch.set_condition(self.frame_skip, m.name2id("actuator", "EPL"), m.name2id("actuator", "EIP"))

@@ -80,3 +80,32 @@ def test_sarcopenia_halves_active_force_and_matches_oracle(hand):
     o2 = Oracle(hand.blob())
     o2.reset(); o2.set_state(qpos=st["qpos"][0], qvel=st["qvel"][0], act=st["act"][0], ctrl=ctrl[0]); o2.step(env.frame_skip)
     assert np.abs(o2.field("qpos") - post["qpos"][0]).max() > 1e-3
+
+
+def test_fatigue_reset_options(hand):
+    """BaseV0's fatigue_reset_random / fatigue_reset_vec kwargs (base_v0.py:30-31,120-127 -> CumulativeFatigue.reset, fatigue.py:114-134):
+    random: MA = u1 u2, MR = u1 (1 - u2), MF = 1 - u1 per muscle (compartments sum to 1, MF ~ U(0,1)); vector: MF = vec, MR = 1 - vec, MA = 0;
+    default: all rested."""
+    import myosuite_mjx_amd as myo
+    from myosuite_mjx_amd import capi
+    nu = hand.nu
+    env = myo.make("myoFatiHandPoseFixed-v0", num_envs=512, fatigue_reset_random=True, as_torch=False)
+    env.reset(seed=3)
+    F = env.batch.read(capi.F_FATIGUE).reshape(512, 3, nu)
+    MA, MR, MF = F[:, 0], F[:, 1], F[:, 2]
+    assert np.abs(MA + MR + MF - 1).max() < 1e-6 and MA.min() >= 0 and MR.min() >= 0 and MF.min() >= 0
+    assert abs(MF.mean() - 0.5) < 0.01 and abs(MF.std() - 12 ** -0.5) < 0.01            # MF = 1 - u1 ~ U(0,1)
+    assert abs(MA.mean() - 0.25) < 0.01 and abs((MA / (MA + MR)).mean() - 0.5) < 0.01   # MA = u1 u2, the active share u2 ~ U(0,1)
+    vec = np.linspace(0.1, 0.9, nu).astype(np.float32)
+    env2 = myo.make("myoFatiHandPoseFixed-v0", num_envs=4, fatigue_reset_vec=vec, as_torch=False)
+    env2.reset(seed=0)
+    F2 = env2.batch.read(capi.F_FATIGUE).reshape(4, 3, nu)
+    assert np.allclose(F2[:, 2], vec) and np.allclose(F2[:, 1], 1 - vec) and not F2[:, 0].any()
+    env3 = myo.make("myoFatiHandPoseFixed-v0", num_envs=4, as_torch=False)
+    env3.reset(seed=0)
+    F3 = env3.batch.read(capi.F_FATIGUE).reshape(4, 3, nu)
+    assert not F3[:, 0].any() and (F3[:, 1] == 1).all() and not F3[:, 2].any()
+    with pytest.raises(AssertionError):
+        myo.make("myoFatiHandPoseFixed-v0", num_envs=4, fatigue_reset_vec=vec[:5])
+    with pytest.raises(TypeError):
+        myo.make("myoFatiHandPoseFixed-v0", num_envs=4, no_such_kwarg=1)

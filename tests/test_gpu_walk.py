@@ -145,3 +145,25 @@ def test_leg_stand_env(legs):
     edge = (np.abs(d - 0.05) < 1e-5) | (np.abs(d - 0.1) < 1e-5) | (np.abs(d - 0.44) < 1e-5)
     assert np.allclose(rwd.cpu().numpy()[~edge], ref[~edge], atol=2e-4) and np.array_equal(term.cpu().numpy()[~edge], (d > 0.44)[~edge])
     assert (env.status() == 0).all()
+
+
+def test_walk_reset_type_random(legs):
+    """WalkEnvV0.get_randomized_initial_state (walk_v0.py:316-332): keyframe 2 or 3 with probability 1/2 each, qpos += N(0, 0.02) on every
+    coordinate except the root height and quaternion, qvel of the chosen keyframe."""
+    import myosuite_mjx_amd as myo
+    from myosuite_mjx_amd import capi
+    B = 2048
+    env = myo.make("myoLegWalk-v0", num_envs=B, reset_type="random", as_torch=False)
+    env.reset(seed=11)
+    q, v = env.batch.read(capi.F_QPOS), env.batch.read(capi.F_QVEL)
+    kq, kv = np.asarray(legs.key_qpos).reshape(-1, legs.nq), np.asarray(legs.key_qvel).reshape(-1, legs.nv)
+    is3 = np.abs(v - kv[3]).max(1) < 1e-6
+    is2 = np.abs(v - kv[2]).max(1) < 1e-6
+    assert (is2 | is3).all() and abs(is3.mean() - 0.5) < 0.04                   # one of the two keyframes, half each
+    base = np.where(is3[:, None], kq[3], kq[2])
+    d = q - base
+    assert np.abs(d[:, 2:7]).max() < 1e-6                                       # height and orientation untouched
+    noisy = np.r_[0, 1, 7:legs.nq]
+    assert abs(d[:, noisy].std() - 0.02) < 0.001 and abs(d[:, noisy].mean()) < 0.001
+    obs, rew, term, trunc, info = env.step(np.zeros((B, env.act_dim), np.float32))
+    assert np.isfinite(obs).all() and (env.status() == 0).all()
