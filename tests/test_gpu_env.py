@@ -308,6 +308,65 @@ def test_bench_two_rank_rehearsal():
     assert d["allgather_ms_rank0"] > 0 and d["allgather_bytes_out"] == 1024 * 108 * 4          # gather time reported separately
 
 
+def test_bench_one_rank_under_torchrun_matches_the_plain_run():
+    """`python bench.py --gpus 1` and the driver's N > 1 launcher form with one process (torchrun --nproc-per-node 1) run
+    the same code path and print the same line (workload, kernel, batch, contract keys); only the clocks differ."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = [os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--batch", "512", "--no-cpu-baseline"]
+    plain = subprocess.run([sys.executable] + args, cwd=root, capture_output=True, text=True, timeout=300)
+    tr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                         "--master-port", "29519"] + args, cwd=root, capture_output=True, text=True, timeout=300)
+    assert plain.returncode == 0 and tr.returncode == 0, plain.stderr[-1500:] + tr.stderr[-1500:]
+    a, b = (json.loads([ln for ln in o.stdout.splitlines() if ln.startswith('{"metric"')][-1]) for o in (plain, tr))
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "dtype", "data", "vs_baseline", "flagged_envs"):
+        assert a[k] == b[k], k
+    assert a["config"]["workload"] == b["config"]["workload"] and a["config"]["global_batch"] == b["config"]["global_batch"] == 512
+    assert a["roofline"]["kernel"] == b["roofline"]["kernel"] and set(a) == set(b) and "allgather_ms_rank0" not in b
+    assert 0.5 < a["value"] / b["value"] < 2.0
+
+
+def test_overlapped_gather_at_the_eight_gpu_buffer_size():
+    """The N = 8 shape of bench.rollout_multi on one GPU: 4096 envs per rank, the gathered observation buffer of 8 x 4096 x 108 floats
+    (14.2 MB, SURVEY 8d config 4 quotes 15.1 MB for the 115-wide reach observation) filled by a stand-in collective that writes this rank's
+    slot on a side stream while the next step kernel runs; the loop never waits on the host and ends with the last step's observations."""
+    import importlib.util, os, torch
+    from myosuite_mjx_amd import capi
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    B, world, rank = 4096, 8, 5
+    env = _make("myoHandPoseRandom-v0", B, seed=5)
+    env.batch.set_env_offset(rank * B)
+    env.reset(seed=5)
+    obs = env.view(capi.F_OBS)
+    staging = torch.empty_like(obs)
+    gathered = torch.zeros((world * B, env.obs_dim), device=obs.device)
+    assert gathered.numel() * 4 == 8 * 4096 * 108 * 4
+    side = torch.cuda.Stream()
+
+    class Handle:
+        def __init__(self, ev): self.ev = ev
+        def wait(self): torch.cuda.current_stream().wait_event(self.ev)
+
+    def gather_async(src):
+        ready = torch.cuda.Event(); ready.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            for r in range(world):                                  # every slot is written each step, like an all-gather's output
+                gathered[r * B:(r + 1) * B].copy_(src, non_blocking=True)
+            done = torch.cuda.Event(); done.record()
+        return Handle(done)
+    st = torch.cuda.current_stream().cuda_stream
+    mode = capi.BENCH_OBS | capi.BENCH_FRESH_ACTIONS | capi.BENCH_AUTORESET
+    ms, kms = bench.rollout_multi(torch, env, 12, mode, st, obs, staging, gather_async)
+    torch.cuda.synchronize()
+    assert 0 < kms <= ms * 1.05 and ms / 12 < 2.5 * kms / 12 + 1.0          # the copies overlap the step kernels instead of serialising with them
+    assert torch.equal(gathered[rank * B:(rank + 1) * B], obs) and torch.equal(gathered[:B], obs)
+
+
 @pytest.mark.parametrize("env_id", ["myoHandPoseRandom-v0", "myoHandObjHoldFixed-v0"])
 def test_fused_epilogue_equals_the_three_launches(env_id):
     """myo_bench_rollout's per-step epilogue for state-only tasks is one launch (post_kernel: observation + reward + done, TimeLimit / done
