@@ -56,20 +56,30 @@ struct Lay {
   int total;                                             // floats per env (padded)
 };
 
+// Model tables are read through pointers stored in these structs.  A pointer loaded from memory has no known address space, and the compiler
+// then emits FLAT loads for every table read (address-space check per access, and the loads count on lgkmcnt as well as vmcnt, so every LDS
+// wait also waits for them).  In device code the fields are therefore typed as GLOBAL pointers (address space 1): plain global_load with an
+// SGPR base.  Host code sees ordinary pointers; the layout is identical.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const int __attribute__((address_space(1)))* gpi;
+typedef const float __attribute__((address_space(1)))* gpf;
+#else
+typedef const int* gpi;
+typedef const float* gpf;
+#endif
+
 struct DevModel {
   int nl, nlevel, nv, nu, ngt, nseg, maxnnz, nwg, ncg, npair, maxkc, ns, nM;
   int iterations, ls_iterations;
   int disable_contact, disable_limit, disable_ellipsoid;
   float timestep, grav[3], tolerance, ls_tolerance, meaninertia, c0[3], origin[3];
-  const int *level_adr, *link_parent, *link_dofadr, *link_dofnum, *child_adr, *child, *dof_link, *dof_type, *dof_parent;
-  const int *site_link, *wg_link, *gt_seg_adr, *gt_seg_num, *gt_dofs, *seg, *dl, *col_adr, *col;
-  const int *cg_link, *cg_type, *pair_i, *pair_dl;
-  const float *link_pos, *link_quat, *link_mass, *link_com, *link_inertia, *dof_pos, *dof_axis, *qpos0, *dof_damping,
-      *dof_armature;
-  const int* act_obs;   // [nu] slot of the actuator's activation in the observation's act block (sim.data.act order), -1: stateless actuator
+  gpi level_adr, link_parent, link_dofadr, link_dofnum, child_adr, child, dof_link, dof_type, dof_parent;
+  gpi site_link, wg_link, gt_seg_adr, gt_seg_num, gt_dofs, seg, dl, col_adr, col;
+  gpi cg_link, cg_type, pair_i, pair_dl;
+  gpf link_pos, link_quat, link_mass, link_com, link_inertia, dof_pos, dof_axis, qpos0, dof_damping, dof_armature;
+  gpi act_obs;   // [nu] slot of the actuator's activation in the observation's act block (sim.data.act order), -1: stateless actuator
   int na_obs;           // number of stateful (muscle) actuators = MuJoCo's na
-  const float *site_lpos, *wg_lpos, *wg_lmat, *wg_radius, *seg_div, *gt_len0, *act, *cg_lpos, *cg_lmat, *cg_size, *cg_rbound,
-      *pair_f, *jl;
+  gpf site_lpos, wg_lpos, wg_lmat, wg_radius, seg_div, gt_len0, act, cg_lpos, cg_lmat, cg_size, cg_rbound, pair_f, jl;
   Lay lay;
 };
 
@@ -92,7 +102,7 @@ struct DevBatch {
   int ovf_row;             // floats per overflow row (0: no overflow storage, the LDS table is the capacity)
   float* linkx;            // [B][12 * nl] link frames of the last substep's position stage (TRK models; NULL otherwise)
 };
-#define NCX 32      // overflow contact rows per env: 64 contacts in all, one per lane of the wave
+#define NCX 48      // overflow contact rows ALLOCATED per env; a kernel with NC LDS slots uses 64 - NC of them: 64 contacts in all, one per lane
 #define NCANDX 256  // overflow candidates per env (MyoHand has 289 pairs: NCAND + NCANDX covers every pair)
 
 struct TaskDev {

@@ -41,6 +41,7 @@ struct myo_model {
   int env_lds_bytes_w = 0;
   bool wave_ok = false, generic_ok = false;
   int n_cu = 0;                 // compute units of the model's device (scheduler sizing)
+  int wave_wpe = 4;             // hand-class kernel variant: 4 waves per SIMD with 32 LDS contact slots, or 5 with 16 (MYO_HAND_WPE)
   bool trk = false;             // TrackEnv model class: step_kernel_w<36,20,32,2,2,false,0,false,true>
   bool hand_sizes = false, leg_sizes = false, terrain_sizes = false;   // table sizes equal Sizes<1> / Sizes<2>: the size-specialised instantiations may be used
   int wave_cfg = 0;             // 0: step_kernel_w<24,8,32,1,4> (hand / finger), 1: step_kernel_w<36,20,48,2,2> (legs)
@@ -100,7 +101,8 @@ template <typename T> static int upload(myo_model* m, const std::vector<T>& v, c
   *out = (const T*)p;
   return 0;
 }
-static int load_f(myo_model* m, const uint8_t* blob, const char* name, const float** out, std::vector<float>* keep = nullptr) {
+// (out is a template so that the struct fields' device-side address-space types do not matter to this host code)
+template <class P> static int load_f(myo_model* m, const uint8_t* blob, const char* name, P* out, std::vector<float>* keep = nullptr) {
   const BlobRec* r = blob_find(blob, name);
   if (!r || r->dtype != 0) return fail(MYO_E_BLOB, std::string("model blob lacks f64 array ") + name);
   size_t n = r->nbytes / 8;
@@ -108,16 +110,22 @@ static int load_f(myo_model* m, const uint8_t* blob, const char* name, const flo
   const double* src = (const double*)(blob + r->offset);
   for (size_t i = 0; i < n; i++) v[i] = (float)src[i];
   if (keep) *keep = v;
-  return upload<float>(m, v, out);
+  const float* tmp = nullptr;
+  int rc = upload<float>(m, v, &tmp);
+  *out = (P)tmp;
+  return rc;
 }
-static int load_i(myo_model* m, const uint8_t* blob, const char* name, const int** out, std::vector<int>* keep = nullptr) {
+template <class P> static int load_i(myo_model* m, const uint8_t* blob, const char* name, P* out, std::vector<int>* keep = nullptr) {
   const BlobRec* r = blob_find(blob, name);
   if (!r || r->dtype != 1) return fail(MYO_E_BLOB, std::string("model blob lacks i32 array ") + name);
   size_t n = r->nbytes / 4;
   std::vector<int> v(n);
   memcpy(v.data(), blob + r->offset, n * 4);
   if (keep) *keep = v;
-  return upload<int>(m, v, out);
+  const int* tmp = nullptr;
+  int rc = upload<int>(m, v, &tmp);
+  *out = (P)tmp;
+  return rc;
 }
 
 static void build_layout_w(const DevModel& d, DevModelW& w, int nvt, int kc, int nc, int nj = 3) {
@@ -294,7 +302,12 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
       m->wave_ok = true; m->wave_cfg = 2; m->generic_ok = false;
       build_layout_w(d, w, 36, 20, 32, 4);
     }
-    else if (common && !needs_full && d.nv <= 24 && d.nu <= 64 && d.ngt <= 64 && d.maxkc <= 8) { m->wave_ok = true; m->wave_cfg = 0; build_layout_w(d, w, 24, 8, 32); }
+    else if (common && !needs_full && d.nv <= 24 && d.nu <= 64 && d.ngt <= 64 && d.maxkc <= 8) {
+      m->wave_ok = true; m->wave_cfg = 0;
+      // occupancy variant: 16 contact slots in LDS (the rest in the HBM overflow rows) bring the slice under 8 KB = 20 waves per CU, at 96 VGPRs
+      if (const char* e = getenv("MYO_HAND_WPE")) if (atoi(e) == 5 && !w.has_tl) m->wave_wpe = 5;
+      build_layout_w(d, w, 24, 8, m->wave_wpe == 5 ? 16 : 32);
+    }
     else if (common && d.nv <= 36 && d.nu <= 128 && d.ngt <= 128 && d.maxkc <= 20) { m->wave_ok = true; m->wave_cfg = 1; build_layout_w(d, w, 36, 20, 32); }
     else { m->wave_ok = false; build_layout_w(d, w, 24, 8, 32); }
     m->hand_sizes = m->wave_ok && m->wave_cfg == 0 && sizes_match<1>(w.nq, d.nv, d.nu, d.nl, d.nlevel, d.maxnnz, d.ngt, d.nseg, d.ncg, d.npair);
@@ -678,6 +691,8 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 16, 1, 5, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 16, 1, 5, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       attr_w = true;
     }
     const int* order = nullptr;
@@ -689,7 +704,7 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     const int n_cu = m->n_cu > 0 ? m->n_cu : 256;                                                        // per model = per device
     const int resident = n_cu * (m->wave_cfg == 0 ? 16 : (m->wave_cfg == 1 ? 8 : std::max(1, (160 * 1024) / std::max(1, m->env_lds_bytes_w))));
     const bool sched_ok = !kflags && Bn >= 64 && Bn <= SCHED_ENV_MASK && nsub + (wk ? 1 : 0) <= 15 && nsub > 0;
-    const bool sched = sched_ok && m->wave_cfg != 2 && !(m->dw.hf.on && !m->terrain_sizes) && (sched_mode == 1 || (sched_mode == -1 && m->wave_cfg == 1 && Bn >= 2 * resident));
+    const bool sched = sched_ok && m->wave_cfg != 2 && m->wave_wpe == 4 && !(m->dw.hf.on && !m->terrain_sizes) && (sched_mode == 1 || (sched_mode == -1 && m->wave_cfg == 1 && Bn >= 2 * resident));
     if (b->balance && Bn >= 1024 && Bn % 4 == 0 && !kflags && !sched) {
       static const int prio_mode = [] { const char* e = getenv("MYO_PRIO"); return e ? atoi(e) : 2; }();
       hipLaunchKernelGGL(balance_kernel, dim3(1), dim3(1024), 0, s, (const int*)b->db.diag, Bn, b->d_order, Bn / 4, prio_mode);
@@ -697,7 +712,8 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     }
     SchedDev S{b->d_sched, b->d_sched + 32, b->sched_stride, nsub + (wk ? 1 : 0)};
     if (!kflags)   // instantiation chosen below, as rocprofv3 prints it (bench.py reports it next to the kernel time)
-      b->last_kernel = m->wave_cfg == 2 ? "step_kernel_w<36,20,32,2,2,false,0,false,true>" : sched ? (m->wave_cfg == 0 ? "step_kernel_w<24,8,32,1,4,true,0,false>" : m->dw.hf.on ? "step_kernel_w<36,20,32,2,2,true,3,true>" : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,true,2,false>" : "step_kernel_w<36,20,32,2,2,true,0,false>"))
+      b->last_kernel = m->wave_cfg == 2 ? "step_kernel_w<36,20,32,2,2,false,0,false,true>" :
+                       (m->wave_cfg == 0 && m->wave_wpe == 5) ? (m->hand_sizes ? "step_kernel_w<24,8,16,1,5,false,1,false,false>" : "step_kernel_w<24,8,16,1,5,false,0,false,false>") : sched ? (m->wave_cfg == 0 ? "step_kernel_w<24,8,32,1,4,true,0,false>" : m->dw.hf.on ? "step_kernel_w<36,20,32,2,2,true,3,true>" : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,true,2,false>" : "step_kernel_w<36,20,32,2,2,true,0,false>"))
                              : (m->wave_cfg == 0 ? (m->hand_sizes ? "step_kernel_w<24,8,32,1,4,false,1,false>" : "step_kernel_w<24,8,32,1,4,false,0,false>")
                                                  : (m->dw.hf.on ? (m->terrain_sizes ? "step_kernel_w<36,20,32,2,2,false,3,true>" : "step_kernel_w<36,20,32,2,2,false,0,true>") : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,false,2,false>" : "step_kernel_w<36,20,32,2,2,false,0,false>")));
     if (sched) {
@@ -720,6 +736,12 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     } else if (m->wave_cfg == 2)   // TrackEnv model class
       hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, false, 0, false, true>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                          (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, wk, kflags, S);
+    else if (m->wave_cfg == 0 && m->wave_wpe == 5 && m->hand_sizes)
+      hipLaunchKernelGGL((step_kernel_w<24, 8, 16, 1, 5, false, 1>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0, S);
+    else if (m->wave_cfg == 0 && m->wave_wpe == 5)
+      hipLaunchKernelGGL((step_kernel_w<24, 8, 16, 1, 5, false, 0>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0, S);
     else if (m->wave_cfg == 0 && m->hand_sizes)
       hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, false, 1>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                          (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0, S);

@@ -28,17 +28,17 @@ struct LayW {
 struct HfDev { int on, nrow, ncol, cg; float size[4], pos[3]; };
 struct DevModelW {
   LayW lay;
-  const int *seg_order, *seg_tendon, *gt_dl;
-  const float* link_mat0;
+  gpi seg_order, seg_tendon, gt_dl;
+  gpf link_mat0;
   int nwrapseg, ndl, has_tl;
-  const float* tl;
+  gpf tl;
   int nq, has_free, neq;          // free-floating root (nq = nv + 1), joint-coupling equalities
   int has_j0;                     // some actuator drives a joint directly: constant moment arms gt_j0 [ngt][maxnnz]
-  const float* gt_j0;
+  gpf gt_j0;
   HfDev hf;                       // (kept last: the field offsets of the tables above feed the hot loops' scalar loads)
-  const int *link_free, *dof_qposadr, *eq_i, *link_chain_adr, *link_chain;
-  const float* eq_f;
-  const float *fl, *mesh_vert;    // TRK models: friction-loss rows [nv][4] = loss, D, B, -; hull vertices of the mesh geoms
+  gpi link_free, dof_qposadr, eq_i, link_chain_adr, link_chain;
+  gpf eq_f;
+  gpf fl, mesh_vert;    // TRK models: friction-loss rows [nv][4] = loss, D, B, -; hull vertices of the mesh geoms
 };
 
 __device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
@@ -379,10 +379,14 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   auto cgrb = [&](int g) -> float { return (OVR && Bt.gsize && g == Bt.gsize_cg) ? Bt.gsize[4 * (size_t)env + 3] : M.cg_rbound[g]; };
   // contacts NC .. NC + NCX - 1 live in this env's HBM overflow rows [dist, pos3, normal3, pair, cJ[3 KC], dof words]; lane = contact still holds
   // for all 64.  The first NC contacts (all of them for > 99.5 % of the states) never leave LDS.
-  static_assert(NC + NCX <= 64, "one lane per contact");
+  constexpr int NCXK = (64 - NC) < NCX ? (64 - NC) : NCX;   // overflow rows this instantiation uses: one lane per contact, 64 in all
   float* const ovf_env = Bt.ovf ? Bt.ovf + (size_t)env * NCX * Bt.ovf_row : nullptr;
   const int ovf_row = Bt.ovf_row;
-  const int nct = ovf_env ? NC + NCX : NC;
+  const int nct = ovf_env ? NC + NCXK : NC;
+  // narrow-phase round width: the MPR's per-lane LDS scratch (9 floats) lives in the contact-jacobian area, which holds 64 lanes' worth only
+  // when NC * NJ * KC >= 576; the low-LDS instantiations (NC = 16) run the narrow phase in rounds of 32 candidates (typical count: 10-20)
+  constexpr int RND = (NC * NJ * KC >= 576) ? 64 : 32;
+  static_assert(RND * 9 <= NC * NJ * KC, "MPR scratch must fit the contact-jacobian area");
   int* const ovf_cand = (!HF && Bt.ovf_cand) ? Bt.ovf_cand + (size_t)env * NCANDX : nullptr;
   bool alive = true;
   int n_mprw = 0;   // MPR warm-start table (pair id + last contact normal in geom 1's frame): entries of the previous substep
@@ -910,8 +914,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       int n_mprw_new = 0;
       SYNC();
       STAMP(6);
-      for (int base = 0; base < ncand; base += 64) {
-        int ci = base + lane;
+      for (int base = 0; base < ncand; base += RND) {
+        int ci = (RND == 64 || lane < RND) ? base + lane : ncand;
         int nsup = -8;                    // support evaluations of this lane's MPR refinement (-8: not an MPR pair)
         bool mpr_hit = false;             // this lane's MPR call found a contact: its normal seeds the next substep's call
         float mpr_n[3] = {0.f, 0.f, 0.f};
