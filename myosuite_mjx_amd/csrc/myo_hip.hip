@@ -41,6 +41,7 @@ struct myo_model {
   int env_lds_bytes_w = 0;
   bool wave_ok = false, generic_ok = false;
   int n_cu = 0;                 // compute units of the model's device (scheduler sizing)
+  bool rk4 = false;             // <option integrator="RK4">: the RK4 instantiations of the wave kernel (generic sizes, no scheduler)
   int wave_wpe = 4;             // hand-class kernel variant: 4 waves per SIMD with 32 LDS contact slots, or 5 with 16 (MYO_HAND_WPE)
   bool trk = false;             // TrackEnv model class: step_kernel_w<36,20,32,2,2,false,0,false,true>
   bool hand_sizes = false, leg_sizes = false, terrain_sizes = false;   // table sizes equal Sizes<1> / Sizes<2>: the size-specialised instantiations may be used
@@ -312,8 +313,14 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
     else { m->wave_ok = false; build_layout_w(d, w, 24, 8, 32); }
     m->hand_sizes = m->wave_ok && m->wave_cfg == 0 && sizes_match<1>(w.nq, d.nv, d.nu, d.nl, d.nlevel, d.maxnnz, d.ngt, d.nseg, d.ncg, d.npair);
     if (m->trk) m->generic_ok = false;
+    if (blob_find(blob, "integrator")) { std::vector<int> ig; if ((rc = load_i(m, blob, "integrator", &tmpi, &ig))) { myo_model_free(m); return rc; } m->rk4 = !ig.empty() && ig[0] == 1; }
+    if (m->rk4) {
+      if (!m->wave_ok || m->trk || w.hf.on) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "RK4: wave kernel models without height field / TrackEnv features only"); }
+      m->generic_ok = false; m->wave_wpe = 4;
+    }
     m->leg_sizes = m->wave_ok && m->wave_cfg == 1 && sizes_match<2>(w.nq, d.nv, d.nu, d.nl, d.nlevel, d.maxnnz, d.ngt, d.nseg, d.ncg, d.npair);
     m->terrain_sizes = m->wave_ok && m->wave_cfg == 1 && w.hf.on && sizes_match<3>(w.nq, d.nv, d.nu, d.nl, d.nlevel, d.maxnnz, d.ngt, d.nseg, d.ncg, d.npair);
+    if (m->rk4) m->hand_sizes = m->leg_sizes = m->terrain_sizes = false;
     if (const char* e = getenv("MYO_NO_SPEC")) if (atoi(e) == 1) m->hand_sizes = m->leg_sizes = m->terrain_sizes = false;   // tests: force the run-time-sized instantiations
     if (!m->wave_ok && !m->generic_ok) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "model exceeds the limits of both step kernels (nv <= 36, nu <= 128, pair dofs <= 20)"); }
     m->env_lds_bytes_w = w.lay.total * 4;
@@ -691,6 +698,8 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 4, false, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 16, 1, 5, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 16, 1, 5, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       attr_w = true;
@@ -704,7 +713,7 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     const int n_cu = m->n_cu > 0 ? m->n_cu : 256;                                                        // per model = per device
     const int resident = n_cu * (m->wave_cfg == 0 ? 16 : (m->wave_cfg == 1 ? 8 : std::max(1, (160 * 1024) / std::max(1, m->env_lds_bytes_w))));
     const bool sched_ok = !kflags && Bn >= 64 && Bn <= SCHED_ENV_MASK && nsub + (wk ? 1 : 0) <= 15 && nsub > 0;
-    const bool sched = sched_ok && m->wave_cfg != 2 && m->wave_wpe == 4 && !(m->dw.hf.on && !m->terrain_sizes) && (sched_mode == 1 || (sched_mode == -1 && m->wave_cfg == 1 && Bn >= 2 * resident));
+    const bool sched = sched_ok && m->wave_cfg != 2 && m->wave_wpe == 4 && !m->rk4 && !(m->dw.hf.on && !m->terrain_sizes) && (sched_mode == 1 || (sched_mode == -1 && m->wave_cfg == 1 && Bn >= 2 * resident));
     if (b->balance && Bn >= 1024 && Bn % 4 == 0 && !kflags && !sched) {
       static const int prio_mode = [] { const char* e = getenv("MYO_PRIO"); return e ? atoi(e) : 2; }();
       hipLaunchKernelGGL(balance_kernel, dim3(1), dim3(1024), 0, s, (const int*)b->db.diag, Bn, b->d_order, Bn / 4, prio_mode);
@@ -712,7 +721,8 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     }
     SchedDev S{b->d_sched, b->d_sched + 32, b->sched_stride, nsub + (wk ? 1 : 0)};
     if (!kflags)   // instantiation chosen below, as rocprofv3 prints it (bench.py reports it next to the kernel time)
-      b->last_kernel = m->wave_cfg == 2 ? "step_kernel_w<36,20,32,2,2,false,0,false,true>" :
+      b->last_kernel = m->rk4 ? (m->wave_cfg == 0 ? "step_kernel_w<24,8,32,1,4,false,0,false,false,true>" : "step_kernel_w<36,20,32,2,2,false,0,false,false,true>") :
+                       m->wave_cfg == 2 ? "step_kernel_w<36,20,32,2,2,false,0,false,true>" :
                        (m->wave_cfg == 0 && m->wave_wpe == 5) ? (m->hand_sizes ? "step_kernel_w<24,8,16,1,5,false,1,false,false>" : "step_kernel_w<24,8,16,1,5,false,0,false,false>") : sched ? (m->wave_cfg == 0 ? "step_kernel_w<24,8,32,1,4,true,0,false>" : m->dw.hf.on ? "step_kernel_w<36,20,32,2,2,true,3,true>" : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,true,2,false>" : "step_kernel_w<36,20,32,2,2,true,0,false>"))
                              : (m->wave_cfg == 0 ? (m->hand_sizes ? "step_kernel_w<24,8,32,1,4,false,1,false>" : "step_kernel_w<24,8,32,1,4,false,0,false>")
                                                  : (m->dw.hf.on ? (m->terrain_sizes ? "step_kernel_w<36,20,32,2,2,false,3,true>" : "step_kernel_w<36,20,32,2,2,false,0,true>") : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,false,2,false>" : "step_kernel_w<36,20,32,2,2,false,0,false>")));
@@ -733,7 +743,13 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
       else
         hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, true, 0>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                            (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, (const int*)nullptr, wk, 0, S);
-    } else if (m->wave_cfg == 2)   // TrackEnv model class
+    } else if (m->rk4 && m->wave_cfg == 0)
+      hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, false, 0, false, false, true>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0, S);
+    else if (m->rk4)
+      hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, false, 0, false, false, true>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, wk, kflags, S);
+    else if (m->wave_cfg == 2)   // TrackEnv model class
       hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, false, 0, false, true>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                          (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, wk, kflags, S);
     else if (m->wave_cfg == 0 && m->wave_wpe == 5 && m->hand_sizes)

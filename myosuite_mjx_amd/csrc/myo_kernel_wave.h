@@ -266,7 +266,10 @@ template <int SPEC> static bool sizes_match(int nq, int nv, int nu, int nl, int 
 
 // TRK (MyoDM TrackEnv model class): condim-4 contacts (6 pyramid rows, a 4th jacobian row for the spin about the normal), joint friction-loss
 // rows, box / convex-hull shapes in the narrow phase.  All of it sits behind `if constexpr (TRK)`: the other instantiations compile as before.
-template <int NVT, int KC, int NC, int NTR, int WPE, bool SCHED, int SPEC, bool HF = false, bool TRK = false>
+// RK4: mj_RungeKutta(4) instead of mj_Euler -- every substep runs the whole forward pass four times (state X0 + h a F[i-1], a = 1/2, 1/2, 1)
+// and ends on X0 + h (F0 + 2 F1 + 2 F2 + F3) / 6; the saved state and the weighted derivative sums live in the registers of lane = dof /
+// lane = actuator.  No implicit joint damping (an Euler-only feature of MuJoCo).
+template <int NVT, int KC, int NC, int NTR, int WPE, bool SCHED, int SPEC, bool HF = false, bool TRK = false, bool RK4 = false>
 __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restrict__ Mp, const DevModelW* __restrict__ Wp, DevBatch Bt,
                                                         const float* __restrict__ action, int actmap, int nsub, long long* stamps,
                                                         const int* __restrict__ order, const DevWalk* __restrict__ wk, int kflags, SchedDev S) {
@@ -397,8 +400,15 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     if (lane_id < 4 * n_mprw) ((int*)(E + Y.mprw))[lane_id] = ldstatei<SCHED>(Wt + lane_id);
   }
   SYNC();
+  static_assert(!(RK4 && SCHED), "the substep scheduler hands out Euler substeps");
   for (int step = s0; step < s1; step++) {
     const bool op = walk && step == nsub;   // observation pass: position / velocity stages at the post-step state, then out
+    // RK4 state of this substep (dead code otherwise): X0 and the weighted sums of the stage derivatives
+    float rk_v0 = 0.f, rk_q0 = 0.f, rk_sv = 0.f, rk_sa = 0.f, rk_t0 = 0.f, rk_quat[4] = {1.f, 0.f, 0.f, 0.f}, rk_a0[NTR], rk_sd[NTR];
+#pragma unroll
+    for (int rr = 0; rr < NTR; rr++) { rk_a0[rr] = 0.f; rk_sd[rr] = 0.f; }
+    int rk_stage = 0;
+  rk_next_stage:
     // compiler-only barrier: keeps the (substep-invariant) model-table loads inside the loop body instead of hoisting
     // ~60 values per lane out of it and spilling them to scratch
     asm volatile("" ::: "memory");
@@ -1514,7 +1524,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       if (refactor) {
         const int dd = lane < nv ? lane : 0;
         const int based = (dd * (dd + 1)) / 2;
-        const float diag_add = phase == 2 ? h * damping : 0.f;
+        const float diag_add = (phase == 2 && !RK4) ? h * damping : 0.f;
 #pragma unroll
         for (int k = 0; k < NVT; k++) {
           float mv = (lane < nv && k <= lane) ? Mp[based + (k <= dd ? k : 0)] : 0.f;                 // lower row of M
@@ -1627,6 +1637,60 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       if (__any(bad) && alive) { flags |= MYO_FLAG_BAD_QACC; alive = false; }
     }
     warm = qacc;
+    if constexpr (RK4) {
+      if (alive) {
+        const float Bw = (rk_stage == 0 || rk_stage == 3) ? (1.f / 6.f) : (1.f / 3.f), a = rk_stage < 2 ? 0.5f : 1.f;
+        const bool last = rk_stage == 3;
+        bool frot = false;
+        if (rk_stage == 0) rk_t0 = time;
+#pragma unroll
+        for (int rr = 0; rr < NTR; rr++) {
+          const int i = lane + 64 * rr;
+          if (i < nu) {
+            if (rk_stage == 0) { rk_a0[rr] = E[Y.act + i]; rk_sd[rr] = 0.f; }
+            rk_sd[rr] += Bw * actdot[rr];
+            E[Y.act + i] = rk_a0[rr] + h * (last ? rk_sd[rr] : a * actdot[rr]);
+          }
+        }
+        float vint = 0.f;   // the velocity this lane's coordinate is advanced with, from X0, over h
+        if (lane < nv) {
+          const float vcur = E[Y.qvel + lane];
+          const int fl = M.dof_link[lane];
+          frot = has_free && W.link_free[fl] && lane - M.link_dofadr[fl] >= 3;
+          if (rk_stage == 0) { rk_v0 = vcur; rk_sv = 0.f; rk_sa = 0.f; if (!frot) rk_q0 = E[Y.qpos + W.dof_qposadr[lane]]; }
+          rk_sv += Bw * vcur; rk_sa += Bw * qaccE;
+          vint = last ? rk_sv : a * vcur;
+          E[Y.qvel + lane] = rk_v0 + h * (last ? rk_sa : a * qaccE);
+          if (!frot) E[Y.qpos + W.dof_qposadr[lane]] = rk_q0 + h * vint;
+          E[Y.xv + lane] = vint;
+        }
+        if (has_free) {
+          SYNC();
+          const int fl = lane < nv ? M.dof_link[lane] : 0;
+          if (frot && lane - M.link_dofadr[fl] == 3) {
+            const int qa = W.dof_qposadr[M.link_dofadr[fl]] + 3;
+            if (rk_stage == 0) { rk_quat[0] = E[Y.qpos + qa]; rk_quat[1] = E[Y.qpos + qa + 1]; rk_quat[2] = E[Y.qpos + qa + 2]; rk_quat[3] = E[Y.qpos + qa + 3]; }
+            float w[3] = {E[Y.xv + lane], E[Y.xv + lane + 1], E[Y.xv + lane + 2]};
+            float wn = norm3(w), ang = h * wn;
+            float o[4] = {rk_quat[0], rk_quat[1], rk_quat[2], rk_quat[3]};
+            if (wn >= MINVALF) {
+              float sn, cs;
+              sincosf(0.5f * ang, &sn, &cs);
+              const float inv = sn / wn, r[4] = {cs, w[0] * inv, w[1] * inv, w[2] * inv}, *q = rk_quat;
+              o[0] = q[0] * r[0] - q[1] * r[1] - q[2] * r[2] - q[3] * r[3];
+              o[1] = q[0] * r[1] + q[1] * r[0] + q[2] * r[3] - q[3] * r[2];
+              o[2] = q[0] * r[2] - q[1] * r[3] + q[2] * r[0] + q[3] * r[1];
+              o[3] = q[0] * r[3] + q[1] * r[2] - q[2] * r[1] + q[3] * r[0];
+            }
+            const float on = 1.0f / sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+            E[Y.qpos + qa] = o[0] * on; E[Y.qpos + qa + 1] = o[1] * on; E[Y.qpos + qa + 2] = o[2] * on; E[Y.qpos + qa + 3] = o[3] * on;
+          }
+        }
+        time = rk_t0 + (last ? h : a * h);
+      }
+      SYNC();
+      if (alive && ++rk_stage < 4) goto rk_next_stage;
+    } else
     if (alive) {
 #pragma unroll
       for (int rr = 0; rr < NTR; rr++) if (lane + 64 * rr < nu) E[Y.act + lane + 64 * rr] += h * actdot[rr];

@@ -1051,8 +1051,9 @@ class _Compiler:
         A["key_qvel"] = np.stack([_floats(k["qvel"], nv) if "qvel" in k else np.zeros(nv) for k in self.keys]) if kq else np.zeros((0, nv))
         # options
         o = self.opt
-        if o["cone"] != "pyramidal" or o["solver"] != "Newton" or o["integrator"] != "Euler":
-            raise NotImplementedError("only pyramidal cones, the Newton solver and Euler integration are restated")
+        if o["cone"] != "pyramidal" or o["solver"] != "Newton" or o["integrator"] not in ("Euler", "RK4"):
+            raise NotImplementedError("only pyramidal cones, the Newton solver and Euler / RK4 integration are restated")
+        A["integrator"] = np.array([1 if o["integrator"] == "RK4" else 0], np.int32)
         A["opt"] = np.array([o["timestep"], o["gravity"][0], o["gravity"][1], o["gravity"][2], o["tolerance"],
                              float(o["iterations"]), float(o["ls_iterations"]), o["ls_tolerance"], o["impratio"],
                              0.0])  # last slot: stat.meaninertia, filled by setconst

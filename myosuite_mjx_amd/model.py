@@ -91,6 +91,14 @@ class Model:
             act[pos, 2] = gp[pos, 2]
         return Model(arrays, self.names, self.source)
 
+    def with_integrator(self, name) -> "Model":
+        """Copy of the model with `<option integrator=...>` set: "Euler" (semi-implicit, implicit joint damping) or "RK4" (mj_RungeKutta)."""
+        if name not in ("Euler", "RK4"):
+            raise ValueError("integrator must be 'Euler' or 'RK4'")
+        arrays = {k: np.array(v, copy=True) for k, v in self.arrays.items()}
+        arrays["integrator"] = np.array([1 if name == "RK4" else 0], np.int32)
+        return Model(arrays, self.names, self.source)
+
     def save(self, stem):
         with open(stem + ".myob", "wb") as f:
             f.write(self.blob())

@@ -52,6 +52,7 @@ typedef struct {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM;
   real timestep, gravity[3], tolerance, ls_tolerance, impratio, meaninertia;
   int iterations, ls_iterations;
+  int integrator;   /* 0: semi-implicit Euler with implicit joint damping (mj_Euler); 1: 4th-order Runge-Kutta (mj_RungeKutta) */
   int *body_parentid, *body_jntadr, *body_jntnum, *body_dofadr, *body_dofnum, *body_weldid, *body_rootid;
   real *body_pos, *body_quat, *body_mass, *body_ipos, *body_iquat, *body_inertia, *body_invweight0;
   real *body_subtreemass;
@@ -194,6 +195,7 @@ Model* myoo_load(const void* blobv, size_t nbytes) {
   if (blob_find(blob, "dof_frictionloss")) { LF(dof_frictionloss); LF(dof_solref_fri); LF(dof_solimp_fri); }
   else { m->dof_frictionloss = (real*)calloc(m->nv + 1, sizeof(real)); m->storage[m->nstorage++] = m->dof_frictionloss; }
   if (blob_find(blob, "geom_meshadr")) { LI(geom_meshadr); LI(geom_meshnum); LF(mesh_vert); }
+  if (blob_find(blob, "integrator")) { int* ig = load_i(m, blob, "integrator"); m->integrator = ig[0]; }
   m->neq = sz[12];
   LI(eq_obj1id); LI(eq_obj2id); LF(eq_data); LF(eq_solref); LF(eq_solimp);
 #undef LF
@@ -2082,12 +2084,79 @@ static void euler(const Model* m, Data* d) { /* mj_Euler with implicit joint dam
   d->time += dt;
 }
 
+/* mj_integratePos [3P]: qpos advanced by velocity `vel` over dt (hinge / slide: linear; free joint: position linear, quaternion by the
+ * body-frame angular velocity) */
+static void integrate_pos(const Model* m, real* qpos, const real* vel, real dt) {
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    if (m->jnt_type[j] == JNT_FREE) {
+      for (int k = 0; k < 3; k++) qpos[qa + k] += dt * vel[da + k];
+      real w[3] = {vel[da + 3], vel[da + 4], vel[da + 5]};
+      real n = norm3(w), ang = n * dt;
+      if (ang > MINVAL) {
+        real s = sin(ang * (real)0.5);
+        real dq[4] = {cos(ang * (real)0.5), w[0] / n * s, w[1] / n * s, w[2] / n * s};
+        mul_quat(qpos + qa + 3, qpos + qa + 3, dq);
+        normalize4(qpos + qa + 3);
+      }
+    } else {
+      qpos[qa] += dt * vel[da];
+    }
+  }
+}
+
+/* mj_RungeKutta(m, d, 4) [3P]: classic RK4 on the state (qpos, qvel, act) with derivative (qvel, qacc, act_dot); the first derivative is
+ * the forward pass mj_step has just done, each further stage sets the state to X0 + h a F[i-1] (a = 1/2, 1/2, 1), the time to
+ * t0 + c h and runs the forward pass again; the result is X0 + h (F0 + 2 F1 + 2 F2 + F3) / 6.  No implicit joint damping (Euler only). */
+static int runge_kutta4(const Model* m, Data* d) {
+  int nq = m->nq, nv = m->nv, na = m->na;
+  static const real A[3] = {(real)0.5, (real)0.5, (real)1}, Bw[4] = {(real)1 / 6, (real)1 / 3, (real)1 / 3, (real)1 / 6};
+  real h = m->timestep, t0 = d->time;
+  real* X0 = (real*)malloc((size_t)(nq + nv + na + 2 * nv + na + 8) * sizeof(real));
+  real* Sv = X0 + nq + nv + na;     /* sum B_j qvel_j */
+  real* Sa = Sv + nv;               /* sum B_j qacc_j */
+  real* Sd = Sa + nv;               /* sum B_j act_dot_j */
+  memcpy(X0, d->qpos, nq * sizeof(real)); memcpy(X0 + nq, d->qvel, nv * sizeof(real)); memcpy(X0 + nq + nv, d->act, na * sizeof(real));
+  for (int k = 0; k < nv; k++) { Sv[k] = Bw[0] * d->qvel[k]; Sa[k] = Bw[0] * d->qacc[k]; }
+  for (int k = 0; k < na; k++) Sd[k] = Bw[0] * d->act_dot[k];
+  int rc = 0;
+  for (int i = 1; i < 4 && !rc; i++) {
+    real a = A[i - 1];
+    real* dv = d->wk + 20 * nv;      /* a * F[i-1].qvel: velocity that advances qpos */
+    for (int k = 0; k < nv; k++) dv[k] = a * d->qvel[k];
+    for (int k = 0; k < nv; k++) d->qvel[k] = X0[nq + k] + h * a * d->qacc[k];
+    for (int k = 0; k < na; k++) d->act[k] = X0[nq + nv + k] + h * a * d->act_dot[k];
+    memcpy(d->qpos, X0, nq * sizeof(real));
+    integrate_pos(m, d->qpos, dv, h);
+    d->time = t0 + a * h;
+    myoo_forward(m, d);
+    if (d->warning & 4) { rc = 4; break; }
+    if (is_bad(d->qacc, nv)) { rc = 2; break; }
+    for (int k = 0; k < nv; k++) { Sv[k] += Bw[i] * d->qvel[k]; Sa[k] += Bw[i] * d->qacc[k]; }
+    for (int k = 0; k < na; k++) Sd[k] += Bw[i] * d->act_dot[k];
+  }
+  if (!rc) {
+    memcpy(d->qpos, X0, nq * sizeof(real));
+    integrate_pos(m, d->qpos, Sv, h);
+    for (int k = 0; k < nv; k++) d->qvel[k] = X0[nq + k] + h * Sa[k];
+    for (int k = 0; k < na; k++) d->act[k] = X0[nq + nv + k] + h * Sd[k];
+    d->time = t0 + h;
+  }
+  free(X0);
+  return rc;
+}
+
 /* one mj_step; returns nonzero if the state went bad and was reset (mj_sim_scene.py:54-61) */
 int myoo_step1(const Model* m, Data* d) {
   if (is_bad(d->qpos, m->nq) || is_bad(d->qvel, m->nv)) { myoo_reset(m, d); d->warning |= 1; return 1; }
   myoo_forward(m, d);
   if (d->warning & 4) return 4;
   if (is_bad(d->qacc, m->nv)) { myoo_reset(m, d); d->warning |= 2; return 2; }
+  if (m->integrator == 1) {
+    int rc = runge_kutta4(m, d);
+    if (rc == 2) { myoo_reset(m, d); d->warning |= 2; }
+    return rc;
+  }
   euler(m, d);
   return 0;
 }
