@@ -289,11 +289,12 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
       m->generic_ok = !w.has_free && w.neq == 0 && !plane_pairs && !condim1 && w.nq == d.nv && d.maxkc <= KCMAX && !w.has_tl && !m->has_affine;
     }
     // TrackEnv model class (lowering: hip_trk = condim-4 pairs | friction loss | box / hull geoms): tables of the TRK instantiation
-    w.fl = nullptr; w.mesh_vert = nullptr;
+    w.fl = nullptr; w.mesh_vert = nullptr; w.mesh_nbr_adr = nullptr; w.mesh_nbr = nullptr; w.mesh_start = nullptr;
     m->trk = false;
     if (blob_find(blob, "hip_trk")) {
       std::vector<int> tk;
-      if ((rc = load_i(m, blob, "hip_trk", &tmpi, &tk)) || (rc = load_f(m, blob, "hip_fl", &w.fl)) || (rc = load_f(m, blob, "hip_mesh_vert", &w.mesh_vert))) { myo_model_free(m); return rc; }
+      if ((rc = load_i(m, blob, "hip_trk", &tmpi, &tk)) || (rc = load_f(m, blob, "hip_fl", &w.fl)) || (rc = load_f(m, blob, "hip_mesh_vert", &w.mesh_vert)) ||
+          (rc = load_i(m, blob, "hip_mesh_nbr_adr", &w.mesh_nbr_adr)) || (rc = load_i(m, blob, "hip_mesh_nbr", &w.mesh_nbr)) || (rc = load_i(m, blob, "hip_mesh_start", &w.mesh_start))) { myo_model_free(m); return rc; }
       m->trk = tk[0] || tk[1] || tk[2];
     }
     const bool common = d.nl <= 64 && d.ncg <= 64 && w.nq <= 64 && w.neq <= 64 && d.maxnnz <= 20;

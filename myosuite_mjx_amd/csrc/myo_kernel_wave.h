@@ -38,6 +38,7 @@ struct DevModelW {
   HfDev hf;                       // (kept last: the field offsets of the tables above feed the hot loops' scalar loads)
   gpi link_free, dof_qposadr, eq_i, link_chain_adr, link_chain;
   gpf eq_f;
+  gpi mesh_nbr_adr, mesh_nbr, mesh_start;   // hull vertex graphs (lowering.py hip_mesh_*)
   gpf fl, mesh_vert;    // TRK models: friction-loss rows [nv][4] = loss, D, B, -; hull vertices of the mesh geoms
 };
 
@@ -1104,7 +1105,10 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             for (int k = 0; k < 9; k++) o1.mat[k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
 #pragma unroll
             for (int k = 0; k < 3; k++) o1.pos[k] = 0.f;
-            if constexpr (TRK) { cobj_shape_poly(o1, M.cg_type[g1], sz1, W.mesh_vert); cobj_shape_poly(o2, M.cg_type[g2], sz2, W.mesh_vert); }
+            if constexpr (TRK) {
+              cobj_shape_poly(o1, M.cg_type[g1], sz1, W.mesh_vert, W.mesh_nbr_adr, W.mesh_nbr, W.mesh_start);
+              cobj_shape_poly(o2, M.cg_type[g2], sz2, W.mesh_vert, W.mesh_nbr_adr, W.mesh_nbr, W.mesh_start);
+            }
             else { cobj_shape(o1, M.cg_type[g1], sz1); cobj_shape(o2, M.cg_type[g2], sz2); }
             o1.margin = o2.margin = 0.5f * margin;
             float depth, dir[3], pos[3], nw[3] = {0.f, 0.f, 0.f};
@@ -1113,6 +1117,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
               if (((const int*)(E + Y.mprw))[4 * i] == p) { nw[0] = E[Y.mprw + 4 * i + 1]; nw[1] = E[Y.mprw + 4 * i + 2]; nw[2] = E[Y.mprw + 4 * i + 3]; have_nw = true; }
             }
             // portal witnesses in per-lane LDS scratch: the contact-jacobian area of region X, not written before the rows stage
+            // (TRK: a 1e-6 tolerance -- MuJoCo's ccd default -- was measured: narrow phase -15 %, but the one-substep qpos error p50 grows 2.7e-6 -> 1.5e-5)
             if (mpr_penetration_wl<TRK ? 2 : 0>(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr, E + Y.cJ + 9 * lane)) {
               dist = margin - depth;
               normalize3(dir);

@@ -286,7 +286,7 @@ __device__ __forceinline__ void make_frame(const float* n, float* t1, float* t2)
 //   ellipsoid S = semi-axes, h = 0 | sphere S = (r,r,r), h = 0 | capsule S = (r,r,r), h = half length | cylinder S = (r,r,0), h = half length.
 // One branch-free formula instead of a per-type switch: in a wave that mixes pad / capsule pairs every lane used to walk through all
 // the type branches of both shapes at each of the ~23 support evaluations of an MPR call.
-struct CObj { float pos[3], mat[9], S[3], h, margin; const float* verts; };  // by value: keeps everything in registers (verts: polytope kernels only)
+struct CObj { float pos[3], mat[9], S[3], h, margin; const float* verts; const int *nadr, *nbr, *start; };  // by value: registers (the pointers: polytope kernels only)
 __device__ __forceinline__ void cobj_shape(CObj& o, int type, const float* size) {
   if (type == GEOM_ELLIPSOID) { o.S[0] = size[0]; o.S[1] = size[1]; o.S[2] = size[2]; o.h = 0.f; }
   else if (type == GEOM_CYLINDER) { o.S[0] = size[0]; o.S[1] = size[0]; o.S[2] = 0.f; o.h = size[1]; }
@@ -300,19 +300,45 @@ __device__ __forceinline__ void support_local(const float* S, float h, const flo
   pl[0] = S[0] * s[0] * inv; pl[1] = S[1] * s[1] * inv; pl[2] = S[2] * s[2] * inv + (dl[2] >= 0 ? h : -h);
 }
 // polytope shapes (TrackEnv kernels, MPR mode 2): h = -2: box with half sizes S; h = -3: convex hull, S[0] vertices at `verts` (support = best vertex)
-__device__ __forceinline__ void cobj_shape_poly(CObj& o, int type, const float* size, const float* mesh_vert) {
-  if (type == 6) { o.S[0] = size[0]; o.S[1] = size[1]; o.S[2] = size[2]; o.h = -2.f; o.verts = nullptr; }
-  else if (type == 7) { o.S[0] = size[1]; o.S[1] = o.S[2] = 0.f; o.h = -3.f; o.verts = mesh_vert + 3 * (int)size[0]; }
-  else { cobj_shape(o, type, size); o.verts = nullptr; }
+// (hull: vertex list + vertex graph, lowering.py hip_mesh_*: nadr[v] .. nadr[v + 1] index the mesh-local neighbour numbers of vertex v in nbr,
+// start = six axis-extreme vertices)
+__device__ __forceinline__ void cobj_shape_poly(CObj& o, int type, const float* size, const float* mesh_vert, const int* nbr_adr, const int* nbr, const int* start) {
+  o.verts = nullptr; o.nadr = nullptr; o.nbr = nullptr; o.start = nullptr;
+  if (type == 6) { o.S[0] = size[0]; o.S[1] = size[1]; o.S[2] = size[2]; o.h = -2.f; }
+  else if (type == 7) {
+    const int adr = (int)size[0];
+    o.S[0] = size[1]; o.S[1] = o.S[2] = 0.f; o.h = -3.f;
+    o.verts = mesh_vert + 3 * adr; o.nadr = nbr_adr + adr; o.nbr = nbr; o.start = start + 6 * (int)size[2];
+  } else cobj_shape(o, type, size);
 }
 template <int MODE> __device__ __forceinline__ void support_shape(const CObj& o, const float* dl, float* pl) {
   if (MODE == 2 && o.h == -2.f) { pl[0] = dl[0] >= 0.f ? o.S[0] : -o.S[0]; pl[1] = dl[1] >= 0.f ? o.S[1] : -o.S[1]; pl[2] = dl[2] >= 0.f ? o.S[2] : -o.S[2]; return; }
   if (MODE == 2 && o.h == -3.f) {
     const int n = (int)o.S[0];
     float bd = -1e30f, bx = 0.f, by = 0.f, bz = 0.f;
-    for (int i = 0; i < n; i++) {
-      const float x = o.verts[3 * i], y = o.verts[3 * i + 1], z = o.verts[3 * i + 2], t = x * dl[0] + y * dl[1] + z * dl[2];
-      if (t > bd) { bd = t; bx = x; by = y; bz = z; }
+    if (n <= 24) {          // small hull: scan
+      for (int i = 0; i < n; i++) {
+        const float x = o.verts[3 * i], y = o.verts[3 * i + 1], z = o.verts[3 * i + 2], t = x * dl[0] + y * dl[1] + z * dl[2];
+        if (t > bd) { bd = t; bx = x; by = y; bz = z; }
+      }
+    } else {                // climb the hull's vertex graph: a vertex no neighbour beats is the support vertex (convexity)
+      int cur = 0;
+      for (int k = 0; k < 6; k++) {
+        const int i = o.start[k];
+        const float x = o.verts[3 * i], y = o.verts[3 * i + 1], z = o.verts[3 * i + 2], t = x * dl[0] + y * dl[1] + z * dl[2];
+        if (t > bd) { bd = t; bx = x; by = y; bz = z; cur = i; }
+      }
+      for (int it = 0; it < 128; it++) {
+        int nxt = cur;
+        const int e1 = o.nadr[cur + 1];
+        for (int e = o.nadr[cur]; e < e1; e++) {
+          const int i = o.nbr[e];
+          const float x = o.verts[3 * i], y = o.verts[3 * i + 1], z = o.verts[3 * i + 2], t = x * dl[0] + y * dl[1] + z * dl[2];
+          if (t > bd) { bd = t; bx = x; by = y; bz = z; nxt = i; }
+        }
+        if (nxt == cur) break;
+        cur = nxt;
+      }
     }
     pl[0] = bx; pl[1] = by; pl[2] = bz;
     return;

@@ -566,6 +566,39 @@ def lower(cm):
             cg_size[k] = [float(A["geom_meshadr"][g]), float(A["geom_meshnum"][g]), 0.0]     # hull: first vertex, vertex count (exact in float32)
     A["hip_cg_size"] = cg_size
     A["hip_mesh_vert"] = np.asarray(A["mesh_vert"], float).reshape(-1, 3) if "mesh_vert" in A else np.zeros((0, 3))
+    # hull vertex graphs: on a convex polytope a vertex that beats all its edge neighbours along a direction is the support point, so the
+    # kernels climb the graph (from the best of six axis-extreme start vertices) instead of scanning all vertices (the airplane's visual hull
+    # has 500).  nbr_adr is indexed by the GLOBAL vertex number, nbr holds mesh-local neighbour numbers, start[6 per mesh] likewise local.
+    nbr_adr, nbr, starts, mesh_of = [0], [], [], {}
+    if "geom_meshadr" in A and len(A["hip_mesh_vert"]):
+        from scipy.spatial import ConvexHull
+        V = A["hip_mesh_vert"]
+        for g in cgs:
+            adr, num = int(A["geom_meshadr"][g]), int(A["geom_meshnum"][g])
+            if m.geom_type[g] != GEOM_MESH or adr < 0 or adr in mesh_of:
+                continue
+            mesh_of[adr] = len(mesh_of)
+        for adr in sorted(mesh_of, key=lambda a: mesh_of[a]):
+            num = int([A["geom_meshnum"][g] for g in cgs if int(A["geom_meshadr"][g]) == adr][0])
+            P = V[adr:adr + num]
+            hull = ConvexHull(P)
+            adj = [set() for _ in range(num)]
+            for tri in hull.simplices:
+                for i in range(3):
+                    a, b = int(tri[i]), int(tri[(i + 1) % 3])
+                    adj[a].add(b); adj[b].add(a)
+            assert all(adj), "every stored vertex is a hull vertex"
+            assert len(nbr_adr) - 1 == adr, "meshes are stored back to back in first-use order"
+            for i in range(num):
+                nbr += sorted(adj[i]); nbr_adr.append(len(nbr))
+            starts += [int(np.argmax(P[:, 0])), int(np.argmin(P[:, 0])), int(np.argmax(P[:, 1])), int(np.argmin(P[:, 1])), int(np.argmax(P[:, 2])), int(np.argmin(P[:, 2]))]
+        for k, g in enumerate(cgs):
+            if m.geom_type[g] == GEOM_MESH and int(A["geom_meshadr"][g]) in mesh_of:
+                cg_size[k, 2] = float(mesh_of[int(A["geom_meshadr"][g])])
+        A["hip_cg_size"] = cg_size
+    A["hip_mesh_nbr_adr"] = np.array(nbr_adr, np.int32)
+    A["hip_mesh_nbr"] = np.array(nbr if nbr else [0], np.int32)
+    A["hip_mesh_start"] = np.array(starts if starts else [0] * 6, np.int32)
     # joint friction loss (mj_instantiateFriction): per dof [frictionloss, D = 1 / R, B] with R = (1 - d) / d * invweight at the row's
     # constant position 0 (impedance = solimp[0]) and aref = -B * qvel
     fl = np.zeros((nv, 4))

@@ -421,7 +421,13 @@ class _Compiler:
             if self.convex_meshes:
                 from scipy.spatial import ConvexHull
                 v = np.unique(tris.reshape(-1, 3), axis=0)
-                m["hull"] = v[np.sort(ConvexHull(v).vertices)]
+                hv = v[np.sort(ConvexHull(v).vertices)]
+                # MuJoCo re-centres a mesh on its centre of mass; the convex narrow phase (MPR) needs the geom's centre INSIDE the shape and the
+                # broad phase wants a tight sphere about it: the hull is stored about the mean of its vertices (an interior point) and the
+                # geom frame origin moves there (geom_pos below)
+                m["hull_center"] = hv.mean(0)
+                m["hull"] = hv - m["hull_center"]
+                m["hull_rmax"] = float(np.linalg.norm(m["hull"], axis=1).max())
         return m["props"]
 
     def _do_body(self, e, parent, childclass):
@@ -894,6 +900,10 @@ class _Compiler:
                 if _can_pair(i):
                     self._mesh_props(self.geoms[i]["mesh"])
                     self.geoms[i]["size"] = np.array([self.meshes[self.geoms[i]["mesh"]]["rmax"], 0.0, 0.0])
+                    if self.convex_meshes:      # (after the inertia pass above, which used the file's frame)
+                        mm = self.meshes[self.geoms[i]["mesh"]]
+                        self.geoms[i] = dict(self.geoms[i], pos=self.geoms[i]["pos"] + quat2mat(self.geoms[i]["quat"]) @ mm["hull_center"],
+                                             size=np.array([mm["hull_rmax"], 0.0, 0.0]))
                 else:
                     keep.remove(i)
         # convex_meshes: a colliding mesh geom is its convex hull (vertex list in the geom frame; support = best vertex)

@@ -209,6 +209,46 @@ class ReferenceMotion:
             return dict(robot=pick(R["robot"], mixr, self.robot_horizon), robot_vel=pick(R["robot_vel"], mixr, self.robot_horizon),
                         object=pick(R["object"], mixo, self.object_horizon))
 
+    def get_reference_torch(self, time, generator=None):
+        """The same lookup with torch tensors on `time`'s device (float64 inside, like the numpy path): no host round trip per env step.
+        time: [B] tensor.  RANDOM draws come from `generator` (a torch.Generator on that device)."""
+        import torch
+        dev = time.device
+        if not hasattr(self, "_tt") or self._tt["time"].device != dev:
+            self._tt = {k: (None if v is None else torch.as_tensor(np.asarray(v, float), dtype=torch.float64, device=dev))
+                        for k, v in self.reference.items() if k in ("time", "robot", "robot_vel", "object")}
+        R = self._tt
+        t = torch.round(time.to(torch.float64) * 1e4) / 1e4
+        B = t.shape[0]
+        if self.type == "FIXED":
+            return {k: (None if R[k] is None else R[k][:1].expand(B, -1)) for k in ("robot", "robot_vel", "object")}
+        if self.type == "RANDOM":
+            draw = lambda a: None if a is None else a[0] + (a[1] - a[0]) * torch.rand((B, a.shape[1]), dtype=torch.float64, device=dev, generator=generator)
+            return dict(robot=draw(R["robot"]), robot_vel=draw(R["robot_vel"]), object=draw(R["object"]))
+        T = R["time"]
+        idx = torch.clamp(torch.searchsorted(T, t, right=True) - 1, 0, self.horizon - 1)
+        held = t >= T[-1]
+        idx = torch.where(held, torch.full_like(idx, self.horizon - 1), idx)
+        exact = held | (T[idx] == t)
+        nxt = torch.clamp(idx + 1, max=self.horizon - 1)
+        dt = torch.where(exact, torch.ones_like(t), T[nxt] - T[idx])
+        if self.interpolation == "linear":
+            blend = ((t - T[idx]) / dt)[:, None]
+            mixr = mixo = lambda a: (1.0 - blend) * a[idx] + blend * a[nxt]
+        else:
+            blend = (t - T[idx] / dt)[:, None]
+            mixr = lambda a: torch.pow(1.0 - blend, a[idx]) + blend * a[nxt]
+            mixo = lambda a: (1.0 - blend) * a[idx] + blend * a[nxt]
+
+        def pick(a, mix, horizon):
+            if a is None:
+                return None
+            if horizon <= 1:
+                return a[:1].expand(B, -1)
+            return torch.where(exact[:, None], a[idx], mix(a))
+        return dict(robot=pick(R["robot"], mixr, self.robot_horizon), robot_vel=pick(R["robot_vel"], mixr, self.robot_horizon),
+                    object=pick(R["object"], mixo, self.object_horizon))
+
 
 # --------------------------------------------------------------------------------------------- the env
 MYODM_DEFAULT_REFERENCE = dict(          # mjx/myodm_v0.py:306-318 (two rows => RANDOM type)
@@ -343,6 +383,8 @@ class TrackEnv:
         self.obs_dim, self.act_dim = m.nq + m.nv, m.nu
         self._views = {}
         self.metrics = {}
+        self._init_dev = torch.tensor(self.init_qpos, device=dev)
+        self._gen = torch.Generator(device=dev).manual_seed(int(seed))
 
     def view(self, field):
         capi = self._capi
@@ -362,11 +404,17 @@ class TrackEnv:
     def reset(self, seed=None, mask=None):
         """All envs (or those in `mask`) back to init_qpos, zero velocity / activation / time (:152-173; the rng argument is ignored there too)."""
         capi, torch = self._capi, self._torch
-        init = torch.tensor(self.init_qpos, device=f"cuda:{self.device}")
-        sel = slice(None) if mask is None else mask
-        self.view(capi.F_QPOS)[sel] = init
-        for f in (capi.F_QVEL, capi.F_ACT, capi.F_CTRL, capi.F_WARMSTART, capi.F_TIME):
-            self.view(f)[sel] = 0
+        if mask is None:
+            self.view(capi.F_QPOS)[:] = self._init_dev
+            for f in (capi.F_QVEL, capi.F_ACT, capi.F_CTRL, capi.F_WARMSTART, capi.F_TIME):
+                self.view(f).zero_()
+        else:                       # masked, without a host round trip: blend in place
+            mk = mask.reshape(-1, 1)
+            q = self.view(capi.F_QPOS)
+            q.copy_(torch.where(mk, self._init_dev, q))
+            for f in (capi.F_QVEL, capi.F_ACT, capi.F_CTRL, capi.F_WARMSTART, capi.F_TIME):
+                v = self.view(f)
+                v.mul_((~mk).to(v.dtype))
         return self._obs()
 
     def step(self, action):
@@ -374,16 +422,14 @@ class TrackEnv:
         dev = f"cuda:{self.device}"
         a = torch.as_tensor(action, dtype=torch.float32, device=dev).reshape(self.num_envs, self.act_dim)
         self.view(capi.F_CTRL)[:] = (a + 1) * (self._hi - self._lo) * 0.5 + self._lo                       # :272-275
-        t0 = self.view(capi.F_TIME)[:, 0].double().cpu().numpy() + self.motion_start_time                    # reference at the pre-step time (:278-279)
-        r = self.ref.get_reference(t0)
-        ref = {k: (None if v is None else torch.as_tensor(v, dtype=torch.float32, device=dev)) for k, v in r.items()}
+        t0 = self.view(capi.F_TIME)[:, 0].double() + self.motion_start_time                                  # reference at the pre-step time (:278-279)
+        r = self.ref.get_reference_torch(t0, self._gen)
+        ref = {k: (None if v is None else v.to(torch.float32)) for k, v in r.items()}
         self.batch.step(None, capi.ACTMAP_NONE, self.n_frames, self._stream())
         obs = self._obs()
         reward, done, self.metrics = self.rwd(ref, self.view(capi.F_QPOS), self.view(capi.F_QVEL), self.view(capi.F_LINKX))
         if self.autoreset:
-            m = done > 0
-            if bool(m.any()):
-                obs = self.reset(mask=m)
+            obs = self.reset(mask=done > 0)
         return obs, reward, done, {"metrics": self.metrics}
 
     def status(self):

@@ -81,7 +81,8 @@ def test_object_rests_on_the_table_with_condim4_rows(track):
         assert o.step(5) == 0
     o.forward()
     z = o.field("qpos")[-4]
-    hull_z = float(np.asarray(m.mesh_vert)[:, 2].min())
+    hulls = [g for g in range(m.ngeom) if int(m.geom_meshnum[g]) > 0]                # hull vertices are stored about each hull's centre (= geom_pos)
+    hull_z = min(float(m.geom_pos[g][2] + np.asarray(m.mesh_vert)[int(m.geom_meshadr[g]):int(m.geom_meshadr[g]) + int(m.geom_meshnum[g]), 2].min()) for g in hulls)
     assert abs((0.035 + z) + hull_z) < 3e-3                                      # lowest hull point on the table top (z = 0)
     cons = o.contacts()
     table = {i for i, t in enumerate(np.asarray(m.geom_type)) if t == 6}
