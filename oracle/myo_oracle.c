@@ -1220,7 +1220,42 @@ static void portal_dir(const Sup* p, real* dir) { /* normal of the portal triang
 /* returns 1 if penetrating; fills depth, dir (from obj1 to obj2), pos */
 static long g_mpr_hist[64];   /* developer statistics: refinement steps per MPR call */
 void myoo_mpr_hist(long* out, int reset) { for (int k = 0; k < 64; k++) { out[k] = g_mpr_hist[k]; if (reset) g_mpr_hist[k] = 0; } }
+/* Output convention of the penetration query (test hook; default 0).
+ *   0: final support plane, refinement converged to 1e-11 (what the HIP path implements; DESIGN.md 3, deviation 1)
+ *   1: libccd's own output as MuJoCo 3.2.8 receives it (third-party dependency, not vendored in /root/reference: libccd 2.1,
+ *      src/mpr.c findPenetr + src/vec3.c ccdVec3PointTriDist2, restated from the published algorithm): refinement stopped at
+ *      MuJoCo's ccd_tolerance 1e-6, depth = distance from the origin to the NEAREST POINT OF THE FINAL PORTAL TRIANGLE, direction =
+ *      that point normalised.  tests/test_oracle_mpr_modes.py measures the gap between the two on seeded hand states. */
+static int g_mpr_mode = 0;
+void myoo_set_mpr_mode(int mode) { g_mpr_mode = mode; }
+static real seg_dist2(const real* a, const real* b, real* w) {   /* origin to segment ab (libccd ccdVec3PointSegmentDist2 with P = 0) */
+  real d[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+  real t = -(a[0] * d[0] + a[1] * d[1] + a[2] * d[2]) / (d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (t <= 0) { for (int k = 0; k < 3; k++) w[k] = a[k]; }
+  else if (t >= 1) { for (int k = 0; k < 3; k++) w[k] = b[k]; }
+  else { for (int k = 0; k < 3; k++) w[k] = a[k] + t * d[k]; }
+  return w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+}
+static real tri_dist2(const real* x0, const real* B, const real* Cc, real* w) {  /* origin to triangle: interior solution, else the nearest edge */
+  real d1[3], d2[3];
+  for (int k = 0; k < 3; k++) { d1[k] = B[k] - x0[k]; d2[k] = Cc[k] - x0[k]; }
+  real v = dot3(d1, d1), ww = dot3(d2, d2), pp = dot3(x0, d1), q = dot3(x0, d2), r = dot3(d1, d2);
+  real sdiv = ww * v - r * r;
+  real s = sdiv != 0 ? (q * r - ww * pp) / sdiv : (real)-1;
+  real t = (-s * r - q) / ww;
+  const real e = (real)2.2e-16;
+  if (s >= -e && s <= 1 + e && t >= -e && t <= 1 + e && t + s <= 1 + e) {
+    for (int k = 0; k < 3; k++) w[k] = x0[k] + s * d1[k] + t * d2[k];
+    return dot3(w, w);
+  }
+  real w2[3], best = seg_dist2(x0, B, w), dd = seg_dist2(x0, Cc, w2);
+  if (dd < best) { best = dd; for (int k = 0; k < 3; k++) w[k] = w2[k]; }
+  dd = seg_dist2(B, Cc, w2);
+  if (dd < best) { best = dd; for (int k = 0; k < 3; k++) w[k] = w2[k]; }
+  return best;
+}
 static int mpr_penetration(const CObj* o1, const CObj* o2, real tol, int maxit, real* depth, real* dirout, real* posout) {
+  if (g_mpr_mode == 1) { tol = (real)1e-6; maxit = 50; }
   Sup p[4];
   real dir[3], va[3], vb[3];
   /* v0: interior point = centre difference */
@@ -1312,6 +1347,12 @@ static int mpr_penetration(const CObj* o1, const CObj* o2, real tol, int maxit, 
     sum = bw[1] + bw[2] + bw[3];
   }
   real inv = 1 / sum;
+  if (g_mpr_mode == 1) {
+    real w[3];
+    real d2 = tri_dist2(p[1].v, p[2].v, p[3].v, w);
+    *depth = sqrt(d2);
+    if (*depth > 0) for (int k = 0; k < 3; k++) dir[k] = w[k] / *depth;
+  }
   for (int k = 0; k < 3; k++) {
     dirout[k] = dir[k];
     posout[k] = (real)0.5 * inv * (bw[0] * (p[0].v1[k] + p[0].v2[k]) + bw[1] * (p[1].v1[k] + p[1].v2[k]) +

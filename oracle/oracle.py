@@ -95,6 +95,11 @@ class Oracle:
         a = np.ascontiguousarray(data, np.float32).ravel()
         self.lib.myoo_set_hfield(self.m, self.d, a.ctypes.data)
 
+    def set_mpr_mode(self, mode):
+        """0 = support-plane output (default, what the HIP path implements); 1 = libccd's nearest-point-of-the-portal output at MuJoCo's
+        ccd_tolerance 1e-6.  Process-wide switch in the loaded library: restore 0 after use."""
+        self.lib.myoo_set_mpr_mode(int(mode))
+
     def reset(self):
         self.lib.myoo_reset(self.m, self.d)
 

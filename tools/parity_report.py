@@ -1,5 +1,7 @@
 """SURVEY.md 8d parity protocol, run on the GPU box: N seeded states per config, identical float32 state injected into the
 f64 oracle and the HIP path, ONE env step (10 substeps), max-abs-err of qpos / qvel / act and of the observation vector.
+Beside each HIP figure the report carries the FLOAT32 FLOOR: the same states through the float32 BUILD of the oracle (same algorithm and
+operation order as the f64 checker, `real` = float) against the f64 oracle -- what single precision alone does to these states.
 Writes gpurun_out/parity_report.json (copy to profiles/)."""
 import json, os, sys, time
 import numpy as np
@@ -49,6 +51,14 @@ def run(name, m, st, nsub=10):
         r["qpos"][e], r["qvel"][e], r["act"][e] = o.field("qpos"), o.field("qvel"), o.field("act")
         ncon[e] = o.ncon
         nefc[e] = o.nefc
+    o32 = Oracle(m.blob(), f32=True)
+    r32 = {k: np.zeros_like(r[k]) for k in r}
+    ncon32 = np.zeros(N, int)
+    for e in range(N):
+        o32.reset(); o32.set_state(qpos=qpos[e], qvel=qvel[e], act=act[e], ctrl=ctrl[e], warm=np.zeros(m.nv), time=0)
+        o32.step(nsub)
+        r32["qpos"][e], r32["qvel"][e], r32["act"][e] = o32.field("qpos"), o32.field("qvel"), o32.field("act")
+        ncon32[e] = o32.ncon
     same = (g["diag"][:, 1] == ncon) & (flags == 0)
     free = same & (ncon == 0)
     cont = same & (ncon > 0)
@@ -62,6 +72,12 @@ def run(name, m, st, nsub=10):
             continue
         d = {k: np.abs(g[k] - r[k])[mask] for k in r}
         out[label] = {k: dict(max=float(v.max()), p99=float(np.quantile(v.max(axis=1), 0.99)), median=float(np.median(v.max(axis=1)))) for k, v in d.items()}
+        m32 = mask & (ncon32 == ncon)
+        d32 = {k: np.abs(r32[k] - r[k])[m32] for k in r}
+        out[label]["float32_oracle_floor"] = {k: dict(max=float(v.max()), p99=float(np.quantile(v.max(axis=1), 0.99)), median=float(np.median(v.max(axis=1)))) for k, v in d32.items()}
+        out[label]["float32_oracle_floor"]["envs"] = int(m32.sum())
+        worst = int(np.flatnonzero(mask)[np.argmax(d["qpos"].max(axis=1))])
+        out[label]["worst_env"] = dict(env=worst, hip_qpos_err=float(np.abs(g["qpos"] - r["qpos"])[worst].max()), float32_oracle_qpos_err=float(np.abs(r32["qpos"] - r["qpos"])[worst].max()))
         # observation entries built from the state: qpos, qvel * dt, act (pose / reach / walk layouts, Appendix C)
         out[label]["obs_state_entries_max"] = float(max(d["qpos"].max(), d["qvel"].max() * dt, d["act"].max()))
         # the same figures over the envs whose active-row count of the last substep agrees (a limit / contact sitting exactly at its

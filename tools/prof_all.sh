@@ -22,8 +22,11 @@ pmc pmc3 SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_WAIT_I
 pmc pmc4 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAIT_INST_ANY
 pmc pmc5 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_LDS_BANK_CONFLICT
 pmc pmc6 GRBM_GUI_ACTIVE SQ_INSTS_FLAT SQ_INSTS_VALU_MFMA_I8 SQ_WAVES_EQ_64
+pmc pmc7 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_ACCESSES_sum
+pmc pmc8 TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum
+pmc pmc9 SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQ_INST_CYCLES_SMEM
 cd $R
-SKIP=30 python3 tools/prof_collect.py $O/${TAG}_pmc_step_kernel_hand.json "step_kernel_w<24" 6389760 $O/prof_${TAG}_trace $O/prof_${TAG}_fetch $O/prof_${TAG}_write $O/prof_${TAG}_pmc1 $O/prof_${TAG}_pmc2 $O/prof_${TAG}_pmc3 $O/prof_${TAG}_pmc4 $O/prof_${TAG}_pmc5 $O/prof_${TAG}_pmc6
+SKIP=30 python3 tools/prof_collect.py $O/${TAG}_pmc_step_kernel_hand.json "step_kernel_w<24" 6389760 $O/prof_${TAG}_trace $O/prof_${TAG}_fetch $O/prof_${TAG}_write $O/prof_${TAG}_pmc1 $O/prof_${TAG}_pmc2 $O/prof_${TAG}_pmc3 $O/prof_${TAG}_pmc4 $O/prof_${TAG}_pmc5 $O/prof_${TAG}_pmc6 $O/prof_${TAG}_pmc7 $O/prof_${TAG}_pmc8 $O/prof_${TAG}_pmc9
 cp $(find $O/prof_${TAG}_trace -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats_hand.csv
 grep "^{\"metric\"" $O/prof_${TAG}_trace.log | tail -1 > $O/${TAG}_bench_line_under_rocprof.json
 # legs

@@ -41,5 +41,12 @@ if "SQ_THREAD_CYCLES_VALU" in c and "SQ_ACTIVE_INST_VALU" in c and c["SQ_ACTIVE_
     res["valu_active_lane_fraction"] = c["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]["mean_per_launch"])
 if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
     res["wave_cycles_waiting_fraction"] = c["SQ_WAIT_ANY"]["mean_per_launch"] / c["SQ_WAVE_CYCLES"]["mean_per_launch"]
+g = lambda k: c[k]["mean_per_launch"] if k in c else None
+if g("TCP_TOTAL_CACHE_ACCESSES_sum") and g("TCP_TCC_READ_REQ_sum") is not None:
+    res["vector_l1_miss_fraction"] = (g("TCP_TCC_READ_REQ_sum") + (g("TCP_TCC_WRITE_REQ_sum") or 0.0)) / g("TCP_TOTAL_CACHE_ACCESSES_sum")
+if g("TCP_TCC_READ_REQ_LATENCY_sum") and g("TCP_TCC_READ_REQ_sum"):
+    res["l1_to_l2_read_latency_cycles"] = g("TCP_TCC_READ_REQ_LATENCY_sum") / g("TCP_TCC_READ_REQ_sum")
+if g("SQC_DCACHE_REQ") and g("SQC_DCACHE_MISSES") is not None:
+    res["scalar_cache_miss_fraction"] = g("SQC_DCACHE_MISSES") / g("SQC_DCACHE_REQ")
 json.dump(res, open(out_path, "w"), indent=1)
 print(json.dumps(res.get("traffic", {})), [k["name"][:40] + f" {k['avg_us']:.1f}us x{k['calls']}" for k in res.get("kernel_stats", [])[:3]])
