@@ -223,10 +223,11 @@ def main():
     except Exception:
         pass
     # measured VALU issue peak of THIS chip at the step kernel's occupancy (4 waves per SIMD): a 20 ms v_fma_f32 probe after the timed region
-    valu_peak = None
+    valu_peak, valu_peak_by_occupancy = None, None
     if rank == 0:
-        try:
-            valu_peak = capi.probe_valu(4, 20000, local)[0]
+        try:   # v_fma_f32 issue-rate microbenchmark at 1 / 2 / 4 / 8 waves per SIMD; the step kernel runs at 4
+            valu_peak_by_occupancy = {str(w): capi.probe_valu(w, 20000, local)[0] for w in (1, 2, 4, 8)}
+            valu_peak = valu_peak_by_occupancy["4"]
         except Exception:
             valu_peak = None
     if rank == 0:
@@ -263,7 +264,7 @@ def main():
                              "wave_insts_per_launch": valu_insts, "insts_source": f"committed rocprofv3 profile {PMC_FILE}",
                              "peak_wave_insts_per_s": valu_peak if valu_peak else N_SIMD * CLOCK_HZ / VALU_CYCLES,
                              "peak_source": "measured in this run: myo_probe_valu, 4 waves per SIMD" if valu_peak else "guide: 1024 SIMDs x 2.4 GHz / 2 cycles",
-                             "peak_guide": N_SIMD * CLOCK_HZ / VALU_CYCLES,
+                             "peak_guide": N_SIMD * CLOCK_HZ / VALU_CYCLES, "peak_measured_by_waves_per_simd": valu_peak_by_occupancy,
                              "frac": valu_insts / (k_ms * 1e-3) / (valu_peak if valu_peak else N_SIMD * CLOCK_HZ / VALU_CYCLES)}},
             "event_ms_per_step_rank0": ev_ms / args.steps,
             **({"repeats": len(runs), "value_per_repeat": [world * B * args.steps / r[0] for r in runs]} if len(runs) > 1 else {}),

@@ -289,12 +289,12 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
       m->generic_ok = !w.has_free && w.neq == 0 && !plane_pairs && !condim1 && w.nq == d.nv && d.maxkc <= KCMAX && !w.has_tl && !m->has_affine;
     }
     // TrackEnv model class (lowering: hip_trk = condim-4 pairs | friction loss | box / hull geoms): tables of the TRK instantiation
-    w.fl = nullptr; w.mesh_vert = nullptr; w.mesh_nbr_adr = nullptr; w.mesh_nbr = nullptr; w.mesh_start = nullptr;
+    w.fl = nullptr; w.mesh_vert = nullptr; w.mesh_rec = nullptr; w.mesh_startrec = nullptr; w.mesh_aabb = nullptr;
     m->trk = false;
     if (blob_find(blob, "hip_trk")) {
       std::vector<int> tk;
       if ((rc = load_i(m, blob, "hip_trk", &tmpi, &tk)) || (rc = load_f(m, blob, "hip_fl", &w.fl)) || (rc = load_f(m, blob, "hip_mesh_vert", &w.mesh_vert)) ||
-          (rc = load_i(m, blob, "hip_mesh_nbr_adr", &w.mesh_nbr_adr)) || (rc = load_i(m, blob, "hip_mesh_nbr", &w.mesh_nbr)) || (rc = load_i(m, blob, "hip_mesh_start", &w.mesh_start))) { myo_model_free(m); return rc; }
+          (rc = load_f(m, blob, "hip_mesh_rec", &w.mesh_rec)) || (rc = load_f(m, blob, "hip_mesh_startrec", &w.mesh_startrec)) || (rc = load_f(m, blob, "hip_mesh_aabb", &w.mesh_aabb))) { myo_model_free(m); return rc; }
       m->trk = tk[0] || tk[1] || tk[2];
     }
     const bool common = d.nl <= 64 && d.ncg <= 64 && w.nq <= 64 && w.neq <= 64 && d.maxnnz <= 20;
@@ -399,8 +399,8 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   { void* pw = nullptr; if ((rc = balloc(b, &pw, sizeof(DevWalk)))) { myo_batch_free(b); return rc; } b->d_walk = (DevWalk*)pw; }
   BA(b->d_stamps, (size_t)B * 12 * 2 * 2)      // 2 x 12 long long per workgroup (diagnostic build)
   BA(b->d_order, B)
-  b->sched_stride = (B + 7) / 8 + 1;
-  BA(b->d_sched, 32 + 8 * b->sched_stride)
+  b->sched_stride = (B + 7) / 8 + 1;                 // per queue with 8 queues; launch_step widens it when the device shows fewer XCDs
+  BA(b->d_sched, 32 + B + 64)
 #undef BA
   if (const char* e = getenv("MYO_LANES")) { int g = atoi(e); if (g == 16 || g == 32 || g == 64) g_lanes = g; }
   HIPCHK(hipMemcpy(b->d_jlo, m->jnt_lo.data(), nv * 4, hipMemcpyHostToDevice));
@@ -720,7 +720,10 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
       hipLaunchKernelGGL(balance_kernel, dim3(1), dim3(1024), 0, s, (const int*)b->db.diag, Bn, b->d_order, Bn / 4, prio_mode);
       order = b->d_order;
     }
-    SchedDev S{b->d_sched, b->d_sched + 32, b->sched_stride, nsub + (wk ? 1 : 0)};
+    // one queue per XCD the device (or its partition) shows: MI355X has 32 CUs per XCD, 8 XCDs in SPX mode (a queue keyed on
+    // XCC_ID & 7 would never be drained on a DPX / QPX / CPX partition)
+    const int nqueue = std::max(1, std::min(8, n_cu / 32));
+    SchedDev S{b->d_sched, b->d_sched + 32, nqueue == 8 ? b->sched_stride : (Bn + nqueue - 1) / nqueue + 1, nsub + (wk ? 1 : 0), nqueue};
     if (!kflags)   // instantiation chosen below, as rocprofv3 prints it (bench.py reports it next to the kernel time)
       b->last_kernel = m->rk4 ? (m->wave_cfg == 0 ? "step_kernel_w<24,8,32,1,4,false,0,false,false,true>" : "step_kernel_w<36,20,32,2,2,false,0,false,false,true>") :
                        m->wave_cfg == 2 ? "step_kernel_w<36,20,32,2,2,false,0,false,true>" :

@@ -38,7 +38,7 @@ struct DevModelW {
   HfDev hf;                       // (kept last: the field offsets of the tables above feed the hot loops' scalar loads)
   gpi link_free, dof_qposadr, eq_i, link_chain_adr, link_chain;
   gpf eq_f;
-  gpi mesh_nbr_adr, mesh_nbr, mesh_start;   // hull vertex graphs (lowering.py hip_mesh_*)
+  gpf mesh_rec, mesh_startrec, mesh_aabb;   // hull vertex graphs as float4 records (lowering.py hip_mesh_rec / hip_mesh_startrec); [nmesh][6] vertex bounding boxes
   gpf fl, mesh_vert;    // TRK models: friction-loss rows [nv][4] = loss, D, B, -; hull vertices of the mesh geoms
 };
 
@@ -225,8 +225,10 @@ template <bool S> __device__ __forceinline__ int ldstatei(const int* p) {
 }
 struct SchedDev {
   int* ctl;      // [8][4]: head (next ticket), tail (next publish index), n (envs of this queue), error
-  int* ring;     // [8][stride]: gen << 24 | substep << 20 | env
+  int* ring;     // [nqueue][stride]: gen << 24 | substep << 20 | env
   int stride, nsubtot;
+  int nqueue;    // queues in use = XCDs of the device (or of its partition: 8 in SPX mode, 4 / 2 / 1 in DPX / QPX / CPX, from the CU count):
+                 // a wave serves queue XCC_ID % nqueue, so no queue is left without waves when fewer than 8 XCDs are visible
 };
 #define SCHED_ENV_MASK 0xFFFFF
 __global__ void __launch_bounds__(1024) sched_init_kernel(const int* __restrict__ diag, int B, SchedDev S) {
@@ -235,7 +237,8 @@ __global__ void __launch_bounds__(1024) sched_init_kernel(const int* __restrict_
   const int t = threadIdx.x;
   if (t < 256) hist[t] = 0;
   if (t == 0) cmax_s = 1;
-  if (t < 8) { int n = (B - t + 7) / 8; S.ctl[4 * t] = 0; S.ctl[4 * t + 1] = n; S.ctl[4 * t + 2] = n; S.ctl[4 * t + 3] = 0; }
+  const int nqu = S.nqueue;
+  if (t < 8) { int n = t < nqu ? (B - t + nqu - 1) / nqu : 0; S.ctl[4 * t] = 0; S.ctl[4 * t + 1] = n; S.ctl[4 * t + 2] = n; S.ctl[4 * t + 3] = 0; }
   __syncthreads();
   int cm = 1;
   for (int e = t; e < B; e += 1024) cm = max(cm, diag[(size_t)e * 8 + 3]);
@@ -249,7 +252,7 @@ __global__ void __launch_bounds__(1024) sched_init_kernel(const int* __restrict_
   for (int e = t; e < B; e += 1024) {
     int b = 255 - min(255, (int)(255LL * diag[(size_t)e * 8 + 3] / cmax));
     int r = atomicAdd(&start[b], 1);                  // rank by descending predicted cost: heavy envs are served first
-    S.ring[(r & 7) * S.stride + (r >> 3)] = e;        // generation 0, substep 0
+    S.ring[(r % nqu) * S.stride + r / nqu] = e;       // generation 0, substep 0
   }
 }
 
@@ -326,7 +329,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
   const float damping = lane_id < nv ? M.dof_damping[lane_id] : 0.f;
   // scheduler state of this wave: the queue of the XCD it runs on
-  const int sq_q = SCHED ? (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7) : 0;
+  const int sq_q = SCHED ? (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7) % S.nqueue : 0;
   int* const sq_ctl = SCHED ? S.ctl + 4 * sq_q : nullptr;
   int* const sq_ring = SCHED ? S.ring + (size_t)sq_q * S.stride : nullptr;
   const int sq_n = SCHED ? sq_ctl[2] : 0;
@@ -841,17 +844,34 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             if (FULL && P[4] >= 2) hit = dot3(dif, E + Y.gax + 3 * g1) <= cgrb(g2) + M.pair_f[12 * p];   // plane: signed distance of the bounding sphere
             else hit = dot3(dif, dif) <= bound * bound;
             if constexpr (TRK) {
-              // a box (table top: bounding sphere 0.7 m) is tested as a box: distance from the other geom's centre to the box, in the box frame
+              // a box (table top: bounding sphere 0.7 m) is tested as a box, a hull as the bounding box of its vertices in the mesh frame
+              // (lowering.py hip_mesh_aabb: centre | half sizes): distance from the other geom's centre to that box against the other
+              // geom's bounding sphere + margin.  The airplane's outer hull has a 0.10 m bounding sphere and thin wings.
               const int t1 = M.cg_type[g1], t2 = M.cg_type[g2];
-              if (hit && (t1 == 6 || t2 == 6) && P[4] == 0) {
-                const int gb = t1 == 6 ? g1 : g2, go = t1 == 6 ? g2 : g1;
-                float Rb[9], cl[3], dd[3] = {E[Y.gpos + 3 * go] - E[Y.gpos + 3 * gb], E[Y.gpos + 3 * go + 1] - E[Y.gpos + 3 * gb + 1], E[Y.gpos + 3 * go + 2] - E[Y.gpos + 3 * gb + 2]};
-                geom_world_mat(M, Y, E, gb, Rb);
-                matTvec(cl, Rb, dd);
-                const float* sb = M.cg_size + 3 * gb;
-                const float ex = fmaxf(fabsf(cl[0]) - sb[0], 0.f), ey = fmaxf(fabsf(cl[1]) - sb[1], 0.f), ez = fmaxf(fabsf(cl[2]) - sb[2], 0.f);
-                const float lim = M.cg_rbound[go] + M.pair_f[12 * p];
-                hit = ex * ex + ey * ey + ez * ez <= lim * lim;
+              if (hit && P[4] == 5) {   // plane - hull: the lowest corner of the hull's vertex bounding box along the plane normal
+                float R2[9], nl[3];
+                const float* n = E + Y.gax + 3 * g1;
+                geom_world_mat(M, Y, E, g2, R2);
+                matTvec(nl, R2, n);
+                gpf bx = W.mesh_aabb + 6 * (int)M.cg_size[3 * g2 + 2];
+                const float low = dot3(dif, n) + nl[0] * bx[0] + nl[1] * bx[1] + nl[2] * bx[2] - (fabsf(nl[0]) * bx[3] + fabsf(nl[1]) * bx[4] + fabsf(nl[2]) * bx[5]);
+                hit = low <= M.pair_f[12 * p];
+              }
+              if (hit && (t1 >= 6 || t2 >= 6) && P[4] == 0) {
+#pragma unroll
+                for (int side = 0; side < 2; side++) {
+                  const int gb = side ? g2 : g1, go = side ? g1 : g2, tb = side ? t2 : t1;
+                  if (tb < 6 || !hit) continue;
+                  float Rb[9], cl[3], dd[3] = {E[Y.gpos + 3 * go] - E[Y.gpos + 3 * gb], E[Y.gpos + 3 * go + 1] - E[Y.gpos + 3 * gb + 1], E[Y.gpos + 3 * go + 2] - E[Y.gpos + 3 * gb + 2]};
+                  geom_world_mat(M, Y, E, gb, Rb);
+                  matTvec(cl, Rb, dd);
+                  const float* sb = M.cg_size + 3 * gb;
+                  float hx = sb[0], hy = sb[1], hz = sb[2];
+                  if (tb == 7) { gpf bx = W.mesh_aabb + 6 * (int)sb[2]; cl[0] -= bx[0]; cl[1] -= bx[1]; cl[2] -= bx[2]; hx = bx[3]; hy = bx[4]; hz = bx[5]; }
+                  const float ex = fmaxf(fabsf(cl[0]) - hx, 0.f), ey = fmaxf(fabsf(cl[1]) - hy, 0.f), ez = fmaxf(fabsf(cl[2]) - hz, 0.f);
+                  const float lim = M.cg_rbound[go] + M.pair_f[12 * p];
+                  hit = ex * ex + ey * ey + ez * ez <= lim * lim;
+                }
               }
             }
             if (hit && !P[4]) {
@@ -991,11 +1011,11 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             float R2[9], nl[3], pw[3];
             geom_world_mat(M, Y, E, g2, R2);
             matTvec(nl, R2, n);
-            const float* V = W.mesh_vert + 3 * (int)sz2[0];
-            const int nvx = (int)sz2[1];
-            float best = 1e30f, bx = 0.f, by = 0.f, bz = 0.f;
-            for (int i = 0; i < nvx; i++) { const float x = V[3 * i], y = V[3 * i + 1], z = V[3 * i + 2], t = x * nl[0] + y * nl[1] + z * nl[2]; if (t < best) { best = t; bx = x; by = y; bz = z; } }
-            const float sp[3] = {bx, by, bz};
+            CObj oh;
+            cobj_shape_poly(oh, 7, sz2, W.mesh_vert, (gpf4)W.mesh_rec, (gpf4)W.mesh_startrec);
+            const float dn[3] = {-nl[0], -nl[1], -nl[2]};
+            float sp[3];
+            support_shape<2>(oh, dn, sp);          // vertex-graph climb (scan for small hulls) instead of a pass over all vertices
             matvec(pw, R2, sp);
             float rel[3] = {x2[0] - x1[0] + pw[0], x2[1] - x1[1] + pw[1], x2[2] - x1[2] + pw[2]};
             float d = dot3(rel, n);
@@ -1106,8 +1126,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
 #pragma unroll
             for (int k = 0; k < 3; k++) o1.pos[k] = 0.f;
             if constexpr (TRK) {
-              cobj_shape_poly(o1, M.cg_type[g1], sz1, W.mesh_vert, W.mesh_nbr_adr, W.mesh_nbr, W.mesh_start);
-              cobj_shape_poly(o2, M.cg_type[g2], sz2, W.mesh_vert, W.mesh_nbr_adr, W.mesh_nbr, W.mesh_start);
+              cobj_shape_poly(o1, M.cg_type[g1], sz1, W.mesh_vert, (gpf4)W.mesh_rec, (gpf4)W.mesh_startrec);
+              cobj_shape_poly(o2, M.cg_type[g2], sz2, W.mesh_vert, (gpf4)W.mesh_rec, (gpf4)W.mesh_startrec);
             }
             else { cobj_shape(o1, M.cg_type[g1], sz1); cobj_shape(o2, M.cg_type[g2], sz2); }
             o1.margin = o2.margin = 0.5f * margin;

@@ -286,7 +286,15 @@ __device__ __forceinline__ void make_frame(const float* n, float* t1, float* t2)
 //   ellipsoid S = semi-axes, h = 0 | sphere S = (r,r,r), h = 0 | capsule S = (r,r,r), h = half length | cylinder S = (r,r,0), h = half length.
 // One branch-free formula instead of a per-type switch: in a wave that mixes pad / capsule pairs every lane used to walk through all
 // the type branches of both shapes at each of the ~23 support evaluations of an MPR call.
-struct CObj { float pos[3], mat[9], S[3], h, margin; const float* verts; const int *nadr, *nbr, *start; };  // by value: registers (the pointers: polytope kernels only)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const float4 __attribute__((address_space(1)))* gpf4;
+#else
+typedef const float4* gpf4;
+#endif
+// by value: registers.  Polytope kernels only: verts (small hulls are scanned), rec / srec (vertex graph as self-contained records, lowering.py
+// hip_mesh_rec / hip_mesh_startrec) and the warm start of the climb: hv = the support vertex of this object's previous query [x, y, z, word]
+// (word < 0: none yet).  Successive MPR directions are close, so the next climb usually ends after one look at the neighbours.
+struct CObj { float pos[3], mat[9], S[3], h, margin; const float* verts; gpf4 rec, srec; mutable float hv[4]; };
 __device__ __forceinline__ void cobj_shape(CObj& o, int type, const float* size) {
   if (type == GEOM_ELLIPSOID) { o.S[0] = size[0]; o.S[1] = size[1]; o.S[2] = size[2]; o.h = 0.f; }
   else if (type == GEOM_CYLINDER) { o.S[0] = size[0]; o.S[1] = size[0]; o.S[2] = 0.f; o.h = size[1]; }
@@ -302,13 +310,13 @@ __device__ __forceinline__ void support_local(const float* S, float h, const flo
 // polytope shapes (TrackEnv kernels, MPR mode 2): h = -2: box with half sizes S; h = -3: convex hull, S[0] vertices at `verts` (support = best vertex)
 // (hull: vertex list + vertex graph, lowering.py hip_mesh_*: nadr[v] .. nadr[v + 1] index the mesh-local neighbour numbers of vertex v in nbr,
 // start = six axis-extreme vertices)
-__device__ __forceinline__ void cobj_shape_poly(CObj& o, int type, const float* size, const float* mesh_vert, const int* nbr_adr, const int* nbr, const int* start) {
-  o.verts = nullptr; o.nadr = nullptr; o.nbr = nullptr; o.start = nullptr;
+__device__ __forceinline__ void cobj_shape_poly(CObj& o, int type, const float* size, const float* mesh_vert, gpf4 rec, gpf4 srec) {
+  o.verts = nullptr; o.rec = nullptr; o.srec = nullptr; o.hv[0] = o.hv[1] = o.hv[2] = 0.f; o.hv[3] = -1.f;
   if (type == 6) { o.S[0] = size[0]; o.S[1] = size[1]; o.S[2] = size[2]; o.h = -2.f; }
   else if (type == 7) {
     const int adr = (int)size[0];
     o.S[0] = size[1]; o.S[1] = o.S[2] = 0.f; o.h = -3.f;
-    o.verts = mesh_vert + 3 * adr; o.nadr = nbr_adr + adr; o.nbr = nbr; o.start = start + 6 * (int)size[2];
+    o.verts = mesh_vert + 3 * adr; o.rec = rec; o.srec = srec + 96 * (int)size[2];
   } else cobj_shape(o, type, size);
 }
 template <int MODE> __device__ __forceinline__ void support_shape(const CObj& o, const float* dl, float* pl) {
@@ -322,23 +330,33 @@ template <int MODE> __device__ __forceinline__ void support_shape(const CObj& o,
         if (t > bd) { bd = t; bx = x; by = y; bz = z; }
       }
     } else {                // climb the hull's vertex graph: a vertex no neighbour beats is the support vertex (convexity)
-      int cur = 0;
-      for (int k = 0; k < 6; k++) {
-        const int i = o.start[k];
-        const float x = o.verts[3 * i], y = o.verts[3 * i + 1], z = o.verts[3 * i + 2], t = x * dl[0] + y * dl[1] + z * dl[2];
-        if (t > bd) { bd = t; bx = x; by = y; bz = z; cur = i; }
+      float bw = o.hv[3];
+      if (bw >= 0.f) { bx = o.hv[0]; by = o.hv[1]; bz = o.hv[2]; bd = bx * dl[0] + by * dl[1] + bz * dl[2]; }
+      else {   // first query of this object: start from the direction table (6 cube faces x 4 x 4 cells, lowering.py _cube_dirs)
+        const float a0 = fabsf(dl[0]), a1 = fabsf(dl[1]), a2 = fabsf(dl[2]);
+        const int axis = (a0 >= a1 && a0 >= a2) ? 0 : (a1 >= a2 ? 1 : 2);
+        const float dm = axis == 0 ? dl[0] : (axis == 1 ? dl[1] : dl[2]), du = axis == 0 ? dl[1] : (axis == 1 ? dl[2] : dl[0]), dv = axis == 0 ? dl[2] : (axis == 1 ? dl[0] : dl[1]);
+        const float inv = 2.0f / fmaxf(fabsf(dm), MINVALF);
+        const int iu = min(3, max(0, (int)(du * inv + 2.0f))), iv = min(3, max(0, (int)(dv * inv + 2.0f)));
+        const float4 r = o.srec[((2 * axis + (dm < 0.f ? 1 : 0)) * 4 + iu) * 4 + iv];
+        bd = r.x * dl[0] + r.y * dl[1] + r.z * dl[2]; bx = r.x; by = r.y; bz = r.z; bw = r.w;
       }
       for (int it = 0; it < 128; it++) {
-        int nxt = cur;
-        const int e1 = o.nadr[cur + 1];
-        for (int e = o.nadr[cur]; e < e1; e++) {
-          const int i = o.nbr[e];
-          const float x = o.verts[3 * i], y = o.verts[3 * i + 1], z = o.verts[3 * i + 2], t = x * dl[0] + y * dl[1] + z * dl[2];
-          if (t > bd) { bd = t; bx = x; by = y; bz = z; nxt = i; }
+        const int word = (int)bw, e0 = word >> 6, deg = word & 63;
+        bool moved = false;
+        for (int e = 0; e < deg; e += 4) {       // lists are padded to a multiple of eight records: four independent 16-byte loads in flight at a time
+          float4 r[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) r[k] = o.rec[e0 + e + k];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const float t = r[k].x * dl[0] + r[k].y * dl[1] + r[k].z * dl[2];
+            if (t > bd) { bd = t; bx = r[k].x; by = r[k].y; bz = r[k].z; bw = r[k].w; moved = true; }
+          }
         }
-        if (nxt == cur) break;
-        cur = nxt;
+        if (!moved) break;
       }
+      o.hv[0] = bx; o.hv[1] = by; o.hv[2] = bz; o.hv[3] = bw;
     }
     pl[0] = bx; pl[1] = by; pl[2] = bz;
     return;

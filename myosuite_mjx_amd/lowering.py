@@ -51,6 +51,22 @@ def _rel_transforms(m):
     return head, R, p
 
 
+
+def _cube_dirs():
+    """Centres of the 6 x 4 x 4 direction cells of the hull start table, in the kernel's cell order (support_shape, myo_physics.h):
+    cell = ((2 * axis + (d[axis] < 0)) * 4 + iu) * 4 + iv, u / v = the two other components (cyclic order) over |d[axis]|, in [-1, 1]."""
+    out = []
+    for axis in range(3):
+        for neg in (0, 1):
+            for iu in range(4):
+                for iv in range(4):
+                    d = np.zeros(3)
+                    d[axis] = -1.0 if neg else 1.0
+                    d[(axis + 1) % 3] = (iu + 0.5) / 2 - 1
+                    d[(axis + 2) % 3] = (iv + 0.5) / 2 - 1
+                    out.append(d / np.linalg.norm(d))
+    return out
+
 def lower(cm):
     m = cm
     A = cm.arrays
@@ -599,6 +615,42 @@ def lower(cm):
     A["hip_mesh_nbr_adr"] = np.array(nbr_adr, np.int32)
     A["hip_mesh_nbr"] = np.array(nbr if nbr else [0], np.int32)
     A["hip_mesh_start"] = np.array(starts if starts else [0] * 6, np.int32)
+    # the same graph as self-contained records, one 16-byte load per neighbour and no index chasing: entry e of the adjacency list holds the
+    # neighbour's position AND where the neighbour's own (padded) adjacency list sits: [x, y, z, float(64 * first_entry + padded_degree)] (exact in float32).
+    # A climb step is then one level of independent loads; hip_mesh_startrec carries, per mesh, a 96-cell direction table of start vertices
+    # (_cube_dirs) in the same form.
+    rec, srec = [], []
+    if len(nbr):
+        V = A["hip_mesh_vert"]
+        adrs = sorted(mesh_of, key=lambda a: mesh_of[a])
+        nums = [int([A["geom_meshnum"][g] for g in cgs if int(A["geom_meshadr"][g]) == a][0]) for a in adrs]
+        # each adjacency list is padded to a multiple of EIGHT entries (last neighbour repeated) so that the kernel loads eight records at a
+        # time without a bounds test; first_rec[v] = where global vertex v's padded list starts
+        pad4 = lambda n: (n + 7) // 8 * 8
+        first_rec = np.concatenate([[0], np.cumsum([pad4(nbr_adr[v + 1] - nbr_adr[v]) for v in range(len(nbr_adr) - 1)])]).astype(int)
+        assert first_rec[-1] < (1 << 18), "adjacency entry numbers are stored exactly in a float32"
+        for a, num in zip(adrs, nums):
+            word = lambda v: float(64 * first_rec[a + v] + pad4(nbr_adr[a + v + 1] - nbr_adr[a + v]))
+            assert max(pad4(nbr_adr[a + v + 1] - nbr_adr[a + v]) for v in range(num)) < 64
+            for v in range(num):
+                lst = nbr[nbr_adr[a + v]:nbr_adr[a + v + 1]]
+                lst = lst + [lst[-1]] * (pad4(len(lst)) - len(lst))
+                assert len(rec) == first_rec[a + v]
+                for w in lst:
+                    rec.append([V[a + w, 0], V[a + w, 1], V[a + w, 2], word(w)])
+            # start table of the climb: 6 cube faces x 4 x 4 cells of directions, each holding the support vertex of the cell centre
+            for d in _cube_dirs():
+                w = int(np.argmax(V[a:a + num] @ d))
+                srec.append([V[a + w, 0], V[a + w, 1], V[a + w, 2], word(w)])
+    # vertex bounding box of each mesh in the mesh frame (broad phase of the TRK kernels): centre | half sizes
+    aabb = []
+    if len(nbr):
+        for a, num in zip(adrs, nums):
+            lo, hi = V[a:a + num].min(0), V[a:a + num].max(0)
+            aabb.append(np.concatenate([(lo + hi) / 2, (hi - lo) / 2]))
+    A["hip_mesh_aabb"] = np.array(aabb if aabb else [[0.0] * 6], float)
+    A["hip_mesh_rec"] = np.array(rec if rec else [[0.0] * 4], float)
+    A["hip_mesh_startrec"] = np.array(srec if srec else [[0.0] * 4] * 96, float)
     # joint friction loss (mj_instantiateFriction): per dof [frictionloss, D = 1 / R, B] with R = (1 - d) / d * invweight at the row's
     # constant position 0 (impedance = solimp[0]) and aref = -B * qvel
     fl = np.zeros((nv, 4))
