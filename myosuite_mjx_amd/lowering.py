@@ -672,6 +672,12 @@ def lower(cm):
                              int(any(m.geom_type[g] in (GEOM_BOX, GEOM_MESH) for g in cgs))], np.int32)
     A["hip_cg_rbound"] = m.geom_rbound[cgs] if cgs else np.zeros(0)
     A["hip_cg_geom"] = np.array(cgs, np.int32)
+    # pair order = candidate order = lane order of the narrow phase, whose 64-lane rounds each cost their slowest lane: the pairs that go
+    # through MPR (generic convex, height-field prisms) come first, so that an env with more than 64 candidates (the usual case for MyoHand:
+    # ~87 per substep, ~20 of them MPR) runs ONE round with MPR lanes and then rounds of analytic pairs only, instead of paying the MPR
+    # latency in every round
+    order = sorted(range(len(pairs_i)), key=lambda i: 0 if pairs_i[i][4] in (0, 4) else 1)
+    pairs_i, pairs_f = [pairs_i[i] for i in order], [pairs_f[i] for i in order]
     A["hip_pair_i"] = np.array(pairs_i, np.int32).reshape(-1, PAIR_INTS)
     A["hip_pair_f"] = np.array(pairs_f).reshape(-1, PAIR_FLTS)
     A["hip_pair_dl"] = np.array(pair_dl, np.int32).reshape(-1, 2)
