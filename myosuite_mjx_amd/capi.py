@@ -76,6 +76,26 @@ def build_library(force=False, verbose=False):
     return LIB_PATH
 
 
+def build_diagnostic(variant, force=False, verbose=False):
+    """Diagnostic builds of the same sources next to libmyo_hip.so (selected at run time with MYO_HIP_LIB=<path>):
+    "poison" (-DMYO_POISON=1): every LDS word of an env's slice starts as a NaN, so a read of a word the launch never wrote -- or a kernel
+    whose addressing went wrong -- shows up in the parity tests (tests/test_gpu_poison.py runs them against this build);
+    "stamps" (-DMYO_STAMPS=1): clock64 per stage (tools/gpu_stamps.py)."""
+    flag = {"poison": "-DMYO_POISON=1", "stamps": "-DMYO_STAMPS=1"}[variant]
+    out = os.path.join(os.path.dirname(LIB_PATH), f"libmyo_hip_{variant}.so")
+    csrc = os.path.dirname(SRC_PATH)
+    newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= newest:
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=on", flag,
+           "-shared", "-fPIC", "-o", out, SRC_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 _lib = None
 
 

@@ -358,6 +358,13 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   float warm = 0.f, qacc = 0.f, actdot[NTR];
 #pragma unroll
   for (int r = 0; r < NTR; r++) actdot[r] = 0.f;
+#if MYO_POISON   // diagnostic build: LDS words start as NaN, so a read of a word this launch never wrote shows up in the results
+  // MYO_POISON = 1: everything; 2: state + frames (qpos .. anchor); 3: xv, qfc; 4: sq; 5: mprw / tJp; 6: region X
+  { const int lo_ = MYO_POISON == 1 ? 0 : MYO_POISON == 2 ? 0 : MYO_POISON == 3 ? Y.xv : MYO_POISON == 4 ? Y.sq : MYO_POISON == 5 ? Y.mprw : Y.X;
+    const int hi_ = MYO_POISON == 1 ? Y.total : MYO_POISON == 2 ? Y.xv : MYO_POISON == 3 ? Y.sq : MYO_POISON == 4 ? Y.mprw : MYO_POISON == 5 ? Y.X : Y.total;
+    for (int i = lo_ + lane_id; i < hi_; i += 64) E[i] = __int_as_float(0x7fc00000); }
+  SYNC();
+#endif
   if (lane_id < nq) E[Y.qpos + lane_id] = ldstate<SCHED>(Bt.qpos + (size_t)env * nq + lane_id);
   if (lane_id < nv) {
     E[Y.qvel + lane_id] = ldstate<SCHED>(Bt.qvel + (size_t)env * nv + lane_id);
@@ -426,6 +433,20 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     }
     STAMP(0);
     // ---------------------------------------------------------------- kinematics (lane = link, level by level)
+    // sines / cosines of all hinge angles first, lane = dof, into the (at this point dead) Hessian scratch: the level loop below would
+    // otherwise evaluate them one after the other inside each link lane (two-dof links: twice), five levels deep.  All 64 lanes evaluate
+    // (clamped index) and only the stores are predicated: the same pass with sincosf inside `if (lane < nv)` produced wrong results in the
+    // generic (SPEC = 0) instantiation on the MI355X -- garbage LDS reads all over the kernel in the -DMYO_POISON build -- while any variant
+    // that also kept an inline sincosf was fine; the cause was not found (tests/test_gpu_poison.py guards the whole class)
+    {
+      const int dd = lane < nv ? lane : 0;
+      const int qa = W.dof_qposadr[dd];
+      float sn, cs;
+      sincosf(E[Y.qpos + qa] - M.qpos0[qa], &sn, &cs);
+      const bool hinge = M.dof_type[dd] == 3;
+      if (lane < nv) { E[Y.sq + lane] = hinge ? sn : 0.f; E[Y.sq + NVT + lane] = hinge ? cs : 1.f; }
+    }
+    SYNC();
     for (int L = 0; L < nlevel_; L++) {
       int l = M.level_adr[L] + lane;
       if (l < M.level_adr[L + 1]) {
@@ -472,8 +493,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           E[Y.anchor + 3 * d] = an[0]; E[Y.anchor + 3 * d + 1] = an[1]; E[Y.anchor + 3 * d + 2] = an[2];
           float ang = E[Y.qpos + W.dof_qposadr[d]] - M.qpos0[W.dof_qposadr[d]];
           if (M.dof_type[d] == 3) {
-            float sn, cs;
-            sincosf(ang, &sn, &cs);
+            const float sn = E[Y.sq + d], cs = E[Y.sq + NVT + d];
             float oc = 1 - cs, x = al[0], y = al[1], z = al[2];
             float Rj[9] = {cs + oc * x * x, oc * x * y - sn * z, oc * x * z + sn * y, oc * x * y + sn * z, cs + oc * y * y, oc * y * z - sn * x,
                            oc * x * z - sn * y, oc * y * z + sn * x, cs + oc * z * z};
@@ -756,16 +776,16 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       }
       break;
     }
+    // backward accumulation of the link forces (6) and composite inertias (10), leaves to root: lane = (link of the level, component), so a
+    // link with five children (the wrist) costs five adds per lane instead of 80 read-add-writes in one lane
     for (int L = nlevel_ - 2; L >= 0; L--) {
-      int l = M.level_adr[L] + lane;
-      if (l < M.level_adr[L + 1]) {
-        for (int ci = M.child_adr[l]; ci < M.child_adr[l + 1]; ci++) {
-          int c = M.child[ci];
-#pragma unroll
-          for (int k = 0; k < 6; k++) E[Y.cfrc + 6 * l + k] += E[Y.cfrc + 6 * c + k];
-#pragma unroll
-          for (int k = 0; k < 10; k++) E[Y.crb + 10 * l + k] += E[Y.crb + 10 * c + k];
-        }
+      const int l0 = M.level_adr[L], nn = (M.level_adr[L + 1] - l0) * 16;
+      for (int idx = lane; idx < nn; idx += 64) {
+        const int l = l0 + (idx >> 4), k = idx & 15;
+        const int base = k < 6 ? Y.cfrc + k : Y.crb + (k - 6), str = k < 6 ? 6 : 10;
+        float acc = E[base + str * l];
+        for (int ci = M.child_adr[l]; ci < M.child_adr[l + 1]; ci++) acc += E[base + str * M.child[ci]];
+        E[base + str * l] = acc;
       }
       SYNC();
     }
