@@ -1534,25 +1534,45 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             float Wn = w0 + w1 + w2 + w3 + w4 + w5, A1 = cmu * (w0 - w1), A2 = cmu * (w2 - w3), B1 = cmu * cmu * (w0 + w1), B2 = cmu * cmu * (w2 + w3);
             const float A3 = cmut * (w4 - w5), B3 = cmut * cmut * (w4 + w5);
             SYNC();
-            for (int c = 0; c < ncon; c++) {   // one contact per step, lanes = entries of its kc x kc block
-              int kc = rdlanei(ckc, c);
-              float sW = rdlane(Wn, c), sA1 = rdlane(A1, c), sA2 = rdlane(A2, c), sB1 = rdlane(B1, c), sB2 = rdlane(B2, c);
-              const float sA3 = TRK ? rdlane(A3, c) : 0.f, sB3 = TRK ? rdlane(B3, c) : 0.f;
-              if (sW == 0.f) continue;
-              auto hblock = [&](const float* cJ, const unsigned int* cdw) {
-                for (int t = lane; t < kc * kc; t += 64) {
-                  int a = t / kc, b = t - a * kc;
-                  int da = CDOFP(cdw, a), db = CDOFP(cdw, b);
-                  if (da >= db) {
-                    float na = cJ[a], nb = cJ[b], ta = cJ[KC + a], tb = cJ[KC + b], ua = cJ[2 * KC + a], ub = cJ[2 * KC + b];
-                    float hv = sW * na * nb + sA1 * (na * tb + ta * nb) + sA2 * (na * ub + ua * nb) + sB1 * ta * tb + sB2 * ua * ub;
-                    if constexpr (TRK) { const float sa = cJ[3 * KC + a], sb = cJ[3 * KC + b]; hv += sA3 * (na * sb + sa * nb) + sB3 * sa * sb; }
-                    atomicAdd(&E[Y.sq + da * (NVT + 1) + db], hv);
-                  }
+            // 64 / KC contacts per pass, lane = (contact of the pass, row a of its kc x kc block): the lane folds the contact's weights into
+            // its row (hv = n_b p_n + t1_b p_t + t2_b p_u [+ s_b p_s]) and walks the columns b; the entries of different contacts meet in
+            // the LDS atomics.  (One contact per pass with lane = block entry spent 7 passes per contact on a 20-dof block, half of the
+            // lanes above the diagonal: 25 % of the TrackEnv kernel.)
+            {
+              constexpr int HG = 64 / KC;
+              const int hg = lane / KC, ha = lane - hg * KC;
+              for (int c0 = 0; c0 < ncon; c0 += HG) {
+                const int c = c0 + hg;
+                const bool on = hg < HG && c < ncon;
+                const int cs = on ? c : 0;
+                const float sW = __shfl(Wn, cs), sA1 = __shfl(A1, cs), sA2 = __shfl(A2, cs), sB1 = __shfl(B1, cs), sB2 = __shfl(B2, cs);
+                const float sA3 = TRK ? __shfl(A3, cs) : 0.f, sB3 = TRK ? __shfl(B3, cs) : 0.f;
+                const int kc = __shfl(ckc, cs);
+                if (on && sW != 0.f && ha < kc) {
+                  auto hrow = [&](const float* cJ, const unsigned int* cdw) {
+                    const int da = CDOFP(cdw, ha);
+                    const float na = cJ[ha], ta = cJ[KC + ha], ua = cJ[2 * KC + ha];
+                    float pn = sW * na + sA1 * ta + sA2 * ua, ps = 0.f;
+                    const float pt = sA1 * na + sB1 * ta, pu = sA2 * na + sB2 * ua;
+                    if constexpr (TRK) { const float sa = cJ[3 * KC + ha]; pn += sA3 * sa; ps = sA3 * na + sB3 * sa; }
+                    for (int hb0 = 0; hb0 < kc; hb0 += 4) {   // four columns at a time: all reads first, then the atomics back to back
+                      float hv[4];
+                      int db[4];
+#pragma unroll
+                      for (int u = 0; u < 4; u++) {
+                        const int hb = min(hb0 + u, KC - 1);
+                        db[u] = (hb0 + u < kc) ? CDOFP(cdw, hb) : 0x7fffffff;
+                        hv[u] = pn * cJ[hb] + pt * cJ[KC + hb] + pu * cJ[2 * KC + hb];
+                        if constexpr (TRK) hv[u] += ps * cJ[3 * KC + hb];
+                      }
+#pragma unroll
+                      for (int u = 0; u < 4; u++) if (da >= db[u]) atomicAdd(&E[Y.sq + da * (NVT + 1) + db[u]], hv[u]);
+                    }
+                  };
+                  if (c < NC) hrow(E + Y.cJ + c * NJ * KC, (const unsigned int*)(E + Y.cdofs) + CDW * c);
+                  else { const float* g = ovf_env + (c - NC) * ovf_row; hrow(g + 8, (const unsigned int*)(g + 8 + NJ * KC)); }
                 }
-              };
-              if (c < NC) hblock(E + Y.cJ + c * NJ * KC, (const unsigned int*)(E + Y.cdofs) + CDW * c);
-              else { const float* g = ovf_env + (c - NC) * ovf_row; hblock(g + 8, (const unsigned int*)(g + 8 + NJ * KC)); }
+              }
             }
             if (eact) {
               atomicAdd(&E[Y.sq + ed1 * (NVT + 1) + ed1], eD);

@@ -24,3 +24,11 @@ tot = st[:, :10].sum(1)
 print("dims", hm.dims.env_lds_bytes if hasattr(hm, "dims") else "", "per-WG total cycles mean", tot.mean(), "max", tot.max(), "diag ncon mean", b.read(capi.F_DIAG)[:, 1].mean(), "ncand", (b.read(capi.F_DIAG)[:, 4] & 0xFFFF).mean() / 5, "f_mpr (sum over rounds of the slowest lane's support evaluations) per substep", b.read(capi.F_DIAG)[:, 5].mean() / 5)
 for k, n in enumerate(NAMES):
     print(f"   {n:26s} {st[:,k].mean()/5:12,.0f} cycles/substep  {100*st[:,k].mean()/tot.mean():5.1f}%")
+sub = st2[B:]
+SUBN = ["newton: forces, cost, gradient, convergence test", "newton: Hessian assembly", "newton+euler: build rows, Cholesky, store L", "newton+euler: triangular solves",
+        "newton: M*search, J*search", "newton: line search", "newton: start (M*warm, J*warm)"]
+for k, n in enumerate(SUBN):
+    print(f"      {n:52s} {sub[:,k].mean()/5:12,.0f} cycles/substep  {100*sub[:,k].mean()/tot.mean():5.1f}%")
+d = b.read(capi.F_DIAG)
+print("   per substep: newton iterations %.2f, factorisations %.2f, line-search evaluations %.2f, constraint rows (last substep) %.1f" %
+      ((d[:, 6] >> 16).mean() / 5, (d[:, 7] >> 16).mean() / 5, (d[:, 7] & 0xFFFF).mean() / 5, d[:, 0].mean()))
