@@ -41,6 +41,7 @@ struct myo_model {
   int env_lds_bytes_w = 0;
   bool wave_ok = false, generic_ok = false;
   int n_cu = 0;                 // compute units of the model's device (scheduler sizing)
+  int kin_floats = 0;           // LDS scratch the two-phase kinematics needs (lowering.py hip_kin_size)
   bool rk4 = false;             // <option integrator="RK4">: the RK4 instantiations of the wave kernel (generic sizes, no scheduler)
   int wave_wpe = 4;             // hand-class kernel variant: 4 waves per SIMD with 32 LDS contact slots, or 5 with 16 (MYO_HAND_WPE)
   bool trk = false;             // TrackEnv model class: step_kernel_w<36,20,32,2,2,false,0,false,true>
@@ -266,7 +267,14 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
       if ((rc = load_i(m, blob, "hip_flags", &tmpi, &fl)) || (rc = load_i(m, blob, "hip_link_free", &w.link_free)) ||
           (rc = load_i(m, blob, "hip_dof_qposadr", &w.dof_qposadr)) || (rc = load_i(m, blob, "hip_link_chain_adr", &w.link_chain_adr)) ||
           (rc = load_i(m, blob, "hip_link_chain", &w.link_chain)) || (rc = load_i(m, blob, "hip_eq_i", &w.eq_i)) ||
+          (rc = load_i(m, blob, "hip_kin_base", &w.kin_base)) || (rc = load_i(m, blob, "hip_kin_adr", &w.kin_adr)) || (rc = load_i(m, blob, "hip_kin_vec", &w.kin_vec)) ||
           (rc = load_f(m, blob, "hip_eq_f", &w.eq_f)) || (rc = load_i(m, blob, "hip_pair_i", &tmpi, &pi))) { myo_model_free(m); return rc; }
+      {
+        std::vector<int> ks;
+        if ((rc = load_i(m, blob, "hip_kin_size", &tmpi, &ks))) { myo_model_free(m); return rc; }
+        m->kin_floats = ks[0];   // checked against the Hessian scratch (nvt x (nvt + 1)) once the kernel class is known
+        w.kin_dnmax = ks.size() > 1 ? ks[1] : 6;
+      }
       w.has_free = fl[0]; w.nq = fl[1]; w.neq = fl[2];
       if (fl.size() < 6) { myo_model_free(m); return fail(MYO_E_BLOB, "hip_flags: blob predates the actuator-kind tables; recompile the model"); }
       w.has_j0 = fl[3]; d.na_obs = fl[4]; m->has_affine = fl[5] != 0;
@@ -324,6 +332,8 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
     if (m->rk4) m->hand_sizes = m->leg_sizes = m->terrain_sizes = false;
     if (const char* e = getenv("MYO_NO_SPEC")) if (atoi(e) == 1) m->hand_sizes = m->leg_sizes = m->terrain_sizes = false;   // tests: force the run-time-sized instantiations
     if (!m->wave_ok && !m->generic_ok) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "model exceeds the limits of both step kernels (nv <= 36, nu <= 128, pair dofs <= 20)"); }
+    { const int nvt = m->wave_cfg == 0 ? 24 : 36;
+      if (m->wave_ok && m->kin_floats > nvt * (nvt + 1)) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "kinematics scratch exceeds the Hessian scratch it borrows"); } }
     m->env_lds_bytes_w = w.lay.total * 4;
     if (m->wave_ok && m->env_lds_bytes_w > 64 * 1024) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "wave kernel working set exceeds 64 KB of LDS"); }
     void* p1 = nullptr; void* p2 = nullptr;
@@ -699,7 +709,7 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, true, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 4, false, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 3, false, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 16, 1, 5, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 16, 1, 5, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -725,7 +735,7 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     const int nqueue = std::max(1, std::min(8, n_cu / 32));
     SchedDev S{b->d_sched, b->d_sched + 32, nqueue == 8 ? b->sched_stride : (Bn + nqueue - 1) / nqueue + 1, nsub + (wk ? 1 : 0), nqueue};
     if (!kflags)   // instantiation chosen below, as rocprofv3 prints it (bench.py reports it next to the kernel time)
-      b->last_kernel = m->rk4 ? (m->wave_cfg == 0 ? "step_kernel_w<24,8,32,1,4,false,0,false,false,true>" : "step_kernel_w<36,20,32,2,2,false,0,false,false,true>") :
+      b->last_kernel = m->rk4 ? (m->wave_cfg == 0 ? "step_kernel_w<24,8,32,1,3,false,0,false,false,true>" : "step_kernel_w<36,20,32,2,2,false,0,false,false,true>") :
                        m->wave_cfg == 2 ? "step_kernel_w<36,20,32,2,2,false,0,false,true>" :
                        (m->wave_cfg == 0 && m->wave_wpe == 5) ? (m->hand_sizes ? "step_kernel_w<24,8,16,1,5,false,1,false,false>" : "step_kernel_w<24,8,16,1,5,false,0,false,false>") : sched ? (m->wave_cfg == 0 ? "step_kernel_w<24,8,32,1,4,true,0,false>" : m->dw.hf.on ? "step_kernel_w<36,20,32,2,2,true,3,true>" : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,true,2,false>" : "step_kernel_w<36,20,32,2,2,true,0,false>"))
                              : (m->wave_cfg == 0 ? (m->hand_sizes ? "step_kernel_w<24,8,32,1,4,false,1,false>" : "step_kernel_w<24,8,32,1,4,false,0,false>")
@@ -748,7 +758,7 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
         hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, true, 0>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                            (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, (const int*)nullptr, wk, 0, S);
     } else if (m->rk4 && m->wave_cfg == 0)
-      hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, false, 0, false, false, true>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+      hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 3, false, 0, false, false, true>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                          (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0, S);
     else if (m->rk4)
       hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, false, 0, false, false, true>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,

@@ -37,6 +37,8 @@ struct DevModelW {
   gpf gt_j0;
   HfDev hf;                       // (kept last: the field offsets of the tables above feed the hot loops' scalar loads)
   gpi link_free, dof_qposadr, eq_i, link_chain_adr, link_chain;
+  int kin_dnmax;                    // longest joint chain of a non-free link (uniform trip count of the phase-1 loop)
+  gpi kin_base, kin_adr, kin_vec;   // two-phase kinematics (lowering.py hip_kin_*): scratch base per link, per-level lists of (link, vector) entries
   gpf eq_f;
   gpf mesh_rec, mesh_startrec, mesh_aabb;   // hull vertex graphs as float4 records (lowering.py hip_mesh_rec / hip_mesh_startrec); [nmesh][6] vertex bounding boxes
   gpf fl, mesh_vert;    // TRK models: friction-loss rows [nv][4] = loss, D, B, -; hull vertices of the mesh geoms
@@ -358,11 +360,14 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   float warm = 0.f, qacc = 0.f, actdot[NTR];
 #pragma unroll
   for (int r = 0; r < NTR; r++) actdot[r] = 0.f;
+#ifndef MYO_POISON_BITS
+#define MYO_POISON_BITS 0x7fc00000
+#endif
 #if MYO_POISON   // diagnostic build: LDS words start as NaN, so a read of a word this launch never wrote shows up in the results
   // MYO_POISON = 1: everything; 2: state + frames (qpos .. anchor); 3: xv, qfc; 4: sq; 5: mprw / tJp; 6: region X
   { const int lo_ = MYO_POISON == 1 ? 0 : MYO_POISON == 2 ? 0 : MYO_POISON == 3 ? Y.xv : MYO_POISON == 4 ? Y.sq : MYO_POISON == 5 ? Y.mprw : Y.X;
     const int hi_ = MYO_POISON == 1 ? Y.total : MYO_POISON == 2 ? Y.xv : MYO_POISON == 3 ? Y.sq : MYO_POISON == 4 ? Y.mprw : MYO_POISON == 5 ? Y.X : Y.total;
-    for (int i = lo_ + lane_id; i < hi_; i += 64) E[i] = __int_as_float(0x7fc00000); }
+    for (int i = lo_ + lane_id; i < hi_; i += 64) E[i] = __int_as_float(MYO_POISON_BITS); }
   SYNC();
 #endif
   if (lane_id < nq) E[Y.qpos + lane_id] = ldstate<SCHED>(Bt.qpos + (size_t)env * nq + lane_id);
@@ -433,82 +438,104 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     }
     STAMP(0);
     // ---------------------------------------------------------------- kinematics (lane = link, level by level)
-    // sines / cosines of all hinge angles first, lane = dof, into the (at this point dead) Hessian scratch: the level loop below would
-    // otherwise evaluate them one after the other inside each link lane (two-dof links: twice), five levels deep.  All 64 lanes evaluate
-    // (clamped index) and only the stores are predicated: the same pass with sincosf inside `if (lane < nv)` produced wrong results in the
-    // generic (SPEC = 0) instantiation on the MI355X -- garbage LDS reads all over the kernel in the -DMYO_POISON build -- while any variant
-    // that also kept an inline sincosf was fine; the cause was not found (tests/test_gpu_poison.py guards the whole class)
+    // Phase 1, lane = link: the link's own joint chain in its PARENT's frame -- rotation columns, origin and, per dof, axis and anchor --
+    // written as 4 + 2 * dofnum vectors to the (at this point dead) Hessian scratch; no link waits for another one here, so the sines /
+    // cosines and the joint rotations of all links are evaluated side by side instead of level after level.  Free-joint links (roots)
+    // take their world pose straight from qpos.  All 64 lanes run the arithmetic on a clamped link index and only the stores are
+    // predicated (a variant with the trigonometry inside `if (lane < ...)` miscompiled in the generic instantiation).
     {
-      const int dd = lane < nv ? lane : 0;
-      const int qa = W.dof_qposadr[dd];
-      float sn, cs;
-      sincosf(E[Y.qpos + qa] - M.qpos0[qa], &sn, &cs);
-      const bool hinge = M.dof_type[dd] == 3;
-      if (lane < nv) { E[Y.sq + lane] = hinge ? sn : 0.f; E[Y.sq + NVT + lane] = hinge ? cs : 1.f; }
-    }
-    SYNC();
-    for (int L = 0; L < nlevel_; L++) {
-      int l = M.level_adr[L] + lane;
-      if (l < M.level_adr[L + 1]) {
-        float pos[3], R[9];
-        int par = M.link_parent[l];
-        const float* lp = M.link_pos + 3 * l;
-        if (par < 0) {
-          pos[0] = lp[0]; pos[1] = lp[1]; pos[2] = lp[2];
+      const int l = lane < nl_ ? lane : 0;
+      const bool mine = lane < nl_;
+      const float* lp = M.link_pos + 3 * l;
+      float A[9], c[3] = {lp[0], lp[1], lp[2]};
 #pragma unroll
-          for (int k = 0; k < 9; k++) R[k] = W.link_mat0[9 * l + k];
-        } else {
-          float v[3];
-          matvec(v, E + Y.lmat + 9 * par, lp);
-          pos[0] = E[Y.lpos + 3 * par] + v[0]; pos[1] = E[Y.lpos + 3 * par + 1] + v[1]; pos[2] = E[Y.lpos + 3 * par + 2] + v[2];
-          matmul3(R, E + Y.lmat + 9 * par, W.link_mat0 + 9 * l);
-        }
-        int da = M.link_dofadr[l], dn = M.link_dofnum[l];
-        if (has_free && W.link_free[l]) {
-          // free joint: pose straight from qpos (position + unit quaternion); its 3 translational dofs act like slides along
-          // the world axes and its 3 rotational dofs like hinges about the body axes through the body origin
-          int qa = W.dof_qposadr[da];
-          pos[0] = E[Y.qpos + qa]; pos[1] = E[Y.qpos + qa + 1]; pos[2] = E[Y.qpos + qa + 2];
-          float q[4] = {E[Y.qpos + qa + 3], E[Y.qpos + qa + 4], E[Y.qpos + qa + 5], E[Y.qpos + qa + 6]};
-          float qn = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-          q[0] *= qn; q[1] *= qn; q[2] *= qn; q[3] *= qn;
-          quat2mat(R, q);
+      for (int k = 0; k < 9; k++) A[k] = W.link_mat0[9 * l + k];
+      const int da = M.link_dofadr[l];
+      int dn = M.link_dofnum[l];
+      const bool isfree = has_free && W.link_free[l];
+      if (isfree) {
+        // free joint: pose straight from qpos (position + unit quaternion); its 3 translational dofs act like slides along
+        // the world axes and its 3 rotational dofs like hinges about the body axes through the body origin
+        const int qa = W.dof_qposadr[da];
+        float pos[3] = {E[Y.qpos + qa], E[Y.qpos + qa + 1], E[Y.qpos + qa + 2]}, R[9];
+        float q[4] = {E[Y.qpos + qa + 3], E[Y.qpos + qa + 4], E[Y.qpos + qa + 5], E[Y.qpos + qa + 6]};
+        float qn = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        q[0] *= qn; q[1] *= qn; q[2] *= qn; q[3] *= qn;
+        quat2mat(R, q);
+        if (mine) {
 #pragma unroll
           for (int k = 0; k < 3; k++) {
             E[Y.axis + 3 * (da + k)] = k == 0 ? 1.f : 0.f; E[Y.axis + 3 * (da + k) + 1] = k == 1 ? 1.f : 0.f; E[Y.axis + 3 * (da + k) + 2] = k == 2 ? 1.f : 0.f;
             E[Y.axis + 3 * (da + 3 + k)] = R[k]; E[Y.axis + 3 * (da + 3 + k) + 1] = R[3 + k]; E[Y.axis + 3 * (da + 3 + k) + 2] = R[6 + k];
 #pragma unroll
-            for (int c = 0; c < 3; c++) { E[Y.anchor + 3 * (da + k) + c] = pos[c]; E[Y.anchor + 3 * (da + 3 + k) + c] = pos[c]; }
+            for (int cc = 0; cc < 3; cc++) { E[Y.anchor + 3 * (da + k) + cc] = pos[cc]; E[Y.anchor + 3 * (da + 3 + k) + cc] = pos[cc]; }
           }
-          dn = 0;
-        }
-        for (int k = 0; k < dn; k++) {
-          int d = da + k;
-          const float* al = M.dof_axis + 3 * d;
-          float ax[3], an[3];
-          matvec(ax, R, al);
-          matvec(an, R, M.dof_pos + 3 * d);
-          an[0] += pos[0]; an[1] += pos[1]; an[2] += pos[2];
-          E[Y.axis + 3 * d] = ax[0]; E[Y.axis + 3 * d + 1] = ax[1]; E[Y.axis + 3 * d + 2] = ax[2];
-          E[Y.anchor + 3 * d] = an[0]; E[Y.anchor + 3 * d + 1] = an[1]; E[Y.anchor + 3 * d + 2] = an[2];
-          float ang = E[Y.qpos + W.dof_qposadr[d]] - M.qpos0[W.dof_qposadr[d]];
-          if (M.dof_type[d] == 3) {
-            const float sn = E[Y.sq + d], cs = E[Y.sq + NVT + d];
-            float oc = 1 - cs, x = al[0], y = al[1], z = al[2];
-            float Rj[9] = {cs + oc * x * x, oc * x * y - sn * z, oc * x * z + sn * y, oc * x * y + sn * z, cs + oc * y * y, oc * y * z - sn * x,
-                           oc * x * z - sn * y, oc * y * z + sn * x, cs + oc * z * z};
-            matmul3(R, R, Rj);
-            float v[3];
-            matvec(v, R, M.dof_pos + 3 * d);
-            pos[0] = an[0] - v[0]; pos[1] = an[1] - v[1]; pos[2] = an[2] - v[2];
-          } else {
-            pos[0] += ax[0] * ang; pos[1] += ax[1] * ang; pos[2] += ax[2] * ang;
-          }
-        }
 #pragma unroll
-        for (int k = 0; k < 3; k++) E[Y.lpos + 3 * l + k] = pos[k];
+          for (int k = 0; k < 3; k++) E[Y.lpos + 3 * l + k] = pos[k];
 #pragma unroll
-        for (int k = 0; k < 9; k++) E[Y.lmat + 9 * l + k] = R[k];
+          for (int k = 0; k < 9; k++) E[Y.lmat + 9 * l + k] = R[k];
+        }
+        dn = 0;
+      }
+      float* const ks = E + Y.sq + W.kin_base[l];
+      // uniform trip count (the model's longest chain) with the body predicated per lane: a loop whose trip count differs between the lanes
+      // would be a long divergent region around the trigonometry, with register spills inside it
+      const int dnmax = W.kin_dnmax;
+      for (int k = 0; k < dnmax; k++) {
+        const bool act = k < dn;
+        const int d = act ? da + k : da;
+        const float* al = M.dof_axis + 3 * d;
+        const float* dp = M.dof_pos + 3 * d;
+        float ax[3], an[3];
+        matvec(ax, A, al);
+        matvec(an, A, dp);
+        an[0] += c[0]; an[1] += c[1]; an[2] += c[2];
+        if (mine && act) {
+          ks[12 + 6 * k] = ax[0]; ks[13 + 6 * k] = ax[1]; ks[14 + 6 * k] = ax[2];
+          ks[15 + 6 * k] = an[0]; ks[16 + 6 * k] = an[1]; ks[17 + 6 * k] = an[2];
+        }
+        const int qa = W.dof_qposadr[d];
+        const float ang = E[Y.qpos + qa] - M.qpos0[qa];
+        const bool hinge = M.dof_type[d] == 3;
+        float sn, cs;
+        sincosf(ang, &sn, &cs);
+        const float oc = 1 - cs, x = al[0], y = al[1], z = al[2];
+        const float Rj[9] = {cs + oc * x * x, oc * x * y - sn * z, oc * x * z + sn * y, oc * x * y + sn * z, cs + oc * y * y, oc * y * z - sn * x,
+                             oc * x * z - sn * y, oc * y * z + sn * x, cs + oc * z * z};
+        float An[9], v[3];
+        matmul3(An, A, Rj);
+        matvec(v, An, dp);
+        const bool rot = act && hinge, lin = act && !hinge;
+#pragma unroll
+        for (int i = 0; i < 9; i++) A[i] = rot ? An[i] : A[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) c[i] = rot ? an[i] - v[i] : (lin ? c[i] + ax[i] * ang : c[i]);
+      }
+      if (mine && !isfree) {
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) { ks[3 * cc] = A[cc]; ks[3 * cc + 1] = A[3 + cc]; ks[3 * cc + 2] = A[6 + cc]; }   // column cc of the local rotation
+        ks[9] = c[0]; ks[10] = c[1]; ks[11] = c[2];
+      }
+    }
+    SYNC();
+    // Phase 2, level by level, lane = (link of the level, vector): world = parent rotation x local vector (+ parent origin for points)
+    for (int L = 0; L < nlevel_; L++) {
+      const int e0 = W.kin_adr[L], e1 = W.kin_adr[L + 1];
+      for (int e = e0 + lane; e < e1; e += 64) {
+        const int w0 = W.kin_vec[2 * e], src = W.kin_vec[2 * e + 1];
+        const int l = w0 & 255, kind = (w0 >> 8) & 3, ix = w0 >> 16;
+        const int par = M.link_parent[l];
+        const float v[3] = {E[Y.sq + src], E[Y.sq + src + 1], E[Y.sq + src + 2]};
+        float w[3] = {v[0], v[1], v[2]};
+        if (par >= 0) {
+          matvec(w, E + Y.lmat + 9 * par, v);
+          if (kind & 1) { w[0] += E[Y.lpos + 3 * par]; w[1] += E[Y.lpos + 3 * par + 1]; w[2] += E[Y.lpos + 3 * par + 2]; }
+        }
+        if (kind == 0) { E[Y.lmat + 9 * l + ix] = w[0]; E[Y.lmat + 9 * l + 3 + ix] = w[1]; E[Y.lmat + 9 * l + 6 + ix] = w[2]; }
+        else {
+          float* const dst = kind == 1 ? E + Y.lpos + 3 * l : (kind == 2 ? E + Y.axis + 3 * ix : E + Y.anchor + 3 * ix);
+          dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2];
+        }
       }
       SYNC();
     }

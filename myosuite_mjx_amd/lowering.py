@@ -524,6 +524,36 @@ def lower(cm):
         chain_adr[l + 1] = len(chain)
     A["hip_link_chain_adr"] = chain_adr
     A["hip_link_chain"] = np.array(chain, np.int32)
+    # kinematics of the wave kernel in two phases: (1) lane = link evaluates the link's own joint chain in its PARENT's frame (independent of
+    # every other link): the columns of R_loc, the origin p_loc and, per dof, axis and anchor, 4 + 2 * dofnum vectors written to an LDS scratch
+    # at kin_base[l] + 3 j; (2) level by level, lane = (link of the level, vector) maps one vector to the world with the parent's frame.
+    # kin_vec entry = [link | kind << 8 | index << 16, scratch offset]: kind 0 = column `index` of the link's rotation, 1 = link origin,
+    # 2 = axis of dof `index`, 3 = anchor of dof `index` (kinds 1 and 3 are points: the parent's origin is added).  Free-joint links take
+    # their pose from qpos directly and have no entries.
+    kin_base = np.zeros(nl, np.int32)
+    o = 0
+    for l in range(nl):
+        kin_base[l] = o
+        if not link_free[l]:
+            o += 3 * (4 + 2 * int(link_dofnum[l]))
+    kin_adr, kin_vec = [0], []
+    for L in range(nlevel):
+        for l in range(int(level_adr[L]), int(level_adr[L + 1])):
+            if link_free[l]:
+                continue
+            j = 0
+            for c in range(3):
+                kin_vec.append([l | (0 << 8) | (c << 16), int(kin_base[l]) + 3 * j]); j += 1
+            kin_vec.append([l | (1 << 8), int(kin_base[l]) + 3 * j]); j += 1
+            for k in range(int(link_dofnum[l])):
+                d = int(link_dofadr[l]) + k
+                kin_vec.append([l | (2 << 8) | (d << 16), int(kin_base[l]) + 3 * j]); j += 1
+                kin_vec.append([l | (3 << 8) | (d << 16), int(kin_base[l]) + 3 * j]); j += 1
+        kin_adr.append(len(kin_vec))
+    A["hip_kin_base"] = kin_base
+    A["hip_kin_adr"] = np.array(kin_adr, np.int32)
+    A["hip_kin_vec"] = np.array(kin_vec if kin_vec else [[0, 0]], np.int32)
+    A["hip_kin_size"] = np.array([o, max([int(link_dofnum[l]) for l in range(nl) if not link_free[l]] + [0])], np.int32)   # scratch floats, longest non-free joint chain
     act_obs = np.full(nu, -1, np.int32)      # slot of each actuator's activation in the observation's "act" block (sim.data.act order)
     act_obs[kind == 0] = np.arange(int((kind == 0).sum()))
     # height field (terrain models): [on, nrow, ncol, collision-geom index] and [x, y half extents, z scale, base depth, position]
