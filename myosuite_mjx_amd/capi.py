@@ -78,8 +78,9 @@ def build_library(force=False, verbose=False):
 
 def build_diagnostic(variant, force=False, verbose=False):
     """Diagnostic builds of the same sources next to libmyo_hip.so (selected at run time with MYO_HIP_LIB=<path>):
-    "poison" (-DMYO_POISON=1): every LDS word of an env's slice starts as a NaN, so a read of a word the launch never wrote -- or a kernel
-    whose addressing went wrong -- shows up in the parity tests (tests/test_gpu_poison.py runs them against this build);
+    "poison" (-DMYO_POISON=1): every LDS word of an env's slice starts as a NaN and the scratch memory of every wave slot is filled with NaNs
+    before each step launch, so a read of a word the launch never wrote -- or a kernel whose addressing went wrong -- shows up in the parity
+    tests (tests/test_gpu_poison.py runs them against this build);
     "stamps" (-DMYO_STAMPS=1): clock64 per stage (tools/gpu_stamps.py)."""
     flag = {"poison": "-DMYO_POISON=1", "stamps": "-DMYO_STAMPS=1"}[variant]
     out = os.path.join(os.path.dirname(LIB_PATH), f"libmyo_hip_{variant}.so")

@@ -689,6 +689,9 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     attr_set = true;
   }
   long long* st = b->d_stamps;
+#if MYO_POISON
+  hipLaunchKernelGGL(scratch_poison_kernel, dim3(16384), dim3(64), 0, s, (float*)b->d_stamps, 0);
+#endif
   if (!(G == 64 && m->wave_ok) && !m->generic_ok)
     return fail(MYO_E_UNSUPPORTED, "this model (tendon limits / free joint / equalities / plane contacts) needs the wave-per-env kernel (lanes = 64)");
   if (G == 64 && m->wave_ok) {

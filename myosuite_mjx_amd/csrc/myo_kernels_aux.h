@@ -368,6 +368,16 @@ __global__ void __launch_bounds__(64) reach_obs_kernel(DevModel M, DevBatch Bt, 
 // own dependent-issue latency is not the limit), with W waves resident on every SIMD (workgroup = 4 W waves, one workgroup per CU forced
 // by its LDS request).  wave-instructions / elapsed time = what the chip's VALUs can issue at that occupancy, at the clock the chip
 // actually holds under this load.
+#if MYO_POISON
+// diagnostic build: fills the private (scratch) memory of every wave slot with NaNs before each step launch, so that a register spill
+// which is stored under a partial exec mask and reloaded under a wider one (or any other read of a scratch word the kernel did not write)
+// turns into wrong numbers instead of depending on what earlier kernels left there
+__global__ void __launch_bounds__(64) scratch_poison_kernel(float* sink, int n) {
+  volatile float buf[512];
+  for (int i = 0; i < 512; i++) buf[i] = __int_as_float(0x7fc00000 | i);
+  if (n < 0) sink[threadIdx.x] = buf[(-n) & 511];
+}
+#endif
 __global__ void __launch_bounds__(1024) valu_probe_kernel(float* out, int iters, float seed) {
   extern __shared__ float lds_dummy[];
   float a0 = seed, a1 = seed + 1.f, a2 = seed + 2.f, a3 = seed + 3.f, a4 = seed + 4.f, a5 = seed + 5.f, a6 = seed + 6.f, a7 = seed + 7.f;

@@ -1,7 +1,9 @@
 """The parity tests once more against the -DMYO_POISON=1 build of the same sources (libmyo_hip_poison.so, built by
-__graft_entry__.build()): every word of an env's LDS slice starts as a NaN there, so a read of a word the launch never wrote -- or a kernel
-whose LDS addressing went wrong, as one variant of the kinematics pre-pass did in round 2 without any plain test noticing reliably --
-turns into wrong numbers or flagged envs instead of passing on whatever the previous workgroup left behind.  Runs in a child process because
+__graft_entry__.build()): every word of an env's LDS slice starts as a NaN there, and a helper kernel fills the private (scratch) memory of
+every wave slot with NaNs before each step launch.  A read of an LDS word the launch never wrote, a register spill stored under a partial
+exec mask and reloaded under a wider one, or a kernel whose addressing went wrong (as two variants of the kinematics pass did in round 2,
+order-dependently and without any plain test noticing reliably) then turns into wrong numbers or flagged envs instead of passing on
+whatever earlier workgroups and kernels left behind.  Runs in a child process because
 the library is chosen when it is first loaded (MYO_HIP_LIB)."""
 import os
 import subprocess
@@ -18,7 +20,7 @@ def test_parity_suites_pass_on_the_lds_poisoned_build():
     assert os.path.exists(lib), "libmyo_hip_poison.so is missing: run __graft_entry__.build()"
     env = dict(os.environ, MYO_HIP_LIB=lib)
     suites = ["tests/test_gpu_parity.py", "tests/test_gpu_legs.py", "tests/test_gpu_track.py", "tests/test_gpu_hold.py", "tests/test_gpu_terrain.py",
-              "tests/test_gpu_rk4.py", "tests/test_gpu_conditions.py"]
+              "tests/test_gpu_rk4.py", "tests/test_gpu_conditions.py", "tests/test_gpu_walk.py", "tests/test_gpu_env.py"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", *suites], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
