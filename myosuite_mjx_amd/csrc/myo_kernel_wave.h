@@ -1347,6 +1347,66 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         if (P[5] == 4) { cmut = F[11]; cD2 = cD; caref[4] = -B * (vn + cmut * vs) + pos; caref[5] = -B * (vn - cmut * vs) + pos; }
       }
     };
+    if constexpr (KC == 8 && !FULL && !TRK) {
+      // hand / finger kernels: jacobians with lane = (contact of the pass, dof slot), eight contacts per pass -- each lane one column of the
+      // three rows (normal, two tangents) instead of one lane walking its contact's eight dofs -- then the row constants with lane = contact
+      float vn_c = 0.f, vt1_c = 0.f, vt2_c = 0.f;
+      const int rg = lane >> 3, rk = lane & 7;
+      for (int c0 = 0; c0 < ncon; c0 += 8) {
+        const int c = c0 + rg;
+        float pv0 = 0.f, pv1 = 0.f, pv2 = 0.f;
+        auto row_cols = [&](const float* ppos, const float* pnrm, const int* ppair, float* cJ, unsigned int* cdw) {
+          const int* P = M.pair_i + 6 * ppair[0];
+          const float n[3] = {pnrm[0], pnrm[1], pnrm[2]}, cp[3] = {ppos[0], ppos[1], ppos[2]};
+          float t1[3], t2[3];
+          make_frame(n, t1, t2);
+          float jn = 0.f, j1 = 0.f, j2 = 0.f;
+          int d = 0;
+          if (rk < P[3]) {
+            d = M.pair_dl[2 * (P[2] + rk)];
+            const float sg = (float)M.pair_dl[2 * (P[2] + rk) + 1];
+            const float* ax = E + Y.axis + 3 * d;
+            float col[3];
+            if (M.dof_type[d] == 3) {
+              const float r[3] = {cp[0] - E[Y.anchor + 3 * d], cp[1] - E[Y.anchor + 3 * d + 1], cp[2] - E[Y.anchor + 3 * d + 2]};
+              cross3(col, ax, r);
+            } else { col[0] = ax[0]; col[1] = ax[1]; col[2] = ax[2]; }
+            jn = sg * dot3(n, col); j1 = sg * dot3(t1, col); j2 = sg * dot3(t2, col);
+            const float qv = E[Y.qvel + d];
+            pv0 = jn * qv; pv1 = j1 * qv; pv2 = j2 * qv;
+          }
+          cJ[rk] = jn; cJ[KC + rk] = j1; cJ[2 * KC + rk] = j2;
+          ((unsigned char*)cdw)[rk] = (unsigned char)d;   // padded entries: zero jacobian, dof 0
+        };
+        if (c < ncon) {
+          if (c < NC) row_cols(E + Y.cpos + 3 * c, E + Y.cnrm + 3 * c, (const int*)(E + Y.cpair) + c, E + Y.cJ + c * NJ * KC, (unsigned int*)(E + Y.cdofs) + CDW * c);
+          else { float* g = ovf_env + (c - NC) * ovf_row; row_cols(g + 1, g + 4, (const int*)g + 7, g + 8, (unsigned int*)(g + 8 + NJ * KC)); }
+        }
+#pragma unroll
+        for (int m_ = 1; m_ < 8; m_ <<= 1) { pv0 += __shfl_xor(pv0, m_); pv1 += __shfl_xor(pv1, m_); pv2 += __shfl_xor(pv2, m_); }
+        const int src = (8 * (lane - c0)) & 63;      // lane = contact c0 + j takes the sums of group j
+        const float a0 = __shfl(pv0, src), a1 = __shfl(pv1, src), a2 = __shfl(pv2, src);
+        if (lane >= c0 && lane < c0 + 8) { vn_c = a0; vt1_c = a1; vt2_c = a2; }
+      }
+      SYNC();
+      if (lane < ncon) {
+        const float* g = lane < NC ? nullptr : ovf_env + (lane - NC) * ovf_row;
+        const int p = lane < NC ? ((const int*)(E + Y.cpair))[lane] : ((const int*)g)[7];
+        const float dist = lane < NC ? E[Y.cdist + lane] : g[0];
+        const int* P = M.pair_i + 6 * p;
+        const float* F = M.pair_f + 12 * p;
+        ckc = P[3];
+        const float incl = F[0] - F[1];
+        cmu = F[2];
+        float imp = impedance(F + 6, dist, incl), K, B;
+        kbi(F[4], F[5], F[7], M.timestep, &K, &B);
+        const float R0 = fmaxf(MINVALF, (1 - imp) / imp * F[3] * (1 + cmu * cmu));
+        cD = 1.0f / fmaxf(MINVALF, 2 * cmu * cmu * R0);
+        const float pos = -K * imp * (dist - incl);
+        caref[0] = -B * (vn_c + cmu * vt1_c) + pos; caref[1] = -B * (vn_c - cmu * vt1_c) + pos;
+        caref[2] = -B * (vn_c + cmu * vt2_c) + pos; caref[3] = -B * (vn_c - cmu * vt2_c) + pos;
+      }
+    } else
     if (lane < ncon) {
       if (lane < NC) build_row(E + Y.cdist + lane, E + Y.cpos + 3 * lane, E + Y.cnrm + 3 * lane, (const int*)(E + Y.cpair) + lane, E + Y.cJ + lane * NJ * KC,
                                (unsigned int*)(E + Y.cdofs) + CDW * lane);
