@@ -226,8 +226,13 @@ def main():
     valu_peak, valu_peak_by_occupancy = None, None
     if rank == 0:
         try:   # v_fma_f32 issue-rate microbenchmark at 1 / 2 / 4 / 8 waves per SIMD; the step kernel runs at 4
-            valu_peak_by_occupancy = {str(w): capi.probe_valu(w, 20000, local)[0] for w in (1, 2, 4, 8)}
-            valu_peak = valu_peak_by_occupancy["4"]
+            valu_peak = capi.probe_valu(4, 20000, local)[0]
+            valu_peak_by_occupancy = {"4": valu_peak}
+            for w in (1, 2, 8):
+                try:
+                    valu_peak_by_occupancy[str(w)] = capi.probe_valu(w, 20000, local)[0]
+                except Exception:
+                    pass
         except Exception:
             valu_peak = None
     if rank == 0:

@@ -952,7 +952,7 @@ const char* myo_bench_last_kernel_name(const myo_batch* b) { return b ? b->last_
 /* measured VALU issue peak of the device at `waves_per_simd` resident waves per SIMD (1, 2, 4 or 8): wave64 v_fma_f32 instructions per second,
  * chip-wide.  One workgroup of 4 * waves_per_simd waves per CU (the LDS request keeps a second workgroup off the CU). */
 int myo_probe_valu(int device, int waves_per_simd, int iters, double* wave_insts_per_s, int* n_cu_out) {
-  if (!wave_insts_per_s || waves_per_simd < 1 || waves_per_simd > 4 || iters < 1) return fail(MYO_E_ARG, "myo_probe_valu: waves_per_simd must be 1..4 (x2 workgroups per CU for 8)");
+  if (!wave_insts_per_s || !(waves_per_simd >= 1 && waves_per_simd <= 4 || waves_per_simd == 8) || iters < 1) return fail(MYO_E_ARG, "myo_probe_valu: waves_per_simd must be 1..4 or 8");
   HIPCHK(hipSetDevice(device));
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -960,13 +960,14 @@ int myo_probe_valu(int device, int waves_per_simd, int iters, double* wave_insts
   const size_t lds = 60 * 1024;   // with 160 KB per CU at most two such workgroups fit: grid = ncu keeps it to one in practice, 2 * ncu gives 8 waves / SIMD
   HIPCHK(hipFuncSetAttribute((const void*)valu_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   float* out = nullptr;
-  const int threads = 256 * waves_per_simd;
+  const int wg_per_cu = waves_per_simd == 8 ? 2 : 1;      // 8 waves per SIMD = two 1024-thread workgroups per CU (2 x 60 KB of LDS fit)
+  const int threads = 256 * (waves_per_simd / wg_per_cu);
   HIPCHK(hipMalloc(&out, (size_t)2 * ncu * threads * 4));
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  hipLaunchKernelGGL(valu_probe_kernel, dim3(ncu), dim3(threads), lds, 0, out, iters / 8 + 1, 1.0f);   // warm-up (clocks, code cache)
+  hipLaunchKernelGGL(valu_probe_kernel, dim3(ncu * wg_per_cu), dim3(threads), lds, 0, out, iters / 8 + 1, 1.0f);   // warm-up (clocks, code cache)
   HIPCHK(hipEventRecord(e0, 0));
-  hipLaunchKernelGGL(valu_probe_kernel, dim3(ncu), dim3(threads), lds, 0, out, iters, 1.0f);
+  hipLaunchKernelGGL(valu_probe_kernel, dim3(ncu * wg_per_cu), dim3(threads), lds, 0, out, iters, 1.0f);
   HIPCHK(hipEventRecord(e1, 0));
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0.f;
