@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <utility>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>

@@ -329,6 +329,13 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
     }
     m->leg_sizes = m->wave_ok && m->wave_cfg == 1 && sizes_match<2>(w.nq, d.nv, d.nu, d.nl, d.nlevel, d.maxnnz, d.ngt, d.nseg, d.ncg, d.npair);
     m->terrain_sizes = m->wave_ok && m->wave_cfg == 1 && w.hf.on && sizes_match<3>(w.nq, d.nv, d.nu, d.nl, d.nlevel, d.maxnnz, d.ngt, d.nseg, d.ncg, d.npair);
+    {  // the specialised instantiations also build in the dof tree (tree-sparse factorisation): it must be the model's
+      std::vector<int> dpar;
+      if ((rc = load_i(m, blob, "dof_parentid", &tmpi, &dpar))) { myo_model_free(m); return rc; }
+      auto same_tree = [&](const int* ref, int n) { if ((int)dpar.size() != n) return false; for (int i = 0; i < n; i++) if (dpar[i] != ref[i]) return false; return true; };
+      if (m->hand_sizes && !same_tree(SpecTree<1>::parent, SpecTree<1>::nv)) m->hand_sizes = false;
+      if ((m->leg_sizes || m->terrain_sizes) && !same_tree(SpecTree<2>::parent, SpecTree<2>::nv)) m->leg_sizes = m->terrain_sizes = false;
+    }
     if (m->rk4) m->hand_sizes = m->leg_sizes = m->terrain_sizes = false;
     if (const char* e = getenv("MYO_NO_SPEC")) if (atoi(e) == 1) m->hand_sizes = m->leg_sizes = m->terrain_sizes = false;   // tests: force the run-time-sized instantiations
     if (!m->wave_ok && !m->generic_ok) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "model exceeds the limits of both step kernels (nv <= 36, nu <= 128, pair dofs <= 20)"); }

@@ -79,6 +79,51 @@ template <int NVT> __device__ __forceinline__ float chol_rows(float (&r)[NVT], i
   }
   return invd;
 }
+// Dof trees of the size-specialised instantiations (parent dof of each dof; myo_model_load checks the model's dof_parentid against them
+// before it selects a specialised instantiation).  The mass matrix M and M + h D couple a dof only with its ancestors and descendants:
+// factorised LEAVES FIRST (lane i <-> dof nv - 1 - i) the Cholesky factor keeps exactly that pattern, no fill-in (Featherstone; MuJoCo's
+// L^T D L does the same) -- MyoHand 93 of 253 entries below the diagonal, MyoLeg 317 of 561.
+template <int SPEC> struct SpecTree { static constexpr int nv = 0; static constexpr int parent[1] = {-1}; };
+template <> struct SpecTree<1> { static constexpr int nv = 23;
+  static constexpr int parent[23] = {-1, 0, 1, 2, 3, 4, 5, 2, 7, 8, 9, 2, 11, 12, 13, 2, 15, 16, 17, 2, 19, 20, 21}; };
+template <> struct SpecTree<2> { static constexpr int nv = 34;
+  static constexpr int parent[34] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 8, 17, 18, 5, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 22, 31, 32}; };
+template <> struct SpecTree<3> : SpecTree<2> {};
+// is dof a an ancestor of dof d?
+template <int SPEC> __host__ __device__ constexpr bool tree_anc(int a, int d) {
+  int p = SpecTree<SPEC>::parent[d];
+  while (p >= 0) { if (p == a) return true; p = SpecTree<SPEC>::parent[p]; }
+  return false;
+}
+// chol_rows on the leaves-first permuted matrix of a tree-structured model: the (j, k) products whose factor entry is structurally zero
+// are not emitted (`if constexpr` over index sequences: a run-time predicate inside `#pragma unroll` loops blocked the unrolling and put
+// the rows into scratch memory)
+template <int NVT, int SPEC, int J, int K> __device__ __forceinline__ void tree_term(float& s, const float (&r)[NVT]) {
+  constexpr int nv = SpecTree<SPEC>::nv;
+  if constexpr (J < nv && K < nv) {
+    if constexpr (tree_anc<SPEC>(nv - 1 - J, nv - 1 - K)) s -= r[K] * rdlane(r[K], J);
+  }
+}
+template <int NVT, int SPEC, int J, int... Ks> __device__ __forceinline__ void tree_col(float& s, const float (&r)[NVT], std::integer_sequence<int, Ks...>) {
+  (tree_term<NVT, SPEC, J, Ks>(s, r), ...);
+}
+template <int NVT, int SPEC, int J> __device__ __forceinline__ void tree_step(float (&r)[NVT], float& invd, int lane) {
+  float s = r[J];
+  tree_col<NVT, SPEC, J>(s, r, std::make_integer_sequence<int, J>{});
+  float pj = fmaxf(rdlane(s, J), MINVALF);
+  float inv = __builtin_amdgcn_rsqf(pj);
+  float dj = pj * inv;
+  r[J] = (lane == J) ? dj : s * inv;
+  if (lane == J) invd = inv;
+}
+template <int NVT, int SPEC, int... Js> __device__ __forceinline__ void tree_all(float (&r)[NVT], float& invd, int lane, std::integer_sequence<int, Js...>) {
+  (tree_step<NVT, SPEC, Js>(r, invd, lane), ...);
+}
+template <int NVT, int SPEC> __device__ __forceinline__ float chol_rows_tree(float (&r)[NVT], int lane) {
+  float invd = 1.0f;
+  tree_all<NVT, SPEC>(r, invd, lane, std::make_integer_sequence<int, NVT>{});
+  return invd;
+}
 // x <- (L L^T)^-1 b ; L rows in registers, L^T columns read from the LDS copy T[j*(NVT+1) + lane]
 template <int NVT> __device__ __forceinline__ float chol_solve_rows(const float (&r)[NVT], float invd, float b, const float* T, int lane) {
   float y = b;
@@ -589,8 +634,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             matmul3(gmat, E + Y.lmat + 9 * gl, M.wg_lmat + 9 * g);
           }
           if (S[3] >= 0) site_world_w(M, Y, E, S[3], side);
-          if constexpr (FULL) wlen = wrap_geom_inl(wp, p0, p1, gpos, gmat, M.wg_radius[g], S[10] != 0, side, S[3] >= 0);
-          else wlen = wrap_geom(wp, p0, p1, gpos, gmat, M.wg_radius[g], S[10] != 0, side, S[3] >= 0);
+          wlen = wrap_geom_inl(wp, p0, p1, gpos, gmat, M.wg_radius[g], S[10] != 0, side, S[3] >= 0);   // always inline: an out-of-line copy passes its arrays through scratch memory
         }
         SUB(7);
         bool wr = wlen >= 0;
@@ -1673,6 +1717,31 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         SUB(1);
       }
       rhs = phase == 0 ? -grad : (phase == 1 ? smooth : smooth + qfc);
+      float x;
+      if (SPEC != 0 && !RK4 && phase != 0) {
+        // unconstrained and Euler solves of the size-specialised instantiations: M (+ h D) factorised leaves first, tree-sparse
+        constexpr int NVS = SpecTree<SPEC>::nv > 0 ? SpecTree<SPEC>::nv : 1;
+        const bool act = lane < NVS;
+        const int q = act ? NVS - 1 - lane : 0;                   // this lane's dof in leaves-first order
+        const float dadd = phase == 2 ? h * __shfl(damping, q) : 0.f;
+        const float rhs_p = act ? __shfl(rhs, q) : 0.f;
+#pragma unroll
+        for (int k = 0; k < NVT; k++) {
+          const int qk = k < NVS ? NVS - 1 - k : 0;               // compile-time after unrolling; qk >= q where k <= lane
+          const float mv = (act && k <= lane) ? Mp[(qk * (qk + 1)) / 2 + q] : 0.f;
+          r[k] = act ? mv + (k == lane ? dadd : 0.f) : (k == lane ? 1.f : 0.f);
+        }
+        SYNC();
+        invd = chol_rows_tree<NVT, SPEC>(r, lane);
+        if (lane < NVT) {
+#pragma unroll
+          for (int k = 0; k < NVT; k++) E[Y.sq + lane * (NVT + 1) + k] = r[k];
+        }
+        SYNC();
+        SUB(2);
+        const float xp = chol_solve_rows<NVT>(r, invd, rhs_p, E + Y.sq, lane);
+        x = __shfl(xp, act ? NVS - 1 - lane : lane);
+      } else {
       if (refactor) {
         const int dd = lane < nv ? lane : 0;
         const int based = (dd * (dd + 1)) / 2;
@@ -1698,7 +1767,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         invd = 1.0f / E[Y.sq + ll * (NVT + 1) + ll];
       }
       SUB(2);
-      float x = chol_solve_rows<NVT>(r, invd, rhs, E + Y.sq, lane);
+      x = chol_solve_rows<NVT>(r, invd, rhs, E + Y.sq, lane);
+      }
       SUB(3);
       if (phase == 1) { qacc = x; qfc = 0.f; phase = 2; continue; }
       if (phase == 2) { qaccE = x; break; }
