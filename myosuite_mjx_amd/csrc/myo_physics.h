@@ -54,6 +54,27 @@ __device__ float wrap_circle(float* pnt, const float* d, const float* sd, bool h
   return rad * acosf(clipf((pnt[0] * pnt[2] + pnt[1] * pnt[3]) / sqr, -1.f, 1.f));
 }
 
+// Short polynomial forms of the inverse / direct trigonometry of the inside-wrap Newton solve, which 15 of MyoHand's 63 wrapping segments run
+// every substep (the library calls carry range reduction and special cases this solve never needs: asinf ~30, sincosf ~45 instructions).
+// asin on [0, 1]: pi/2 - sqrt(1 - x) P7(x) (Abramowitz & Stegun 4.4.46, |error| <= 2e-8 before float rounding); sin / cos on [0, pi/2]:
+// the single-precision minimax polynomials on [0, pi/4] with the complement swap above pi/4.  The solve stops at |f| <= 1e-6.
+__device__ __forceinline__ float asin01f(float x) {
+  float p = -0.0012624911f;
+  p = p * x + 0.0066700901f; p = p * x - 0.0170881256f; p = p * x + 0.0308918810f; p = p * x - 0.0501743046f;
+  p = p * x + 0.0889789874f; p = p * x - 0.2145988016f; p = p * x + 1.5707963050f;
+  return 1.57079632679f - sqrtf(fmaxf(0.f, 1.f - x)) * p;
+}
+__device__ __forceinline__ float acos11f(float x) {       // acos on [-1, 1]
+  const float a = asin01f(fabsf(x));
+  return x >= 0.f ? 1.57079632679f - a : 1.57079632679f + a;
+}
+__device__ __forceinline__ void sincos_q1f(float th, float* sn, float* cs) {   // th in [0, pi/2]
+  const bool hi = th > 0.785398163f;
+  const float r = hi ? 1.57079632679f - th : th, z = r * r;
+  const float s = r + r * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+  const float c = 1.f + z * (-0.5f + z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f)));
+  *sn = hi ? c : s; *cs = hi ? s : c;
+}
 __device__ float wrap_inside(float* pnt, const float* d, float rad) {
   const float zinit = 1.f - 1e-7f, tolerance = 1e-6f;
   float len0 = sqrtf(d[0] * d[0] + d[1] * d[1]), len1 = sqrtf(d[2] * d[2] + d[3] * d[3]);
@@ -75,24 +96,24 @@ __device__ float wrap_inside(float* pnt, const float* d, float rad) {
   float cosG = (len0 * len0 + len1 * len1 - dd) / (2 * len0 * len1);
   if (cosG < -1 + MINVALF) return -1;
   if (cosG > 1 - MINVALF) return 0;
-  float Gang = acosf(cosG);
+  float Gang = acos11f(cosG);
   // Newton on theta = asin(z): same root as MuJoCo's iteration in z, but well conditioned in float near z -> 1
   (void)zinit;
   float th = 1.57079632679f - 4.4721360e-4f;
-  float sn = sinf(th), f = asinf(A * sn) + asinf(B * sn) - 2 * th + Gang;
+  float sn = 0.9999999f, cs = 4.4721359e-4f;          // sin / cos of the start angle
+  float f = asin01f(A * sn) + asin01f(B * sn) - 2 * th + Gang;
   if (f > 0) return 0;
   for (int iter = 0; iter < 20 && fabsf(f) > tolerance; iter++) {
-    float cs = cosf(th);
     float df = A * cs / fmaxf(MINVALF, sqrtf(1 - A * A * sn * sn)) + B * cs / fmaxf(MINVALF, sqrtf(1 - B * B * sn * sn)) - 2;
     th = clipf(th - f / df, 1e-6f, 1.57079632679f);
-    sn = sinf(th);
-    f = asinf(A * sn) + asinf(B * sn) - 2 * th + Gang;
+    sincos_q1f(th, &sn, &cs);
+    f = asin01f(A * sn) + asin01f(B * sn) - 2 * th + Gang;
   }
   float vec[2], ang;
-  if (d[0] * d[3] - d[1] * d[2] > 0) { vec[0] = d[0] / len0; vec[1] = d[1] / len0; ang = th - asinf(A * sn); }
-  else { vec[0] = d[2] / len1; vec[1] = d[3] / len1; ang = th - asinf(B * sn); }
+  if (d[0] * d[3] - d[1] * d[2] > 0) { vec[0] = d[0] / len0; vec[1] = d[1] / len0; ang = th - asin01f(A * sn); }
+  else { vec[0] = d[2] / len1; vec[1] = d[3] / len1; ang = th - asin01f(B * sn); }
   float sa, ca;
-  sincosf(ang, &sa, &ca);
+  sincos_q1f(clipf(ang, 0.f, 1.57079632679f), &sa, &ca);
   pnt[0] = rad * (ca * vec[0] - sa * vec[1]);
   pnt[1] = rad * (sa * vec[0] + ca * vec[1]);
   pnt[2] = pnt[0]; pnt[3] = pnt[1];
