@@ -200,3 +200,46 @@ def test_hand_object_model():
         fresh = M.from_mjcf(os.path.join(REFERENCE, "envs/myo/assets/hand/myohand_hold.xml"))
         for k, v in fresh.arrays.items():
             assert np.allclose(np.asarray(v, float), np.asarray(m.arrays[k], float), rtol=0, atol=1e-12), k
+
+
+@pytest.mark.parametrize("name", ["hand", "finger", "legs"])
+def test_two_phase_kinematics_tables(name, request):
+    """hip_kin_*: every non-free link has its 4 + 2 * dofnum vectors exactly once, in its own level, at distinct scratch offsets that fit the
+    Hessian scratch the kernel borrows; kinds and indices address the right rows (lowering.py, wave kernel phase 1 / phase 2)."""
+    m = request.getfixturevalue(name)
+    A = m.arrays
+    nl, nlevel, nv = (int(x) for x in A["hip_sizes"][:3])
+    adr, vec, base = A["hip_kin_adr"], np.asarray(A["hip_kin_vec"]).reshape(-1, 2), A["hip_kin_base"]
+    free, dofadr, dofnum, level_adr = A["hip_link_free"], A["hip_link_dofadr"], A["hip_link_dofnum"], A["hip_level_adr"]
+    assert len(adr) == nlevel + 1 and adr[-1] == len(vec)
+    nvt = 24 if nv <= 24 else 36
+    assert int(A["hip_kin_size"][0]) <= nvt * (nvt + 1)
+    seen = set()
+    for L in range(nlevel):
+        for w0, src in vec[adr[L]:adr[L + 1]]:
+            l, kind, ix = int(w0) & 255, (int(w0) >> 8) & 3, int(w0) >> 16
+            assert level_adr[L] <= l < level_adr[L + 1] and not free[l]
+            assert base[l] <= src < base[l] + 3 * (4 + 2 * dofnum[l]) and (src - base[l]) % 3 == 0
+            if kind in (2, 3):
+                assert dofadr[l] <= ix < dofadr[l] + dofnum[l]
+            elif kind == 0:
+                assert 0 <= ix < 3
+            assert (l, kind, ix if kind != 1 else 0) not in seen
+            seen.add((l, kind, ix if kind != 1 else 0))
+    assert len(seen) == sum(4 + 2 * int(dofnum[l]) for l in range(nl) if not free[l])
+    assert int(A["hip_kin_size"][1]) == max([int(dofnum[l]) for l in range(nl) if not free[l]] + [0])
+
+
+def test_specialised_instantiations_know_the_models_dof_trees(hand, legs):
+    """The size-specialised kernels build in the dof tree (tree-sparse factorisation, SpecTree<1> / SpecTree<2> in myo_kernel_wave.h);
+    myo_model_load falls back to the generic instantiation when a model's dof_parentid differs, so a silent mismatch would only cost speed:
+    this keeps the header and the compiled config models in step."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "myosuite_mjx_amd", "csrc", "myo_kernel_wave.h")).read()
+    for spec, m in ((1, hand), (2, legs)):
+        mm = re.search(r"struct SpecTree<%d> \{ static constexpr int nv = (\d+);\s*static constexpr int parent\[\d+\] = \{([^}]*)\}" % spec, src)
+        assert mm, spec
+        parent = [int(x) for x in mm.group(2).split(",")]
+        assert int(mm.group(1)) == len(parent) == len(m.arrays["dof_parentid"])
+        assert parent == [int(x) for x in m.arrays["dof_parentid"]]
