@@ -183,3 +183,16 @@ def test_terrain_4096_envs_equal_their_shards():
     if not (os.environ.get("MYO_NO_SPEC") or os.environ.get("MYO_SCHED")):     # default selection: scheduled full batch, one wave per env for the shards
         assert env.batch.last_kernel_name() == "step_kernel_w<36,20,32,2,2,true,3,true>" and shards[0].batch.last_kernel_name() == "step_kernel_w<36,20,32,2,2,false,3,true>"
     assert int((env.status() & 16).sum()) == 0
+
+
+def test_config_models_run_on_their_specialised_instantiations():
+    """The headline envs must take the size- and tree-specialised kernels (a mismatch between a compiled asset and the tables built into
+    myo_kernel_wave.h silently falls back to the generic instantiation: correct, but several per cent slower)."""
+    import torch
+    import myosuite_mjx_amd as myo
+    for env_id, n, want in (("myoHandPoseRandom-v0", 256, "step_kernel_w<24,8,32,1,4,false,1,false>"),
+                            ("myoLegWalk-v0", 256, "step_kernel_w<36,20,32,2,2,false,2,false>")):
+        env = myo.make(env_id, num_envs=n)
+        env.reset(seed=0)
+        env.step(torch.zeros((n, env.act_dim), device="cuda"))
+        assert env.batch.last_kernel_name() == want, (env_id, env.batch.last_kernel_name())
