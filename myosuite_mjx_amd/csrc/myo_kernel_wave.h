@@ -1450,6 +1450,85 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         caref[0] = -B * (vn_c + cmu * vt1_c) + pos; caref[1] = -B * (vn_c - cmu * vt1_c) + pos;
         caref[2] = -B * (vn_c + cmu * vt2_c) + pos; caref[3] = -B * (vn_c - cmu * vt2_c) + pos;
       }
+    } else if constexpr (KC == 20) {
+      // 36-dof kernels: the same idea with three contacts per pass (lane = (contact of the pass, one of its 20 dof slots)); the three or four
+      // velocity sums of a contact meet in LDS atomics on the (still unused) search-vector scratch
+      const int rg = lane / KC, rk = lane - rg * KC;
+      float vn_c = 0.f, vt1_c = 0.f, vt2_c = 0.f, vs_c = 0.f;
+      for (int c0 = 0; c0 < ncon; c0 += 3) {
+        if (lane < 12) E[Y.xv + lane] = 0.f;
+        SYNC();
+        const int c = c0 + rg;
+        auto row_cols = [&](const float* ppos, const float* pnrm, const int* ppair, float* cJ, unsigned int* cdw) {
+          const int* P = M.pair_i + 6 * ppair[0];
+          const float n[3] = {pnrm[0], pnrm[1], pnrm[2]}, cp[3] = {ppos[0], ppos[1], ppos[2]};
+          float t1[3], t2[3];
+          make_frame(n, t1, t2);
+          if (P[4] == 2) {   // plane - capsule: first tangent along the capsule axis (MuJoCo's frame for this pair type)
+            const float* ax = E + Y.gax + 3 * P[1];
+            float t = dot3(ax, n), y[3] = {ax[0] - t * n[0], ax[1] - t * n[1], ax[2] - t * n[2]};
+            float yn = norm3(y);
+            if (yn >= 0.5f) {
+              float inv = 1.0f / yn;
+              t1[0] = y[0] * inv; t1[1] = y[1] * inv; t1[2] = y[2] * inv;
+              cross3(t2, n, t1);
+            }
+          }
+          float jn = 0.f, j1 = 0.f, j2 = 0.f, js = 0.f;
+          int d = 0;
+          if (rk < P[3]) {
+            d = M.pair_dl[2 * (P[2] + rk)];
+            const float sg = (float)M.pair_dl[2 * (P[2] + rk) + 1];
+            const float* ax = E + Y.axis + 3 * d;
+            float col[3];
+            const bool hinge = M.dof_type[d] == 3;
+            if (hinge) {
+              const float r[3] = {cp[0] - E[Y.anchor + 3 * d], cp[1] - E[Y.anchor + 3 * d + 1], cp[2] - E[Y.anchor + 3 * d + 2]};
+              cross3(col, ax, r);
+            } else { col[0] = ax[0]; col[1] = ax[1]; col[2] = ax[2]; }
+            jn = sg * dot3(n, col); j1 = sg * dot3(t1, col); j2 = sg * dot3(t2, col);
+            const float qv = E[Y.qvel + d];
+            atomicAdd(&E[Y.xv + 4 * rg], jn * qv); atomicAdd(&E[Y.xv + 4 * rg + 1], j1 * qv); atomicAdd(&E[Y.xv + 4 * rg + 2], j2 * qv);
+            if constexpr (TRK) { js = hinge ? sg * dot3(n, ax) : 0.f; atomicAdd(&E[Y.xv + 4 * rg + 3], js * qv); }   // relative angular velocity about the normal
+          }
+          cJ[rk] = jn; cJ[KC + rk] = j1; cJ[2 * KC + rk] = j2;
+          if constexpr (TRK) cJ[3 * KC + rk] = js;
+          ((unsigned char*)cdw)[rk] = (unsigned char)d;   // padded entries: zero jacobian, dof 0
+        };
+        if (rg < 3 && c < ncon) {
+          if (c < NC) row_cols(E + Y.cpos + 3 * c, E + Y.cnrm + 3 * c, (const int*)(E + Y.cpair) + c, E + Y.cJ + c * NJ * KC, (unsigned int*)(E + Y.cdofs) + CDW * c);
+          else { float* g = ovf_env + (c - NC) * ovf_row; row_cols(g + 1, g + 4, (const int*)g + 7, g + 8, (unsigned int*)(g + 8 + NJ * KC)); }
+        }
+        SYNC();
+        if (lane >= c0 && lane < c0 + 3) { const int g = lane - c0; vn_c = E[Y.xv + 4 * g]; vt1_c = E[Y.xv + 4 * g + 1]; vt2_c = E[Y.xv + 4 * g + 2]; vs_c = E[Y.xv + 4 * g + 3]; }
+        SYNC();
+      }
+      if (lane < ncon) {
+        const float* g = lane < NC ? nullptr : ovf_env + (lane - NC) * ovf_row;
+        const int p = lane < NC ? ((const int*)(E + Y.cpair))[lane] : ((const int*)g)[7];
+        const float dist = lane < NC ? E[Y.cdist + lane] : g[0];
+        const int* P = M.pair_i + 6 * p;
+        const float* F = M.pair_f + 12 * p;
+        ckc = P[3];
+        const float incl = F[0] - F[1];
+        cmu = F[2];
+        float imp = impedance(F + 6, dist, incl), K, B;
+        kbi(F[4], F[5], F[7], M.timestep, &K, &B);
+        if (P[5] == 1) {
+          // condim 1 (explicit <pair>): one frictionless row = four identical "pyramid" rows with mu = 0 and D/4 each
+          cmu = 0.f;
+          cD = 0.25f / fmaxf(MINVALF, (1 - imp) / imp * F[3]);
+        } else {
+          float R0 = fmaxf(MINVALF, (1 - imp) / imp * F[3] * (1 + cmu * cmu));
+          cD = 1.0f / fmaxf(MINVALF, 2 * cmu * cmu * R0);
+        }
+        const float pos = -K * imp * (dist - incl);
+        caref[0] = -B * (vn_c + cmu * vt1_c) + pos; caref[1] = -B * (vn_c - cmu * vt1_c) + pos;
+        caref[2] = -B * (vn_c + cmu * vt2_c) + pos; caref[3] = -B * (vn_c - cmu * vt2_c) + pos;
+        if constexpr (TRK) {
+          if (P[5] == 4) { cmut = F[11]; cD2 = cD; caref[4] = -B * (vn_c + cmut * vs_c) + pos; caref[5] = -B * (vn_c - cmut * vs_c) + pos; }
+        }
+      }
     } else
     if (lane < ncon) {
       if (lane < NC) build_row(E + Y.cdist + lane, E + Y.cpos + 3 * lane, E + Y.cnrm + 3 * lane, (const int*)(E + Y.cpair) + lane, E + Y.cJ + lane * NJ * KC,
