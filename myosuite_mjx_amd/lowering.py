@@ -706,7 +706,14 @@ def lower(cm):
     # through MPR (generic convex, height-field prisms) come first, so that an env with more than 64 candidates (the usual case for MyoHand:
     # ~87 per substep, ~20 of them MPR) runs ONE round with MPR lanes and then rounds of analytic pairs only, instead of paying the MPR
     # latency in every round
-    order = sorted(range(len(pairs_i)), key=lambda i: 0 if pairs_i[i][4] in (0, 4) else 1)
+    # (among the MPR pairs: convex-hull pairs first, then boxes, then the smooth shapes -- a hull support is a vertex-graph climb, ~8x the
+    # cost of an ellipsoid support, so the round that carries them should carry all of them)
+    def _cost_class(i):
+        if pairs_i[i][4] not in (0, 4):
+            return 3
+        ty = {int(m.geom_type[cgs[pairs_i[i][0]]]), int(m.geom_type[cgs[pairs_i[i][1]]])}
+        return 0 if GEOM_MESH in ty else (1 if GEOM_BOX in ty else 2)
+    order = sorted(range(len(pairs_i)), key=_cost_class)
     pairs_i, pairs_f = [pairs_i[i] for i in order], [pairs_f[i] for i in order]
     A["hip_pair_i"] = np.array(pairs_i, np.int32).reshape(-1, PAIR_INTS)
     A["hip_pair_f"] = np.array(pairs_f).reshape(-1, PAIR_FLTS)
