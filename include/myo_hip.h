@@ -208,7 +208,8 @@ int myo_bench_rollout(myo_batch*, int steps, int nsubsteps, uint64_t seed, int m
  * asynchronous calls since the previous collection (waits for them); events are recorded on the launches' own stream */
 int myo_bench_last_kernel_ms(myo_batch*, float* ms_out);
 /* roofline probe (no reference counterpart): measured chip-wide issue rate of wave64 v_fma_f32 instructions per second with
- * `waves_per_simd` (1..4) waves resident on every SIMD; bench.py prices the step kernel's VALU instruction count against it */
+ * `waves_per_simd` (1..4, or 8 = two workgroups per CU) waves resident on every SIMD; bench.py prices the step kernel's VALU instruction
+ * count against the figure at 4, the occupancy the hand kernel runs at */
 int myo_probe_valu(int device, int waves_per_simd, int iters, double* wave_insts_per_s, int* n_cu_out);
 /* name of the step-kernel template instantiation the last launch used, spelled as rocprofv3 prints it */
 const char* myo_bench_last_kernel_name(const myo_batch*);
