@@ -649,6 +649,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         atomicAdd(&E[Y.tlen + gts], L);
       }
     }
+    if (lane < nv) E[Y.qfc + lane] = 0.f;   // actuator forces are scattered to their dofs below (the solver's force scratch is free here)
     SYNC();
     SUB(8);
 #pragma unroll
@@ -672,17 +673,18 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         if (A[10] < 0.f) { f = A[0] * clipf(E[Y.ctrl + gt], A[12], A[13]) + A[1] + A[14] * (A[2] * L + A[3] * vel); ad = 0.f; }   // stateless affine actuator
         else muscle(A, A[14] * L, A[14] * vel, E[Y.act + gt], E[Y.ctrl + gt], &f, &ad);
         actdot[rr] = ad;
-        E[Y.tforce + gt] = f * A[14];
+        const float ft = f * A[14];
+        E[Y.tforce + gt] = ft;
+        // J^T f of the actuators, lane = tendon: its <= maxnnz moment arms go to their dofs with LDS atomics (one lane per dof walking the
+        // dof's whole column -- two dozen tendons for the wrist dofs -- was the longer chain)
+        for (int k = 0; k < maxnnz_; k++) {
+          const int d = M.gt_dofs[gt * maxnnz_ + k];
+          if (d >= 0) atomicAdd(&E[Y.qfc + d], Jrow[k] * ft);
+        }
       }
     }
     SYNC();
-    float qfa = 0.f;
-    if (lane < nv) {
-      for (int k = M.col_adr[lane]; k < M.col_adr[lane + 1]; k++) {
-        int t = M.col[2 * k], slot = M.col[2 * k + 1];
-        qfa += E[Y.tJ + t * maxnnz_ + slot] * E[Y.tforce + t];
-      }
-    }
+    const float qfa = lane < nv ? E[Y.qfc + lane] : 0.f;
     if (step == nsub - 1) {   // diagnostics of the last substep
       for (int i = lane; i < nu; i += 64) { Bt.tenlen[(size_t)env * nu + i] = E[Y.tlen + i]; Bt.actforce[(size_t)env * nu + i] = E[Y.tforce + i]; }
     }
