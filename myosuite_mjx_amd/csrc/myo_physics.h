@@ -120,10 +120,10 @@ __device__ float wrap_inside(float* pnt, const float* d, float rad) {
   return 0;
 }
 
-// returns wrap length (<0: no wrap); wpnt = two world points.  Two copies of one body: the 24-dof (hand / finger) kernels call the
-// out-of-line wrap_geom, the 36-dof kernels inline wrap_geom_inl (+4 %: an out-of-line call passes its array arguments through scratch
-// memory) -- inlining it into the hand kernel as well, or even routing the out-of-line copy through the inline one, costs that
-// kernel 0.6 % (register allocation again), so the two are kept textually separate
+// returns wrap length (<0: no wrap); wpnt = two world points.  Two copies of one body: the wave kernels inline wrap_geom_inl (an out-of-line
+// call passes its array arguments through scratch memory: 3-5 % on every wave kernel; round 1 kept the hand kernel on the out-of-line copy for
+// 0.6 %, but once that kernel grew the compiler stopped inlining it on its own and the call cost 2.7 %); the 16 / 32-lane cross-check kernel
+// keeps the out-of-line wrap_geom
 #define MYO_WRAP_GEOM_BODY  \
   float p[6], s[3] = {0, 0, 0}, tmp[3], axis[6], d[4], sd[2] = {0, 0}, pnt[4], res[6];  \
   tmp[0] = x0[0] - xpos[0]; tmp[1] = x0[1] - xpos[1]; tmp[2] = x0[2] - xpos[2];  \
