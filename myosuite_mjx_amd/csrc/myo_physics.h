@@ -24,6 +24,7 @@ __device__ float wrap_circle(float* pnt, const float* d, const float* sd, bool h
   if (tmp[0] * tmp[0] + tmp[1] * tmp[1] > sqr && (!has_side || sd[0] * tmp[0] + sd[1] * tmp[1] >= 0)) return -1;
   float s0 = sqrtf(sq0 - sqr), s1 = sqrtf(sq1 - sqr);
   float sol[2][4], good[2];
+  bool crossing[2];     // the candidate's two straight pieces intersect: it is rejected, also when it is the better of the two
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     float sgn = i == 0 ? 1.f : -1.f;
@@ -44,13 +45,13 @@ __device__ float wrap_circle(float* pnt, const float* d, const float* sd, bool h
     // meaningless in float; skip it there (changes the length by O(r*1e-9), see DESIGN.md "float safeguards")
     float gz0 = sol[i][0] - sol[i][2], gz1 = sol[i][1] - sol[i][3];
     bool grazing = gz0 * gz0 + gz1 * gz1 < 1e-6f * sqr;
-    if (!grazing && is_intersect(d, sol[i], d + 2, sol[i] + 2)) good[i] = -10000.f;
+    crossing[i] = !grazing && is_intersect(d, sol[i], d + 2, sol[i] + 2);
+    if (crossing[i]) good[i] = -10000.f;
   }
   int i = good[0] > good[1] ? 0 : 1;
 #pragma unroll
   for (int k = 0; k < 4; k++) pnt[k] = i == 0 ? sol[0][k] : sol[1][k];
-  bool grazing = (pnt[0] - pnt[2]) * (pnt[0] - pnt[2]) + (pnt[1] - pnt[3]) * (pnt[1] - pnt[3]) < 1e-6f * sqr;
-  if (!grazing && is_intersect(d, pnt, d + 2, pnt + 2)) return -1;
+  if (i == 0 ? crossing[0] : crossing[1]) return -1;      // the same test MuJoCo repeats on the chosen candidate: reuse its result
   return rad * acosf(clipf((pnt[0] * pnt[2] + pnt[1] * pnt[3]) / sqr, -1.f, 1.f));
 }
 
@@ -151,8 +152,7 @@ __device__ float wrap_inside(float* pnt, const float* d, float rad) {
     }  \
     float inv = 1.0f / nrm;  \
     nrmv[0] *= inv; nrmv[1] *= inv; nrmv[2] *= inv;  \
-    cross3(axis + 3, nrmv, axis);  \
-    normalize3(axis + 3);  \
+    cross3(axis + 3, nrmv, axis);  /* unit already: cross product of two orthonormal vectors */  \
     d[0] = dot3(p, axis); d[1] = dot3(p, axis + 3); d[2] = dot3(p + 3, axis); d[3] = dot3(p + 3, axis + 3);  \
     if (has_side) { sd[0] = dot3(s, axis); sd[1] = dot3(s, axis + 3); }  \
   } else {  \
