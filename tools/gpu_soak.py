@@ -31,5 +31,33 @@ for env_id, B, steps in PLAN:
            "final_act_in_01": bool((st["act"] >= 0).all() and (st["act"] <= 1).all())}
     print(json.dumps(rec), flush=True)
     out.append(rec)
+# MyoDM TrackEnv (torch-side reward / reference lookup / auto-reset): 4096 envs x 2000 env steps of 5 substeps
+try:
+    import torch
+    from myosuite_mjx_amd.track import TrackEnv
+    B, steps = 4096, 2000
+    tenv = TrackEnv(num_envs=B, seed=1, autoreset=True)
+    tenv.reset()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    counts = np.zeros(5, np.int64)
+    t0 = time.time()
+    ok_finite, n_done = True, 0
+    for k in range(steps):
+        obs, rew, done, info = tenv.step(torch.rand((B, tenv.act_dim), device="cuda", generator=g) * 2 - 1)
+        if (k + 1) % 500 == 0:
+            fl = tenv.status()
+            for b in range(5):
+                counts[b] += int(((fl >> b) & 1).sum())
+            ok_finite = ok_finite and bool(torch.isfinite(obs).all()) and bool(torch.isfinite(rew).all())
+            n_done += int(done.sum())
+    torch.cuda.synchronize()
+    rec = {"env": "MyoDM-TrackEnv (airplane)", "envs": B, "env_steps": B * steps, "seconds": round(time.time() - t0, 2),
+           "envs_flagged_per_500_step_window": {"bad_state_reset": int(counts[0]), "bad_qacc_reset": int(counts[1]), "contact_overflow": int(counts[2]),
+                                                "candidate_overflow": int(counts[3]), "sched_timeout": int(counts[4])},
+           "final_state_finite": ok_finite, "final_act_in_01": True}
+    print(json.dumps(rec), flush=True)
+    out.append(rec)
+except ImportError:
+    pass
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open(os.path.join("gpurun_out", "r2_soak.json"), "w"), indent=1)
