@@ -20,6 +20,8 @@ MODELS = {
     "myolegs_terrain": ("myosuite/simhive/myo_sim/leg/myolegs.xml",),     # height field raised and colliding (TerrainEnvV0)
     # MyoDM TrackEnv (mjx/myodm_v0.py:306-308): myohand_object.xml with OBJECT_NAME -> airplane; meshes collide as convex hulls
     "myohand_object_airplane": ("myosuite/envs/myo/assets/hand/myohand_object.xml", {"OBJECT_NAME": "airplane"}),
+    # a second MyoDM object (MyoHand_cup_drink1.npz is the other motion file of tests/golden/ref_motion.npz): same code, another asset
+    "myohand_object_cup": ("myosuite/envs/myo/assets/hand/myohand_object.xml", {"OBJECT_NAME": "cup"}),
 }
 
 if __name__ == "__main__":
