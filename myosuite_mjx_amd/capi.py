@@ -56,8 +56,11 @@ class WalkConfig(C.Structure):
 TERRAIN_NONE, TERRAIN_ROUGH, TERRAIN_HILLY, TERRAIN_STAIRS = 0, 1, 2, 3
 
 
+# -mllvm -disable-machine-licm: the post-ISel loop-invariant code motion hoists constant materialisations (polynomial coefficients, masks) out
+# of the 10-substep loop into the kernel prologue, where a dozen of them stay live in VGPRs for the whole kernel and push other values into
+# scratch memory; with the pass off the headline kernel needs no register spill at all (35 before; tests/test_kernel_resources.py)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=on",
-               "-fgpu-flush-denormals-to-zero"]
+               "-fgpu-flush-denormals-to-zero", "-mllvm", "-disable-machine-licm", *os.environ.get("MYO_HIPCC_EXTRA", "").split()]
 
 
 def build_library(force=False, verbose=False):

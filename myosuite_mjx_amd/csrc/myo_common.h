@@ -74,6 +74,7 @@ struct DevModel {
   int iterations, ls_iterations;
   int disable_contact, disable_limit, disable_ellipsoid;
   float timestep, grav[3], tolerance, ls_tolerance, meaninertia, c0[3], origin[3];
+  float newton_scale;   // 1 / (meaninertia * max(nv, 1)): scale of the solver's stopping tests
   gpi level_adr, link_parent, link_dofadr, link_dofnum, child_adr, child, dof_link, dof_type, dof_parent;
   gpi site_link, wg_link, gt_seg_adr, gt_seg_num, gt_dofs, seg, dl, col_adr, col;
   gpi cg_link, cg_type, pair_i, pair_dl;

@@ -43,7 +43,6 @@ struct myo_model {
   int n_cu = 0;                 // compute units of the model's device (scheduler sizing)
   int kin_floats = 0;           // LDS scratch the two-phase kinematics needs (lowering.py hip_kin_size)
   bool rk4 = false;             // <option integrator="RK4">: the RK4 instantiations of the wave kernel (generic sizes, no scheduler)
-  int wave_wpe = 4;             // hand-class kernel variant: 4 waves per SIMD with 32 LDS contact slots, or 5 with 16 (MYO_HAND_WPE)
   bool trk = false;             // TrackEnv model class: step_kernel_w<36,20,32,2,2,false,0,false,true>
   bool hand_sizes = false, leg_sizes = false, terrain_sizes = false;   // table sizes equal Sizes<1> / Sizes<2>: the size-specialised instantiations may be used
   int wave_cfg = 0;             // 0: step_kernel_w<24,8,32,1,4> (hand / finger), 1: step_kernel_w<36,20,48,2,2> (legs)
@@ -131,29 +130,7 @@ template <class P> static int load_i(myo_model* m, const uint8_t* blob, const ch
 }
 
 static void build_layout_w(const DevModel& d, DevModelW& w, int nvt, int kc, int nc, int nj = 3) {
-  LayW& Y = w.lay;
-  int o = 0;
-  auto take = [&](int n) { int r = o; o += n; return r; };
-  int nv = d.nv, nu = d.nu, nl = d.nl;
-  Y.qpos = take(w.nq); Y.qvel = take(nv); Y.act = take(nu); Y.ctrl = take(nu);
-  Y.lpos = take(3 * nl); Y.lmat = take(9 * nl); Y.axis = take(3 * nv); Y.anchor = take(3 * nv);
-  Y.xv = take(nvt); Y.qfc = take(nvt); Y.sq = take(nvt * (nvt + 1)); Y.mprw = take(4 * MPRW);
-  Y.tJp = w.has_tl ? take(d.ngt * d.maxnnz) : 0;
-  Y.X = o;
-  Y.tJ = take(d.ngt * d.maxnnz); Y.tlen = take(d.ngt); Y.tforce = take(nu);
-  int endT = o;
-  o = Y.X;
-  Y.cdof = take(6 * nv); Y.cinert = take(10 * nl); Y.crb = take(10 * nl); Y.cvel = take(6 * nl); Y.cacc = take(6 * nl); Y.cfrc = take(6 * nl);
-  int endD = o;
-  o = Y.X;
-  Y.Mp = o;
-  Y.gpos = take(3 * d.ncg); Y.gax = take(3 * d.ncg);
-  Y.cand = take(NCAND);
-  if (o - Y.Mp < (nvt * (nvt + 1)) / 2) o = Y.Mp + (nvt * (nvt + 1)) / 2; Y.cdist = take(nc); Y.cpos = take(3 * nc); Y.cnrm = take(3 * nc); Y.cpair = take(nc);
-  Y.cJ = take(nc * nj * kc); Y.cdofs = take(nc * ((kc + 3) / 4));   // nj jacobian rows of kc entries per contact; kc dof ids per contact, one byte each
-  if (o < endT) o = endT;
-  if (o < endD) o = endD;
-  Y.total = o;
+  w.lay = layout_w(w.nq, d.nv, d.nu, d.nl, d.ngt, d.maxnnz, d.ncg, w.has_tl != 0, nvt, kc, nc, nj);   // (myo_kernel_wave.h: shared with the compile-time layouts)
 }
 
 static void build_layout(DevModel& d) {
@@ -215,6 +192,7 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
   d.timestep = (float)O[0]; d.grav[0] = (float)O[1]; d.grav[1] = (float)O[2]; d.grav[2] = (float)O[3];
   d.tolerance = (float)O[4]; d.iterations = (int)O[5]; d.ls_iterations = (int)O[6]; d.ls_tolerance = (float)O[7];
   d.meaninertia = (float)O[9];
+  d.newton_scale = 1.0f / (d.meaninertia * (float)(d.nv > 1 ? d.nv : 1));
   int rc = 0;
   std::vector<float> c0, jl;
   const float* tmp;
@@ -314,9 +292,7 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
     }
     else if (common && !needs_full && d.nv <= 24 && d.nu <= 64 && d.ngt <= 64 && d.maxkc <= 8) {
       m->wave_ok = true; m->wave_cfg = 0;
-      // occupancy variant: 16 contact slots in LDS (the rest in the HBM overflow rows) bring the slice under 8 KB = 20 waves per CU, at 96 VGPRs
-      if (const char* e = getenv("MYO_HAND_WPE")) if (atoi(e) == 5 && !w.has_tl) m->wave_wpe = 5;
-      build_layout_w(d, w, 24, 8, m->wave_wpe == 5 ? 16 : 32);
+      build_layout_w(d, w, 24, 8, 32);
     }
     else if (common && d.nv <= 36 && d.nu <= 128 && d.ngt <= 128 && d.maxkc <= 20) { m->wave_ok = true; m->wave_cfg = 1; build_layout_w(d, w, 36, 20, 32); }
     else { m->wave_ok = false; build_layout_w(d, w, 24, 8, 32); }
@@ -325,7 +301,7 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
     if (blob_find(blob, "integrator")) { std::vector<int> ig; if ((rc = load_i(m, blob, "integrator", &tmpi, &ig))) { myo_model_free(m); return rc; } m->rk4 = !ig.empty() && ig[0] == 1; }
     if (m->rk4) {
       if (!m->wave_ok || m->trk || w.hf.on) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "RK4: wave kernel models without height field / TrackEnv features only"); }
-      m->generic_ok = false; m->wave_wpe = 4;
+      m->generic_ok = false;
     }
     m->leg_sizes = m->wave_ok && m->wave_cfg == 1 && sizes_match<2>(w.nq, d.nv, d.nu, d.nl, d.nlevel, d.maxnnz, d.ngt, d.nseg, d.ncg, d.npair);
     m->terrain_sizes = m->wave_ok && m->wave_cfg == 1 && w.hf.on && sizes_match<3>(w.nq, d.nv, d.nu, d.nl, d.nlevel, d.maxnnz, d.ngt, d.nseg, d.ncg, d.npair);
@@ -337,6 +313,11 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
       if ((m->leg_sizes || m->terrain_sizes) && !same_tree(SpecTree<2>::parent, SpecTree<2>::nv)) m->leg_sizes = m->terrain_sizes = false;
     }
     if (m->rk4) m->hand_sizes = m->leg_sizes = m->terrain_sizes = false;
+    if (w.has_tl) m->hand_sizes = m->leg_sizes = m->terrain_sizes = false;   // the specialised instantiations compile the tendon-limit rows out
+    // ... and their LDS layout in: it must be the one this model was given
+    if (m->hand_sizes && !layout_match<1, 24, 8, 32, 3>(w.lay)) m->hand_sizes = false;
+    if (m->leg_sizes && !layout_match<2, 36, 20, 32, 3>(w.lay)) m->leg_sizes = false;
+    if (m->terrain_sizes && !layout_match<3, 36, 20, 32, 3>(w.lay)) m->terrain_sizes = false;
     if (const char* e = getenv("MYO_NO_SPEC")) if (atoi(e) == 1) m->hand_sizes = m->leg_sizes = m->terrain_sizes = false;   // tests: force the run-time-sized instantiations
     if (!m->wave_ok && !m->generic_ok) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "model exceeds the limits of both step kernels (nv <= 36, nu <= 128, pair dofs <= 20)"); }
     { const int nvt = m->wave_cfg == 0 ? 24 : 36;
@@ -697,7 +678,12 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
   }
   long long* st = b->d_stamps;
 #if MYO_POISON
-  hipLaunchKernelGGL(scratch_poison_kernel, dim3(16384), dim3(64), 0, s, (float*)b->d_stamps, 0);
+  {  // MYO_POISON_MODE (diagnostic build only): bit 0 scratch memory, bit 1 vector registers, bit 2 scalar registers; default all
+    static const int pmode = [] { const char* e = getenv("MYO_POISON_MODE"); return e ? atoi(e) : 7; }();
+    if (pmode & 1) hipLaunchKernelGGL(scratch_poison_kernel, dim3(16384), dim3(64), 0, s, (float*)b->d_stamps, 0);
+    if (pmode & 2) hipLaunchKernelGGL(vgpr_poison_kernel, dim3(8192), dim3(64), 0, s, 0x7fc0dead);
+    if (pmode & 4) hipLaunchKernelGGL(sgpr_poison_kernel, dim3(32768), dim3(64), 0, s);
+  }
 #endif
   if (!(G == 64 && m->wave_ok) && !m->generic_ok)
     return fail(MYO_E_UNSUPPORTED, "this model (tendon limits / free joint / equalities / plane contacts) needs the wave-per-env kernel (lanes = 64)");
@@ -708,10 +694,9 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     std::lock_guard<std::mutex> attr_lock(attr_mu);
     bool& attr_w = attr_w_dev[m->device & 63];
     if (!attr_w) {
-      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 4, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 3, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 4, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 4, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -721,8 +706,6 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 32, 1, 3, false, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<36, 20, 32, 2, 2, false, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 16, 1, 5, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      HIPCHK(hipFuncSetAttribute((const void*)step_kernel_w<24, 8, 16, 1, 5, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       attr_w = true;
     }
     const int* order = nullptr;
@@ -734,7 +717,7 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     const int n_cu = m->n_cu > 0 ? m->n_cu : 256;                                                        // per model = per device
     const int resident = n_cu * (m->wave_cfg == 0 ? 16 : (m->wave_cfg == 1 ? 8 : std::max(1, (160 * 1024) / std::max(1, m->env_lds_bytes_w))));
     const bool sched_ok = !kflags && Bn >= 64 && Bn <= SCHED_ENV_MASK && nsub + (wk ? 1 : 0) <= 15 && nsub > 0;
-    const bool sched = sched_ok && m->wave_cfg != 2 && m->wave_wpe == 4 && !m->rk4 && !(m->dw.hf.on && !m->terrain_sizes) && (sched_mode == 1 || (sched_mode == -1 && m->wave_cfg == 1 && Bn >= 2 * resident));
+    const bool sched = sched_ok && m->wave_cfg == 1 && !m->rk4 && !(m->dw.hf.on && !m->terrain_sizes) && (sched_mode == 1 || (sched_mode == -1 && m->wave_cfg == 1 && Bn >= 2 * resident));
     if (b->balance && Bn >= 1024 && Bn % 4 == 0 && !kflags && !sched) {
       static const int prio_mode = [] { const char* e = getenv("MYO_PRIO"); return e ? atoi(e) : 2; }();
       hipLaunchKernelGGL(balance_kernel, dim3(1), dim3(1024), 0, s, (const int*)b->db.diag, Bn, b->d_order, Bn / 4, prio_mode);
@@ -747,18 +730,15 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     if (!kflags)   // instantiation chosen below, as rocprofv3 prints it (bench.py reports it next to the kernel time)
       b->last_kernel = m->rk4 ? (m->wave_cfg == 0 ? "step_kernel_w<24,8,32,1,3,false,0,false,false,true>" : "step_kernel_w<36,20,32,2,2,false,0,false,false,true>") :
                        m->wave_cfg == 2 ? "step_kernel_w<36,20,32,2,2,false,0,false,true>" :
-                       (m->wave_cfg == 0 && m->wave_wpe == 5) ? (m->hand_sizes ? "step_kernel_w<24,8,16,1,5,false,1,false,false>" : "step_kernel_w<24,8,16,1,5,false,0,false,false>") : sched ? (m->wave_cfg == 0 ? "step_kernel_w<24,8,32,1,4,true,0,false>" : m->dw.hf.on ? "step_kernel_w<36,20,32,2,2,true,3,true>" : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,true,2,false>" : "step_kernel_w<36,20,32,2,2,true,0,false>"))
-                             : (m->wave_cfg == 0 ? (m->hand_sizes ? "step_kernel_w<24,8,32,1,4,false,1,false>" : "step_kernel_w<24,8,32,1,4,false,0,false>")
+                       sched ? (m->dw.hf.on ? "step_kernel_w<36,20,32,2,2,true,3,true>" : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,true,2,false>" : "step_kernel_w<36,20,32,2,2,true,0,false>"))
+                             : (m->wave_cfg == 0 ? (m->hand_sizes ? "step_kernel_w<24,8,32,1,4,false,1,false>" : "step_kernel_w<24,8,32,1,3,false,0,false>")
                                                  : (m->dw.hf.on ? (m->terrain_sizes ? "step_kernel_w<36,20,32,2,2,false,3,true>" : "step_kernel_w<36,20,32,2,2,false,0,true>") : (m->leg_sizes ? "step_kernel_w<36,20,32,2,2,false,2,false>" : "step_kernel_w<36,20,32,2,2,false,0,false>")));
     if (sched) {
       hipLaunchKernelGGL(sched_init_kernel, dim3(1), dim3(1024), 0, s, (const int*)b->db.diag, Bn, S);
       int grid = Bn < resident ? Bn : resident;    // persistent waves: no more workgroups than the chip holds at once
       static const int grid_override = [] { const char* e = getenv("MYO_SCHED_GRID"); return e ? atoi(e) : 0; }();
       if (grid_override > 0 && grid_override < grid) grid = grid_override;
-      if (m->wave_cfg == 0)
-        hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, true, 0>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
-                           (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, (const int*)nullptr, (const DevWalk*)nullptr, 0, S);
-      else if (m->dw.hf.on)
+      if (m->dw.hf.on)
         hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, true, 3, true>), dim3(grid), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                            (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, (const int*)nullptr, wk, 0, S);
       else if (m->leg_sizes)
@@ -776,17 +756,11 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
     else if (m->wave_cfg == 2)   // TrackEnv model class
       hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, false, 0, false, true>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                          (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, wk, kflags, S);
-    else if (m->wave_cfg == 0 && m->wave_wpe == 5 && m->hand_sizes)
-      hipLaunchKernelGGL((step_kernel_w<24, 8, 16, 1, 5, false, 1>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
-                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0, S);
-    else if (m->wave_cfg == 0 && m->wave_wpe == 5)
-      hipLaunchKernelGGL((step_kernel_w<24, 8, 16, 1, 5, false, 0>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
-                         (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0, S);
     else if (m->wave_cfg == 0 && m->hand_sizes)
       hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, false, 1>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                          (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0, S);
     else if (m->wave_cfg == 0)
-      hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 4, false, 0>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
+      hipLaunchKernelGGL((step_kernel_w<24, 8, 32, 1, 3, false, 0>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,
                          (const DevModelW*)m->d_dw, b->db, action, actmap, nsub, st, order, (const DevWalk*)nullptr, 0, S);
     else if (m->dw.hf.on && m->terrain_sizes)     // terrain models: the instantiations with the height-field narrow phase
       hipLaunchKernelGGL((step_kernel_w<36, 20, 32, 2, 2, false, 3, true>), dim3(Bn), dim3(64), (size_t)m->env_lds_bytes_w, s, (const DevModel*)m->d_dm,

@@ -24,6 +24,35 @@ struct LayW {
   int tJp;                                                    // persistent sparse tendon rows (only for models with tendon limits)
   int total;
 };
+// The one definition of the wave kernel's LDS layout: myo_model_load runs it on the model's sizes, the size-specialised instantiations
+// evaluate it at compile time on Sizes<SPEC> (every LDS address is then an immediate: round 2 read ~250 layout words per substep
+// through scalar loads, each behind an s_waitcnt that also drains the LDS queue).
+__host__ __device__ constexpr LayW layout_w(int nq, int nv, int nu, int nl, int ngt, int maxnnz, int ncg, bool has_tl, int nvt, int kc, int nc, int nj) {
+  LayW Y{};
+  int o = 0;
+  Y.qpos = o; o += nq; Y.qvel = o; o += nv; Y.act = o; o += nu; Y.ctrl = o; o += nu;
+  Y.lpos = o; o += 3 * nl; Y.lmat = o; o += 9 * nl; Y.axis = o; o += 3 * nv; Y.anchor = o; o += 3 * nv;
+  Y.xv = o; o += nvt; Y.qfc = o; o += nvt; Y.sq = o; o += nvt * (nvt + 1); Y.mprw = o; o += 4 * MPRW;
+  Y.tJp = 0;
+  if (has_tl) { Y.tJp = o; o += ngt * maxnnz + 2 * ngt; }   // + tendon lengths and velocities, read again by the tendon-limit rows
+  Y.X = o;
+  Y.tJ = o; o += ngt * maxnnz; Y.tlen = o; o += ngt; Y.tforce = o; o += nu;
+  const int endT = o;
+  o = Y.X;
+  Y.cdof = o; o += 6 * nv; Y.cinert = o; o += 10 * nl; Y.crb = o; o += 10 * nl; Y.cvel = o; o += 6 * nl; Y.cacc = o; o += 6 * nl; Y.cfrc = o; o += 6 * nl;
+  const int endD = o;
+  o = Y.X;
+  Y.Mp = o;
+  Y.gpos = o; o += 3 * ncg; Y.gax = o; o += 3 * ncg;
+  Y.cand = o; o += NCAND;
+  if (o - Y.Mp < (nvt * (nvt + 1)) / 2) o = Y.Mp + (nvt * (nvt + 1)) / 2;
+  Y.cdist = o; o += nc; Y.cpos = o; o += 3 * nc; Y.cnrm = o; o += 3 * nc; Y.cpair = o; o += nc;
+  Y.cJ = o; o += nc * nj * kc; Y.cdofs = o; o += nc * ((kc + 3) / 4);   // nj jacobian rows of kc entries per contact; kc dof ids per contact, one byte each
+  if (o < endT) o = endT;
+  if (o < endD) o = endD;
+  Y.total = o;
+  return Y;
+}
 // colliding height field (terrain models): world-fixed, axis-aligned; elevation data lives per env in DevBatch.hfield
 struct HfDev { int on, nrow, ncol, cg; float size[4], pos[3]; };
 struct DevModelW {
@@ -46,6 +75,8 @@ struct DevModelW {
 
 __device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ int rdlanei(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+// wave-uniform float kept in a scalar register (a VGPR copy of it would be one more value live across every stage)
+__device__ __forceinline__ float uniformf(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
@@ -58,6 +89,13 @@ __device__ __forceinline__ float wave_sum(float v) {
   return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
 }
 #define WFOR(i, n) for (int i = lane; i < (n); i += 64)
+// this lane's index in the wave, recomputed where it is needed (two instructions): a copy of threadIdx.x kept for the whole kernel is a
+// register that is live across every stage, and was the first thing the allocator spilled
+__device__ __forceinline__ int wave_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 // dof id k (0..KC-1) of contact c from the byte-packed table (CDW = ints per contact, a constexpr of the kernel)
 #define CDOF(E_, Y_, c_, k_) ((int)((((const unsigned int*)((E_) + (Y_).cdofs))[CDW * (c_) + ((k_) >> 2)] >> (8 * ((k_) & 3))) & 255u))
 // same from a pointer to the contact's own packed words (LDS row or HBM overflow row)
@@ -156,7 +194,7 @@ template <int NVT> __device__ __forceinline__ float symv_lds(const float* Mp, fl
   return s;
 }
 
-__device__ __forceinline__ void site_world_w(const DevModel& M, const LayW& Y, const float* E, int s, float* out) {
+template <class LY> __device__ __forceinline__ void site_world_w(const DevModel& M, const LY& Y, const float* E, int s, float* out) {
   int l = M.site_link[s];
   const float* lp = M.site_lpos + 3 * s;
   float a = lp[0], b = lp[1], c = lp[2];
@@ -167,7 +205,7 @@ __device__ __forceinline__ void site_world_w(const DevModel& M, const LayW& Y, c
   out[1] = P[1] + R[3] * a + R[4] * b + R[5] * c;
   out[2] = P[2] + R[6] * a + R[7] * b + R[8] * c;
 }
-__device__ __forceinline__ void geom_world_pos(const DevModel& M, const LayW& Y, const float* E, int g, float* out) {
+template <class LY> __device__ __forceinline__ void geom_world_pos(const DevModel& M, const LY& Y, const float* E, int g, float* out) {
   int l = M.cg_link[g];
   const float* lp = M.cg_lpos + 3 * g;
   float a = lp[0], b = lp[1], c = lp[2];
@@ -178,7 +216,7 @@ __device__ __forceinline__ void geom_world_pos(const DevModel& M, const LayW& Y,
   out[1] = P[1] + R[3] * a + R[4] * b + R[5] * c;
   out[2] = P[2] + R[6] * a + R[7] * b + R[8] * c;
 }
-__device__ __forceinline__ void geom_world_mat(const DevModel& M, const LayW& Y, const float* E, int g, float* R) {
+template <class LY> __device__ __forceinline__ void geom_world_mat(const DevModel& M, const LY& Y, const float* E, int g, float* R) {
   int l = M.cg_link[g];
   if (l < 0) {
 #pragma unroll
@@ -190,7 +228,7 @@ __device__ __forceinline__ void geom_world_mat(const DevModel& M, const LayW& Y,
 // moment-arm entries of one straight tendon piece
 // Jt = this tendon's sparse jacobian row in LDS (zeroed before the segment rounds): the entries are accumulated with LDS float atomics
 // by the segment lanes themselves (one wave: deterministic order) instead of being gathered entry by entry by the tendon's lane
-__device__ __forceinline__ float straight_w(const DevModel& M, const LayW& Y, float* E, float* Jt, const float* pa, const float* pb, int adr, int n,
+template <class LY> __device__ __forceinline__ float straight_w(const DevModel& M, const LY& Y, float* E, float* Jt, const float* pa, const float* pb, int adr, int n,
                                             float invdiv, bool active) {
   float dif[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
   float dist = norm3(dif);
@@ -315,6 +353,20 @@ template <int SPEC> static bool sizes_match(int nq, int nv, int nu, int nl, int 
          ncg == Z::ncg && npair == Z::npair;
 }
 
+// compile-time layout of a size-specialised instantiation (SPEC models have no tendon limits: myo_model_load checks it)
+template <int SPEC, int NVT, int KC, int NC, int NJ> struct LayC {
+  typedef Sizes<SPEC> Z;
+  static constexpr LayW L = layout_w(Z::nq, Z::nv, Z::nu, Z::nl, Z::nu, Z::maxnnz, Z::ncg, false, NVT, KC, NC, NJ);
+  static constexpr int qpos = L.qpos, qvel = L.qvel, act = L.act, ctrl = L.ctrl, lpos = L.lpos, lmat = L.lmat, axis = L.axis, anchor = L.anchor, xv = L.xv,
+                       qfc = L.qfc, sq = L.sq, mprw = L.mprw, X = L.X, tJ = L.tJ, tlen = L.tlen, tforce = L.tforce, cdof = L.cdof, cinert = L.cinert, crb = L.crb,
+                       cvel = L.cvel, cacc = L.cacc, cfrc = L.cfrc, gpos = L.gpos, gax = L.gax, cand = L.cand, cdist = L.cdist, cpos = L.cpos, cnrm = L.cnrm,
+                       cpair = L.cpair, cJ = L.cJ, cdofs = L.cdofs, Mp = L.Mp, tJp = L.tJp, total = L.total;
+};
+template <int SPEC, int NVT, int KC, int NC, int NJ> static bool layout_match(const LayW& a) {
+  const LayW b = layout_w(Sizes<SPEC>::nq, Sizes<SPEC>::nv, Sizes<SPEC>::nu, Sizes<SPEC>::nl, Sizes<SPEC>::nu, Sizes<SPEC>::maxnnz, Sizes<SPEC>::ncg, false, NVT, KC, NC, NJ);
+  return memcmp(&a, &b, sizeof(LayW)) == 0;
+}
+
 // TRK (MyoDM TrackEnv model class): condim-4 contacts (6 pyramid rows, a 4th jacobian row for the spin about the normal), joint friction-loss
 // rows, box / convex-hull shapes in the narrow phase.  All of it sits behind `if constexpr (TRK)`: the other instantiations compile as before.
 // RK4: mj_RungeKutta(4) instead of mj_Euler -- every substep runs the whole forward pass four times (state X0 + h a F[i-1], a = 1/2, 1/2, 1)
@@ -329,8 +381,10 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   // pinning ~150 SGPRs for the whole kernel
   const DevModel& M = *Mp;
   const DevModelW& W = *Wp;
-  const LayW& Y = W.lay;
-  const int lane_id = threadIdx.x;
+  // LDS layout: compile-time constants in the size-specialised instantiations (every LDS address an immediate), read from the model otherwise
+  const LayC<SPEC, NVT, KC, NC, (TRK ? 4 : 3)> Yc{};
+  const auto& Y = [&]() -> const auto& { if constexpr (SPEC != 0) return Yc; else return W.lay; }();
+#define lane_id wave_lane()
   // workgroup -> env map: a speed-only placement hint (envs sorted by last step's cost, see balance_kernel); results of an
   // env never depend on which workgroup steps it
   const int oe = (!SCHED && order) ? order[blockIdx.x] : blockIdx.x;
@@ -359,6 +413,9 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   constexpr bool FULL = NVT > 24;
   const bool has_free = FULL && W.has_free;
   const int neq = FULL ? W.neq : 0;
+  // tendon limits: never in the size-specialised and TRK instantiations (myo_model_load checks it), so their tendon lengths / velocities
+  // do not stay live in registers from the tendon stage to the row stage
+  const bool has_tl = (SPEC != 0 || TRK) ? false : (W.has_tl != 0);
   const bool walk = FULL && wk != nullptr;   // fused observation / reward pass of the walk task after the last substep
   if (!SCHED && FULL && (kflags & KF_RESET_ONLY) && Bt.elapsed[env] != 0) return;   // wave-uniform: refresh only the envs an auto-reset just touched
 #if MYO_STAMPS
@@ -373,8 +430,6 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
 #endif
   const int nsubtot = nsub + (walk ? 1 : 0);
   const float h = M.timestep;
-  const float scale = 1.0f / (M.meaninertia * (float)(nv > 1 ? nv : 1));
-  const float damping = lane_id < nv ? M.dof_damping[lane_id] : 0.f;
   // scheduler state of this wave: the queue of the XCD it runs on
   const int sq_q = SCHED ? (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7) % S.nqueue : 0;
   int* const sq_ctl = SCHED ? S.ctl + 4 * sq_q : nullptr;
@@ -402,7 +457,11 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   }
   // ---- state: LDS copies of what other lanes gather; per-dof / per-actuator scalars stay in registers.  Under the scheduler the
   // rows were written by another CU of this XCD: agent-scope loads read them from L2 instead of a possibly stale L1 line
-  float warm = 0.f, qacc = 0.f, actdot[NTR];
+  float actdot[NTR];   // (RK4 only)
+  // the solver's warm start (= the previous substep's qacc) stays in the batch row Bt.warm between substeps: one coalesced store after the
+  // solve, one load before the next (issued ahead of the row stage); a register for it would be live across every stage of the substep and
+  // the 16-envs-per-CU LDS slice has no 24 floats to spare
+  float* const warm_row = Bt.warm + (size_t)env * nv;
 #pragma unroll
   for (int r = 0; r < NTR; r++) actdot[r] = 0.f;
 #ifndef MYO_POISON_BITS
@@ -418,7 +477,6 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   if (lane_id < nq) E[Y.qpos + lane_id] = ldstate<SCHED>(Bt.qpos + (size_t)env * nq + lane_id);
   if (lane_id < nv) {
     E[Y.qvel + lane_id] = ldstate<SCHED>(Bt.qvel + (size_t)env * nv + lane_id);
-    warm = ldstate<SCHED>(Bt.warm + (size_t)env * nv + lane_id);
   }
   for (int i = lane_id; i < nu; i += 64) {
     E[Y.act + i] = ldstate<SCHED>(Bt.act + (size_t)env * nu + i);
@@ -427,7 +485,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     else c = ldstate<SCHED>(Bt.ctrl + (size_t)env * nu + i);
     E[Y.ctrl + i] = c;
   }
-  float time = ldstate<SCHED>(Bt.time + env);
+  float time = uniformf(ldstate<SCHED>(Bt.time + env));
   int flags = 0, d_nefc = 0, d_ncon = 0, d_iter = 0, d_cost = 0;
   int f_cand = 0, f_mpr = 0, f_ncon = 0, f_iter = 0, f_itcon = 0, f_ls = 0, f_fact = 0;   // work features of this env step (placement cost model)
   if (SCHED && s0 > 0) {   // accumulators of the earlier substeps of this env step
@@ -449,8 +507,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   const int nct = ovf_env ? NC + NCXK : NC;
   // narrow-phase round width: the MPR's per-lane LDS scratch (9 floats) lives in the contact-jacobian area, which holds 64 lanes' worth only
   // when NC * NJ * KC >= 576; the low-LDS instantiations (NC = 16) run the narrow phase in rounds of 32 candidates (typical count: 10-20)
-  constexpr int RND = (NC * NJ * KC >= 576) ? 64 : 32;
-  static_assert(RND * 9 <= NC * NJ * KC, "MPR scratch must fit the contact-jacobian area");
+  constexpr int RND = (NC * NJ * KC >= 768) ? 64 : 32;
+  static_assert(RND * 12 <= NC * NJ * KC, "MPR scratch must fit the contact-jacobian area");
   int* const ovf_cand = (!HF && Bt.ovf_cand) ? Bt.ovf_cand + (size_t)env * NCANDX : nullptr;
   bool alive = true;
   int n_mprw = 0;   // MPR warm-start table (pair id + last contact normal in geom 1's frame): entries of the previous substep
@@ -474,7 +532,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     // ~60 values per lane out of it and spilling them to scratch
     asm volatile("" ::: "memory");
     int lane;   // opaque per-iteration copy of the lane id: address arithmetic derived from it cannot be hoisted (and spilled)
-    asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane_id));
+    lane = wave_lane();
     {  // mj_checkPos / mj_checkVel
       bool bad = false;
       if (lane < nq) { float a = E[Y.qpos + lane]; bad = !(a == a) || fabsf(a) > MAXVALF; }
@@ -664,15 +722,18 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       for (int k = 0; k < maxnnz_; k++) {
         int d = M.gt_dofs[gt * maxnnz_ + k];
         if (d >= 0) vel += Jrow[k] * E[Y.qvel + d];
-        if (W.has_tl) E[Y.tJp + gt * maxnnz_ + k] = Jrow[k];
+        if (has_tl) E[Y.tJp + gt * maxnnz_ + k] = Jrow[k];
       }
       tvel_r[rr] = vel;
+      if (has_tl) { E[Y.tJp + ngt_ * maxnnz_ + gt] = L; E[Y.tJp + ngt_ * maxnnz_ + ngt_ + gt] = vel; }
       if (gt < nu) {
         const float* A = M.act + 16 * gt;
         float f, ad;
         if (A[10] < 0.f) { f = A[0] * clipf(E[Y.ctrl + gt], A[12], A[13]) + A[1] + A[14] * (A[2] * L + A[3] * vel); ad = 0.f; }   // stateless affine actuator
         else muscle(A, A[14] * L, A[14] * vel, E[Y.act + gt], E[Y.ctrl + gt], &f, &ad);
-        actdot[rr] = ad;
+        if constexpr (RK4) actdot[rr] = ad;
+        else if (!op) E[Y.act + gt] += h * ad;   // Euler: the activation is advanced right here (nothing reads it again in this substep; a bad-state env is
+                                                 // reset as a whole afterwards), so no derivative stays live in a register across collision and solver
         const float ft = f * A[14];
         E[Y.tforce + gt] = ft;
         // J^T f of the actuators, lane = tendon: its <= maxnnz moment arms go to their dofs with LDS atomics (one lane per dof walking the
@@ -884,7 +945,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         E[Y.sq + a * (NVT + 1) + d] = sdot;
         a = M.dof_parent[a];
       }
-      smooth = -damping * E[Y.qvel + d] - bias + qfa;
+      smooth = -M.dof_damping[d] * E[Y.qvel + d] - bias + qfa;
     }
     SYNC();  // region X changes owner: dynamics scratch -> collision / contact rows
     SUB(11);
@@ -1038,6 +1099,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       int n_mprw_new = 0;
       SYNC();
       STAMP(6);
+      MeshTab MT;   // hull tables of the TRK models (wave-uniform)
+      if constexpr (TRK) { MT.vert = W.mesh_vert; MT.rec = (gpf4)W.mesh_rec; MT.srec = (gpf4)W.mesh_startrec; }
       for (int base = 0; base < ncand; base += RND) {
         int ci = (RND == 64 || lane < RND) ? base + lane : ncand;
         int nsup = -8;                    // support evaluations of this lane's MPR refinement (-8: not an MPR pair)
@@ -1105,10 +1168,10 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             geom_world_mat(M, Y, E, g2, R2);
             matTvec(nl, R2, n);
             CObj oh;
-            cobj_shape_poly(oh, 7, sz2, W.mesh_vert, (gpf4)W.mesh_rec, (gpf4)W.mesh_startrec);
+            cobj_shape_poly(oh, 7, sz2);
             const float dn[3] = {-nl[0], -nl[1], -nl[2]};
             float sp[3];
-            support_shape<2>(oh, dn, sp);          // vertex-graph climb (scan for small hulls) instead of a pass over all vertices
+            support_shape<2>(oh, dn, sp, MT);        // vertex-graph climb (scan for small hulls) instead of a pass over all vertices
             matvec(pw, R2, sp);
             float rel[3] = {x2[0] - x1[0] + pw[0], x2[1] - x1[1] + pw[1], x2[2] - x1[2] + pw[2]};
             float d = dot3(rel, n);
@@ -1184,7 +1247,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
               if (((const int*)(E + Y.mprw))[4 * i] == p) { nw[0] = E[Y.mprw + 4 * i + 1]; nw[1] = E[Y.mprw + 4 * i + 2]; nw[2] = E[Y.mprw + 4 * i + 3]; have_nw = true; }
             }
             bool pen;
-            if constexpr (HF) pen = mpr_penetration_wl<true>(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr, E + Y.cJ + 9 * lane);
+            if constexpr (HF) pen = mpr_penetration_wl<true>(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr, E + Y.cJ + 12 * lane);
             else pen = mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr);
             if (pen) {
               dist = margin - depth;
@@ -1219,8 +1282,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
 #pragma unroll
             for (int k = 0; k < 3; k++) o1.pos[k] = 0.f;
             if constexpr (TRK) {
-              cobj_shape_poly(o1, M.cg_type[g1], sz1, W.mesh_vert, (gpf4)W.mesh_rec, (gpf4)W.mesh_startrec);
-              cobj_shape_poly(o2, M.cg_type[g2], sz2, W.mesh_vert, (gpf4)W.mesh_rec, (gpf4)W.mesh_startrec);
+              cobj_shape_poly(o1, M.cg_type[g1], sz1);
+              cobj_shape_poly(o2, M.cg_type[g2], sz2);
             }
             else { cobj_shape(o1, M.cg_type[g1], sz1); cobj_shape(o2, M.cg_type[g2], sz2); }
             o1.margin = o2.margin = 0.5f * margin;
@@ -1231,7 +1294,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             }
             // portal witnesses in per-lane LDS scratch: the contact-jacobian area of region X, not written before the rows stage
             // (TRK: a 1e-6 tolerance -- MuJoCo's ccd default -- was measured: narrow phase -15 %, but the one-substep qpos error p50 grows 2.7e-6 -> 1.5e-5)
-            if (mpr_penetration_wl<TRK ? 2 : 0>(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr, E + Y.cJ + 9 * lane)) {
+            if (mpr_penetration_wl<TRK ? 2 : 0>(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr, E + Y.cJ + 12 * lane, MT)) {
               dist = margin - depth;
               normalize3(dir);
               mpr_hit = true; mpr_n[0] = dir[0]; mpr_n[1] = dir[1]; mpr_n[2] = dir[2];
@@ -1305,6 +1368,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     } else n_mprw = 0;
     STAMP(4);
     // ---------------------------------------------------------------- constraint rows (registers: lane = dof / lane = contact)
+    const float warm_r = lane < nv ? ldstate<SCHED>(warm_row + lane) : 0.f;   // (its latency hides behind the row stage)
     float lsign = 0.f, laref = 0.f, lD = 0.f;
     if (lane < nv && !M.disable_limit) {
       const float* J = M.jl + 12 * lane;
@@ -1551,7 +1615,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       nefc += __popcll(__ballot(flf > 0.f));
     }
     const int ncon_real = ncon;
-    if (W.has_tl) {
+    if (has_tl) {
       // an active tendon limit becomes a frictionless pseudo-contact: jacobian = +-(sparse tendon row), mu = 0 and D/4 on each
       // of the four identical "pyramid" rows, which together act exactly like the single MuJoCo limit row
       int nt = ncon;
@@ -1563,14 +1627,15 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       if (gt < ngt_ && !M.disable_limit) {
         const float* T = W.tl + 12 * gt;
         if (T[0] != 0) {
-          float margin = T[3], dlo = tlen_r[rr] - T[1], dhi = T[2] - tlen_r[rr], dist = 0;
+          const float tl_len = E[Y.tJp + ngt_ * maxnnz_ + gt], tl_vel = E[Y.tJp + ngt_ * maxnnz_ + ngt_ + gt];   // (LDS copies: not live in registers across collision)
+          float margin = T[3], dlo = tl_len - T[1], dhi = T[2] - tl_len, dist = 0;
           if (dlo < margin && dlo <= dhi) { t_sign = 1; dist = dlo; }
           else if (dhi < margin) { t_sign = -1; dist = dhi; }
           if (t_sign != 0) {
             float imp = impedance(T + 6, dist, margin), K, B;
             float R = fmaxf(MINVALF, (1 - imp) / imp * T[11]);
             kbi(T[4], T[5], T[7], M.timestep, &K, &B);
-            t_aref = -B * (t_sign * tvel_r[rr]) - K * imp * (dist - margin);
+            t_aref = -B * (t_sign * tl_vel) - K * imp * (dist - margin);
             t_D = 1.0f / R;
             tact = true;
           }
@@ -1642,13 +1707,13 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     SUB0();
     // ---------------------------------------------------------------- solver: Newton iterations, then the Euler solve, sharing ONE
     // instance of the unrolled register Cholesky.  phase 0 = Newton, 1 = unconstrained (nefc == 0), 2 = Euler (implicit damping)
-    float Ma = 0.f, grad = 0.f, qfc = 0.f, ljar = 0.f, ljv = 0.f, cost = 0.f, qaccE = 0.f;
+    float Ma = 0.f, grad = 0.f, qfc = 0.f, ljar = 0.f, ljv = 0.f, cost = 0.f, qaccE = 0.f, qacc = 0.f;
     float cjar[NR], cjv[NR];
 #pragma unroll
     for (int k = 0; k < NR; k++) { cjar[k] = 0.f; cjv[k] = 0.f; }
     int phase = nefc > 0 ? 0 : 1, iters = 0;
     if (phase == 0) {  // start from the warm start (MuJoCo also tries qacc_smooth; the minimiser is the same)
-      qacc = warm;
+      qacc = warm_r;
       Ma = symv_lds<NVT>(Mp, qacc, lane, nv);
       ljar = lsign * qacc - laref;
       if constexpr (TRK) fljar = qacc - flaref;
@@ -1673,10 +1738,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     SUB(6);
     bool first = true;
     int sig_prev = -1;
-    const int lane_s = lane;
     while (true) {
-      int lane;   // opaque copy again: keeps the 24 per-lane symv addresses from being hoisted out of the loop and spilled
-      asm volatile("v_mov_b32 %0, %1" : "=v"(lane) : "v"(lane_s));
+      const int lane = wave_lane();   // opaque copy again: keeps the 24 per-lane symv addresses from being hoisted out of the loop and spilled
       float r[NVT], rhs, invd;
       bool refactor = true;
       if (phase == 0) {
@@ -1743,6 +1806,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         float newcost = wave_sum(cst);
         grad = Ma - smooth - qfc;
         if (!first) {
+          const float scale = M.newton_scale;   // 1 / (meaninertia * nv), computed at load: a scalar load here instead of a VGPR live across every stage
           float improvement = scale * (cost - newcost);
           float gn = scale * sqrtf(wave_sum(grad * grad));
           // float32 round-off of the gradient's own terms: below it the iteration only chases noise (float32 oracle build: 2.7 -> 1.9
@@ -1827,7 +1891,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         constexpr int NVS = SpecTree<SPEC>::nv > 0 ? SpecTree<SPEC>::nv : 1;
         const bool act = lane < NVS;
         const int q = act ? NVS - 1 - lane : 0;                   // this lane's dof in leaves-first order
-        const float dadd = phase == 2 ? h * __shfl(damping, q) : 0.f;
+        const float dadd = phase == 2 ? h * M.dof_damping[q] : 0.f;
         const float rhs_p = act ? __shfl(rhs, q) : 0.f;
 #pragma unroll
         for (int k = 0; k < NVT; k++) {
@@ -1849,7 +1913,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       if (refactor) {
         const int dd = lane < nv ? lane : 0;
         const int based = (dd * (dd + 1)) / 2;
-        const float diag_add = (phase == 2 && !RK4) ? h * damping : 0.f;
+        const float diag_add = (phase == 2 && !RK4) ? h * M.dof_damping[dd] : 0.f;
 #pragma unroll
         for (int k = 0; k < NVT; k++) {
           float mv = (lane < nv && k <= lane) ? Mp[based + (k <= dd ? k : 0)] : 0.f;                 // lower row of M
@@ -1932,7 +1996,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         // stop when the slope is below MuJoCo's tolerance -- or below the float32 round-off of the terms that cancel in it: without
         // the second test the search chases noise (measured on the float32 oracle build: 4.6 -> 1.45 evaluations per search, the float64
         // build needs 1.6; solution unchanged)
-        float gtol = fmaxf(fmaxf(M.tolerance * M.ls_tolerance * sn / scale, LS_FLOOR * d1init), LS_NOISE * (fabsf(g1) + fabsf(2 * a * g2) + fabsf(sp1)));
+        float gtol = fmaxf(fmaxf(M.tolerance * M.ls_tolerance * sn / M.newton_scale, LS_FLOOR * d1init), LS_NOISE * (fabsf(g1) + fabsf(2 * a * g2) + fabsf(sp1)));
         if (fabsf(d1) < gtol) break;
         if (d1 < 0) { lo = alpha; dlo = d1; d2lo = d2; } else { hi = alpha; dhi = d1; d2hi = d2; }
         float cand = alpha - d1 / d2;
@@ -1962,7 +2026,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       bool bad = lane < nv && (!(qacc == qacc) || fabsf(qacc) > MAXVALF);
       if (__any(bad) && alive) { flags |= MYO_FLAG_BAD_QACC; alive = false; }
     }
-    warm = qacc;
+    if (lane < nv) warm_row[lane] = qacc;
     if constexpr (RK4) {
       if (alive) {
         const float Bw = (rk_stage == 0 || rk_stage == 3) ? (1.f / 6.f) : (1.f / 3.f), a = rk_stage < 2 ? 0.5f : 1.f;
@@ -2012,14 +2076,12 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             E[Y.qpos + qa] = o[0] * on; E[Y.qpos + qa + 1] = o[1] * on; E[Y.qpos + qa + 2] = o[2] * on; E[Y.qpos + qa + 3] = o[3] * on;
           }
         }
-        time = rk_t0 + (last ? h : a * h);
+        time = uniformf(rk_t0 + (last ? h : a * h));
       }
       SYNC();
       if (alive && ++rk_stage < 4) goto rk_next_stage;
     } else
     if (alive) {
-#pragma unroll
-      for (int rr = 0; rr < NTR; rr++) if (lane + 64 * rr < nu) E[Y.act + lane + 64 * rr] += h * actdot[rr];
       bool frot = false;
       if (lane < nv) {
         float v = E[Y.qvel + lane] + h * qaccE;
@@ -2050,7 +2112,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           }
         }
       }
-      time += h;
+      time = uniformf(time + h);
     }
     SYNC();
     STAMP(8);
@@ -2058,15 +2120,14 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   if (!SCHED && FULL && (kflags & KF_AUX)) return;   // observation-only launch: the state arrays are not touched
   if (!alive) {  // a bad env is reset like mj_resetData (mj_sim_scene.py:56-61)
     if (lane_id < nq) E[Y.qpos + lane_id] = M.qpos0[lane_id];
-    if (lane_id < nv) { E[Y.qvel + lane_id] = 0; warm = 0; }
+    if (lane_id < nv) { E[Y.qvel + lane_id] = 0; warm_row[lane_id] = 0.f; }
     for (int i = lane_id; i < nu; i += 64) { E[Y.act + i] = 0; E[Y.ctrl + i] = 0; }
     time = 0;
   }
   if (lane_id < nq) Bt.qpos[(size_t)env * nq + lane_id] = E[Y.qpos + lane_id];
   if (lane_id < nv) {
     Bt.qvel[(size_t)env * nv + lane_id] = E[Y.qvel + lane_id];
-    Bt.warm[(size_t)env * nv + lane_id] = warm;
-    Bt.qacc[(size_t)env * nv + lane_id] = qacc;
+    Bt.qacc[(size_t)env * nv + lane_id] = warm_row[lane_id];   // (= the last substep's qacc; zero for an env that was just reset, like mj_resetData)
   }
   for (int i = lane_id; i < nu; i += 64) {
     Bt.act[(size_t)env * nu + i] = E[Y.act + i];
@@ -2111,4 +2172,5 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
 #endif
 }
 
+#undef lane_id
 #endif  // MYO_KERNEL_WAVE_H

@@ -377,6 +377,29 @@ __global__ void __launch_bounds__(64) scratch_poison_kernel(float* sink, int n) 
   for (int i = 0; i < 512; i++) buf[i] = __int_as_float(0x7fc00000 | i);
   if (n < 0) sink[threadIdx.x] = buf[(-n) & 511];
 }
+// ... and the register files: a wave starts with whatever the previous wave left in its VGPR / AGPR / SGPR allocation, so a read of a
+// register the kernel never wrote (a value defined under a lane predicate and read by other lanes through a shuffle / v_readlane, an
+// `implicit-def`) is order-dependent in exactly the way a stale scratch word is.  One wave per SIMD owning all 512 vector registers writes
+// NaN patterns into every one of them; a second kernel at 8 waves per SIMD does the same for the scalar registers.
+#define MYO_R1(p, n) p #n
+#define MYO_R10(M, p, t) M(p, t##0) M(p, t##1) M(p, t##2) M(p, t##3) M(p, t##4) M(p, t##5) M(p, t##6) M(p, t##7) M(p, t##8) M(p, t##9)
+#define MYO_R100(M, p, h) MYO_R10(M, p, h##0) MYO_R10(M, p, h##1) MYO_R10(M, p, h##2) MYO_R10(M, p, h##3) MYO_R10(M, p, h##4) \
+                          MYO_R10(M, p, h##5) MYO_R10(M, p, h##6) MYO_R10(M, p, h##7) MYO_R10(M, p, h##8) MYO_R10(M, p, h##9)
+#define MYO_R256(M, p) MYO_R10(M, p, ) MYO_R10(M, p, 1) MYO_R10(M, p, 2) MYO_R10(M, p, 3) MYO_R10(M, p, 4) MYO_R10(M, p, 5) MYO_R10(M, p, 6) \
+                       MYO_R10(M, p, 7) MYO_R10(M, p, 8) MYO_R10(M, p, 9) MYO_R100(M, p, 1) MYO_R10(M, p, 20) MYO_R10(M, p, 21) MYO_R10(M, p, 22) \
+                       MYO_R10(M, p, 23) MYO_R10(M, p, 24) M(p, 250) M(p, 251) M(p, 252) M(p, 253) M(p, 254) M(p, 255)
+#define MYO_R102(M, p) MYO_R10(M, p, ) MYO_R10(M, p, 1) MYO_R10(M, p, 2) MYO_R10(M, p, 3) MYO_R10(M, p, 4) MYO_R10(M, p, 5) MYO_R10(M, p, 6) \
+                       MYO_R10(M, p, 7) MYO_R10(M, p, 8) MYO_R10(M, p, 9) M(p, 100) M(p, 101)
+#define MYO_WV(p, n) "v_mov_b32 v" #n ", %0\n\t"
+#define MYO_WA(p, n) "v_accvgpr_write_b32 a" #n ", %0\n\t"
+#define MYO_WS(p, n) "s_mov_b32 s" #n ", 0x7fc0beef\n\t"
+#define MYO_CL(p, n) , p #n
+__global__ void __launch_bounds__(64, 1) vgpr_poison_kernel(int bits) {
+  asm volatile(MYO_R256(MYO_WV, "") MYO_R256(MYO_WA, "") "s_nop 0" : : "s"(bits) : "memory" MYO_R256(MYO_CL, "v") MYO_R256(MYO_CL, "a"));
+}
+__global__ void __launch_bounds__(64, 8) sgpr_poison_kernel() {
+  asm volatile(MYO_R102(MYO_WS, "") "s_nop 0" : : : "memory" MYO_R102(MYO_CL, "s"));
+}
 #endif
 __global__ void __launch_bounds__(1024) valu_probe_kernel(float* out, int iters, float seed) {
   extern __shared__ float lds_dummy[];

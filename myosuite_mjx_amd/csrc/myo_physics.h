@@ -315,7 +315,10 @@ typedef const float4* gpf4;
 // by value: registers.  Polytope kernels only: verts (small hulls are scanned), rec / srec (vertex graph as self-contained records, lowering.py
 // hip_mesh_rec / hip_mesh_startrec) and the warm start of the climb: hv = the support vertex of this object's previous query [x, y, z, word]
 // (word < 0: none yet).  Successive MPR directions are close, so the next climb usually ends after one look at the neighbours.
-struct CObj { float pos[3], mat[9], S[3], h, margin; const float* verts; gpf4 rec, srec; mutable float hv[4]; };
+struct CObj { float pos[3], mat[9], S[3], h, margin; int vadr, sadr; mutable float hv[4]; };
+// the mesh tables themselves are wave-uniform and travel beside the objects (scalar registers): a CObj only keeps where its own vertices
+// (vadr, in vertices) and its start-direction table (sadr, in records) begin -- two ints instead of three 64-bit pointers per object
+struct MeshTab { gpf vert = nullptr; gpf4 rec = nullptr, srec = nullptr; };
 __device__ __forceinline__ void cobj_shape(CObj& o, int type, const float* size) {
   if (type == GEOM_ELLIPSOID) { o.S[0] = size[0]; o.S[1] = size[1]; o.S[2] = size[2]; o.h = 0.f; }
   else if (type == GEOM_CYLINDER) { o.S[0] = size[0]; o.S[1] = size[0]; o.S[2] = 0.f; o.h = size[1]; }
@@ -331,23 +334,23 @@ __device__ __forceinline__ void support_local(const float* S, float h, const flo
 // polytope shapes (TrackEnv kernels, MPR mode 2): h = -2: box with half sizes S; h = -3: convex hull, S[0] vertices at `verts` (support = best vertex)
 // (hull: vertex list + vertex graph, lowering.py hip_mesh_*: nadr[v] .. nadr[v + 1] index the mesh-local neighbour numbers of vertex v in nbr,
 // start = six axis-extreme vertices)
-__device__ __forceinline__ void cobj_shape_poly(CObj& o, int type, const float* size, const float* mesh_vert, gpf4 rec, gpf4 srec) {
-  o.verts = nullptr; o.rec = nullptr; o.srec = nullptr; o.hv[0] = o.hv[1] = o.hv[2] = 0.f; o.hv[3] = -1.f;
+__device__ __forceinline__ void cobj_shape_poly(CObj& o, int type, const float* size) {
+  o.vadr = 0; o.sadr = 0; o.hv[0] = o.hv[1] = o.hv[2] = 0.f; o.hv[3] = -1.f;
   if (type == 6) { o.S[0] = size[0]; o.S[1] = size[1]; o.S[2] = size[2]; o.h = -2.f; }
   else if (type == 7) {
     const int adr = (int)size[0];
     o.S[0] = size[1]; o.S[1] = o.S[2] = 0.f; o.h = -3.f;
-    o.verts = mesh_vert + 3 * adr; o.rec = rec; o.srec = srec + 96 * (int)size[2];
+    o.vadr = adr; o.sadr = 96 * (int)size[2];
   } else cobj_shape(o, type, size);
 }
-template <int MODE> __device__ __forceinline__ void support_shape(const CObj& o, const float* dl, float* pl) {
+template <int MODE> __device__ __forceinline__ void support_shape(const CObj& o, const float* dl, float* pl, const MeshTab& T = MeshTab{}) {
   if (MODE == 2 && o.h == -2.f) { pl[0] = dl[0] >= 0.f ? o.S[0] : -o.S[0]; pl[1] = dl[1] >= 0.f ? o.S[1] : -o.S[1]; pl[2] = dl[2] >= 0.f ? o.S[2] : -o.S[2]; return; }
   if (MODE == 2 && o.h == -3.f) {
     const int n = (int)o.S[0];
     float bd = -1e30f, bx = 0.f, by = 0.f, bz = 0.f;
     if (n <= 24) {          // small hull: scan
       for (int i = 0; i < n; i++) {
-        const float x = o.verts[3 * i], y = o.verts[3 * i + 1], z = o.verts[3 * i + 2], t = x * dl[0] + y * dl[1] + z * dl[2];
+        const float x = T.vert[3 * (o.vadr + i)], y = T.vert[3 * (o.vadr + i) + 1], z = T.vert[3 * (o.vadr + i) + 2], t = x * dl[0] + y * dl[1] + z * dl[2];
         if (t > bd) { bd = t; bx = x; by = y; bz = z; }
       }
     } else {                // climb the hull's vertex graph: a vertex no neighbour beats is the support vertex (convexity)
@@ -359,7 +362,7 @@ template <int MODE> __device__ __forceinline__ void support_shape(const CObj& o,
         const float dm = axis == 0 ? dl[0] : (axis == 1 ? dl[1] : dl[2]), du = axis == 0 ? dl[1] : (axis == 1 ? dl[2] : dl[0]), dv = axis == 0 ? dl[2] : (axis == 1 ? dl[0] : dl[1]);
         const float inv = 2.0f / fmaxf(fabsf(dm), MINVALF);
         const int iu = min(3, max(0, (int)(du * inv + 2.0f))), iv = min(3, max(0, (int)(dv * inv + 2.0f)));
-        const float4 r = o.srec[((2 * axis + (dm < 0.f ? 1 : 0)) * 4 + iu) * 4 + iv];
+        const float4 r = T.srec[o.sadr + ((2 * axis + (dm < 0.f ? 1 : 0)) * 4 + iu) * 4 + iv];
         bd = r.x * dl[0] + r.y * dl[1] + r.z * dl[2]; bx = r.x; by = r.y; bz = r.z; bw = r.w;
       }
       for (int it = 0; it < 128; it++) {
@@ -368,7 +371,7 @@ template <int MODE> __device__ __forceinline__ void support_shape(const CObj& o,
         for (int e = 0; e < deg; e += 4) {       // lists are padded to a multiple of eight records: four independent 16-byte loads in flight at a time
           float4 r[4];
 #pragma unroll
-          for (int k = 0; k < 4; k++) r[k] = o.rec[e0 + e + k];
+          for (int k = 0; k < 4; k++) r[k] = T.rec[e0 + e + k];
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const float t = r[k].x * dl[0] + r[k].y * dl[1] + r[k].z * dl[2];
@@ -393,7 +396,7 @@ struct Sup { float v[3], v1[3]; };  // Minkowski point and its witness on obj1 (
 // only the bottom or the top triangle can be extremal, by the sign of dir_z.
 // HF is an int mode: 0 smooth primitives, 1 (true) height-field prisms in `a`, 2 polytopes (box / convex hull) in `a` or `b`
 template <int HF = 0>
-__device__ void mink_support(const CObj& a, const CObj& b, const float* dir, Sup& s) {
+__device__ void mink_support(const CObj& a, const CObj& b, const float* dir, Sup& s, const MeshTab& T = MeshTab{}) {
   float nd[3] = {-dir[0], -dir[1], -dir[2]}, dl[3], pl[3], w2[3];
   if (HF == 1 && a.h < 0.f) {
     const bool top = dir[2] >= 0.f;
@@ -409,9 +412,9 @@ __device__ void mink_support(const CObj& a, const CObj& b, const float* dir, Sup
     const float zt = w0 * a.mat[6] + w1 * a.mat[7] + w2 * a.mat[8];
     s.v1[2] = top ? zt : a.S[0];
   } else
-  support_shape<HF>(a, dir, s.v1);
+  support_shape<HF>(a, dir, s.v1, T);
   matTvec(dl, b.mat, nd);
-  support_shape<HF>(b, dl, pl);
+  support_shape<HF>(b, dl, pl, T);
   matvec(w2, b.mat, pl);
   const float m2 = a.margin + b.margin;
 #pragma unroll
@@ -441,7 +444,7 @@ __device__ __forceinline__ void expand_portal(Sup* p, const Sup& v4) {
 #endif
 template <int HF>
 __device__ __forceinline__ bool mpr_penetration_t(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup = nullptr,
-                                  const float* nwarm = nullptr) {
+                                  const float* nwarm = nullptr, const MeshTab& T = MeshTab{}) {
   Sup p[4];
   float dir[3], va[3], vb[3];
 #pragma unroll
@@ -458,7 +461,7 @@ __device__ __forceinline__ bool mpr_penetration_t(const CObj& o1, const CObj& o2
 #pragma unroll
       for (int i = 0; i < 3; i++) dir[i] = nwarm[i] + MPR_WARM_EPS * (c * t1[i] + sn * t2[i]);
       normalize3(dir);
-      mink_support<HF>(o1, o2, dir, p[k]);
+      mink_support<HF>(o1, o2, dir, p[k], T);
       beyond = beyond && dot3(p[k].v, dir) >= 0;
     }
     float s12, s23, s31;
@@ -471,7 +474,7 @@ __device__ __forceinline__ bool mpr_penetration_t(const CObj& o1, const CObj& o2
   if (!warm_ok) {
   dir[0] = -p[0].v[0]; dir[1] = -p[0].v[1]; dir[2] = -p[0].v[2];
   normalize3(dir);
-  mink_support<HF>(o1, o2, dir, p[1]);
+  mink_support<HF>(o1, o2, dir, p[1], T);
   if (dot3(p[1].v, dir) < 0) return false;
   cross3(dir, p[0].v, p[1].v);
   if (norm3(dir) < 1e-12f) {
@@ -482,7 +485,7 @@ __device__ __forceinline__ bool mpr_penetration_t(const CObj& o1, const CObj& o2
     return true;
   }
   normalize3(dir);
-  mink_support<HF>(o1, o2, dir, p[2]);
+  mink_support<HF>(o1, o2, dir, p[2], T);
   if (dot3(p[2].v, dir) < 0) return false;
 #pragma unroll
   for (int k = 0; k < 3; k++) { va[k] = p[1].v[k] - p[0].v[k]; vb[k] = p[2].v[k] - p[0].v[k]; }
@@ -491,7 +494,7 @@ __device__ __forceinline__ bool mpr_penetration_t(const CObj& o1, const CObj& o2
   if (dot3(dir, p[0].v) > 0) { Sup t = p[1]; p[1] = p[2]; p[2] = t; dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
   for (int it = 0;; it++) {
     if (it > maxit) return false;
-    mink_support<HF>(o1, o2, dir, p[3]);
+    mink_support<HF>(o1, o2, dir, p[3], T);
     if (dot3(p[3].v, dir) < 0) return false;
     bool cont = false;
     cross3(va, p[1].v, p[3].v);
@@ -512,7 +515,7 @@ __device__ __forceinline__ bool mpr_penetration_t(const CObj& o1, const CObj& o2
     portal_dir(p, dir);
     if (dot3(dir, p[1].v) >= 0) break;
     Sup v4;
-    mink_support<HF>(o1, o2, dir, v4);
+    mink_support<HF>(o1, o2, dir, v4, T);
     float dv4 = dot3(v4.v, dir);
     float dmin = fminf(fminf(dv4 - dot3(p[1].v, dir), dv4 - dot3(p[2].v, dir)), dv4 - dot3(p[3].v, dir));
     if (dv4 < 0 || dmin <= tol) return false;
@@ -521,7 +524,7 @@ __device__ __forceinline__ bool mpr_penetration_t(const CObj& o1, const CObj& o2
   Sup v4;
   for (int it = 0;; it++) {
     portal_dir(p, dir);
-    mink_support<HF>(o1, o2, dir, v4);
+    mink_support<HF>(o1, o2, dir, v4, T);
     float dv4 = dot3(v4.v, dir);
     float dmin = fminf(fminf(dv4 - dot3(p[1].v, dir), dv4 - dot3(p[2].v, dir)), dv4 - dot3(p[3].v, dir));
     if (dmin <= tol || it > maxit) { if (nsup) *nsup = it; break; }
@@ -559,7 +562,7 @@ __device__ bool mpr_penetration(const CObj& o1, const CObj& o2, float tol, int m
   return mpr_penetration_t<0>(o1, o2, tol, maxit, depth, dirout, posout, nsup, nwarm);
 }
 
-// Same algorithm with the portal's obj-1 witness points kept in LDS (wl: 9 floats of per-lane scratch) instead of registers: they are only
+// Same algorithm with the portal's obj-1 witness points and the interior point kept in LDS (wl: 12 floats of per-lane scratch) instead of registers: they are only
 // needed once, for the contact position at the very end, and 9 VGPRs fewer across the refinement loop is what the MyoHand kernel's
 // register allocation needs (its only spills sit around this call).  Obj 1 sits at the origin of its own frame (o1.pos = 0).
 __device__ __forceinline__ void wl_set(float* wl, int k, const float* w) { wl[3 * (k - 1)] = w[0]; wl[3 * (k - 1) + 1] = w[1]; wl[3 * (k - 1) + 2] = w[2]; }
@@ -574,13 +577,16 @@ __device__ __forceinline__ void wl_swap(float* wl, int a, int b) {
 #define V3COPY(a, b) { a[0] = b[0]; a[1] = b[1]; a[2] = b[2]; }
 template <int HF = 0>
 __device__ __forceinline__ bool mpr_penetration_wl(const CObj& o1, const CObj& o2, float tol, int maxit, float* depth, float* dirout, float* posout, int* nsup,
-                                                   const float* nwarm, float* wl) {
-  float p0[3], p1[3], p2[3], p3[3];
+                                                   const float* nwarm, float* wl, const MeshTab& T = MeshTab{}) {
+  float p1[3], p2[3], p3[3];   // (p0, the interior point, is read in a handful of places only: it lives in wl[9..11])
   Sup s;
   float dir[3], va[3], vb[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) p0[k] = -o2.pos[k];
-  if (norm3(p0) < MINVALF) p0[0] += 1e-5f;
+  {
+    float q[3] = {-o2.pos[0], -o2.pos[1], -o2.pos[2]};
+    if (norm3(q) < MINVALF) q[0] += 1e-5f;
+    wl[9] = q[0]; wl[10] = q[1]; wl[11] = q[2];
+  }
+#define P0LOAD() const float p0[3] = {wl[9], wl[10], wl[11]}
   bool warm_ok = false;
   if (nwarm) {
     float t1[3], t2[3];
@@ -589,22 +595,23 @@ __device__ __forceinline__ bool mpr_penetration_wl(const CObj& o1, const CObj& o
 #pragma unroll
     for (int i = 0; i < 3; i++) dir[i] = nwarm[i] + MPR_WARM_EPS * t1[i];
     normalize3(dir);
-    mink_support<HF>(o1, o2, dir, s);
+    mink_support<HF>(o1, o2, dir, s, T);
     V3COPY(p1, s.v); wl_set(wl, 1, s.v1);
     beyond = beyond && dot3(s.v, dir) >= 0;
 #pragma unroll
     for (int i = 0; i < 3; i++) dir[i] = nwarm[i] + MPR_WARM_EPS * (-0.5f * t1[i] + 0.8660254f * t2[i]);
     normalize3(dir);
-    mink_support<HF>(o1, o2, dir, s);
+    mink_support<HF>(o1, o2, dir, s, T);
     V3COPY(p2, s.v); wl_set(wl, 2, s.v1);
     beyond = beyond && dot3(s.v, dir) >= 0;
 #pragma unroll
     for (int i = 0; i < 3; i++) dir[i] = nwarm[i] + MPR_WARM_EPS * (-0.5f * t1[i] - 0.8660254f * t2[i]);
     normalize3(dir);
-    mink_support<HF>(o1, o2, dir, s);
+    mink_support<HF>(o1, o2, dir, s, T);
     V3COPY(p3, s.v); wl_set(wl, 3, s.v1);
     beyond = beyond && dot3(s.v, dir) >= 0;
     float s12, s23, s31;
+    P0LOAD();
     cross3(va, p1, p2); s12 = dot3(va, p0);
     cross3(va, p2, p3); s23 = dot3(va, p0);
     cross3(va, p3, p1); s31 = dot3(va, p0);
@@ -612,9 +619,10 @@ __device__ __forceinline__ bool mpr_penetration_wl(const CObj& o1, const CObj& o
     else warm_ok = beyond && s12 <= 0 && s23 <= 0 && s31 <= 0;
   }
   if (!warm_ok) {
+    P0LOAD();
     dir[0] = -p0[0]; dir[1] = -p0[1]; dir[2] = -p0[2];
     normalize3(dir);
-    mink_support<HF>(o1, o2, dir, s);
+    mink_support<HF>(o1, o2, dir, s, T);
     V3COPY(p1, s.v); wl_set(wl, 1, s.v1);
     if (dot3(p1, dir) < 0) return false;
     cross3(dir, p0, p1);
@@ -626,7 +634,7 @@ __device__ __forceinline__ bool mpr_penetration_wl(const CObj& o1, const CObj& o
       return true;
     }
     normalize3(dir);
-    mink_support<HF>(o1, o2, dir, s);
+    mink_support<HF>(o1, o2, dir, s, T);
     V3COPY(p2, s.v); wl_set(wl, 2, s.v1);
     if (dot3(p2, dir) < 0) return false;
 #pragma unroll
@@ -636,7 +644,7 @@ __device__ __forceinline__ bool mpr_penetration_wl(const CObj& o1, const CObj& o
     if (dot3(dir, p0) > 0) { V3SWAP(p1, p2); wl_swap(wl, 1, 2); dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2]; }
     for (int it = 0;; it++) {
       if (it > maxit) return false;
-      mink_support<HF>(o1, o2, dir, s);
+      mink_support<HF>(o1, o2, dir, s, T);
       V3COPY(p3, s.v); wl_set(wl, 3, s.v1);
       if (dot3(p3, dir) < 0) return false;
       bool cont = false;
@@ -655,7 +663,7 @@ __device__ __forceinline__ bool mpr_penetration_wl(const CObj& o1, const CObj& o
   }
 #define PORTAL_DIR() { float a_[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, b_[3] = {p3[0] - p1[0], p3[1] - p1[1], p3[2] - p1[2]}; cross3(dir, a_, b_); normalize3(dir); }
 #define EXPAND_PORTAL() { \
-    float va_[3]; cross3(va_, s.v, p0); \
+    P0LOAD(); float va_[3]; cross3(va_, s.v, p0); \
     const int idx_ = dot3(p1, va_) > 0 ? (dot3(p2, va_) > 0 ? 1 : 3) : (dot3(p3, va_) > 0 ? 2 : 1); \
     _Pragma("unroll") for (int k = 0; k < 3; k++) { p1[k] = idx_ == 1 ? s.v[k] : p1[k]; p2[k] = idx_ == 2 ? s.v[k] : p2[k]; p3[k] = idx_ == 3 ? s.v[k] : p3[k]; } \
     wl_set(wl, idx_, s.v1); }
@@ -663,7 +671,7 @@ __device__ __forceinline__ bool mpr_penetration_wl(const CObj& o1, const CObj& o
     if (it > maxit) return false;
     PORTAL_DIR();
     if (dot3(dir, p1) >= 0) break;
-    mink_support<HF>(o1, o2, dir, s);
+    mink_support<HF>(o1, o2, dir, s, T);
     float dv4 = dot3(s.v, dir);
     float dmin = fminf(fminf(dv4 - dot3(p1, dir), dv4 - dot3(p2, dir)), dv4 - dot3(p3, dir));
     if (dv4 < 0 || dmin <= tol) return false;
@@ -671,7 +679,7 @@ __device__ __forceinline__ bool mpr_penetration_wl(const CObj& o1, const CObj& o
   }
   for (int it = 0;; it++) {
     PORTAL_DIR();
-    mink_support<HF>(o1, o2, dir, s);
+    mink_support<HF>(o1, o2, dir, s, T);
     float dv4 = dot3(s.v, dir);
     float dmin = fminf(fminf(dv4 - dot3(p1, dir), dv4 - dot3(p2, dir)), dv4 - dot3(p3, dir));
     if (dmin <= tol || it > maxit) { if (nsup) *nsup = it; break; }
@@ -680,6 +688,7 @@ __device__ __forceinline__ bool mpr_penetration_wl(const CObj& o1, const CObj& o
 #undef PORTAL_DIR
 #undef EXPAND_PORTAL
   *depth = dot3(s.v, dir);
+  P0LOAD();
   float bw[4], cr[3];
   cross3(cr, p1, p2); bw[0] = dot3(cr, p3);
   cross3(cr, p3, p2); bw[1] = dot3(cr, p0);
@@ -702,6 +711,7 @@ __device__ __forceinline__ bool mpr_penetration_wl(const CObj& o1, const CObj& o
   }
   return true;
 }
+#undef P0LOAD
 #undef V3SWAP
 #undef V3COPY
 

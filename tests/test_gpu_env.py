@@ -304,7 +304,7 @@ def test_bench_two_rank_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 1024 and d["steps"] == 10 and d["warmup"] == 3 and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["value"] - 1024 * 10 / (d["ms_per_step"] * 10 / 1e3)) < 1e-6 * d["value"]
-    assert d["roofline"]["kernel"].startswith("step_kernel_w<24,8,32,1,4," + ("true" if os.environ.get("MYO_SCHED") == "1" else "false")) and "cpu_baseline" not in d and "rehearsal" in d
+    assert d["roofline"]["kernel"].startswith("step_kernel_w<24,8,32,1,4,false") and "cpu_baseline" not in d and "rehearsal" in d
     assert d["allgather_ms_rank0"] > 0 and d["allgather_bytes_out"] == 1024 * 108 * 4          # gather time reported separately
 
 
