@@ -26,8 +26,11 @@ FP32_PEAK_TFLOPS = 157.3
 N_SIMD = 256 * 4        # MI355X_MICROARCH.md: 256 CUs, 4 SIMDs each
 CLOCK_HZ = 2.4e9        # max engine clock
 VALU_CYCLES = 2.0       # MI355X_MICROARCH.md: a wave64 v_fma_f32 issues over 2 cycles on a SIMD-32 (4 for one wave alone)
-PMC_FILE = "profiles/r2_pmc_step_kernel_hand.json"      # committed rocprofv3 counters of the headline kernel (tools/prof_all.sh)
+# committed rocprofv3 counters of the step kernel per (env, envs per GPU) (tools/prof_all.sh): HBM traffic and VALU instruction counts
+PMC_FILES = {("myoHandPoseRandom-v0", 4096): "profiles/r3_pmc_step_kernel_hand.json", ("myoHandPoseRandom-v0", 32768): "profiles/r3_pmc_step_kernel_hand_B32768.json",
+             ("myoLegWalk-v0", 4096): "profiles/r3_pmc_step_kernel_legs.json", ("MyoHandAirplaneRandom-v0", 4096): "profiles/r3_pmc_step_kernel_trackenv.json"}
 FLOP_FILE = "profiles/r2_flops_oracle.json"             # committed flop count of the oracle's instrumented build (tools/count_flops.py)
+TRACK_ALIAS = "MyoDM-TrackEnv"                          # round-2 spelling of the MyoDM TrackEnv extra measurement = MyoHandAirplaneRandom-v0
 
 
 def flops_per_env_step(env_id):
@@ -93,32 +96,6 @@ def rollout_multi(torch, env, nsteps, mode, stream, obs, staging, gather_async):
     return e0.elapsed_time(e1), kms
 
 
-def track_bench(args):
-    """Extra measurement (not the BASELINE headline): the MJX flavour's own env, MyoDM TrackEnv (mjx/myodm_v0.py) with its module-level
-    default reference, `--batch` envs, 5 substeps per env step, U(-1,1) actions; reward / done computed on the device each step."""
-    import torch
-    from myosuite_mjx_amd import capi
-    from myosuite_mjx_amd.track import TrackEnv
-    B = args.batch
-    env = TrackEnv(num_envs=B, seed=0, autoreset=True)
-    env.reset()
-    g = torch.Generator(device="cuda").manual_seed(0)
-    acts = [torch.rand((B, env.act_dim), device="cuda", generator=g) * 2 - 1 for _ in range(8)]
-    for i in range(args.warmup):
-        env.step(acts[i % 8])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        env.step(acts[i % 8])
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    print(json.dumps({"metric": f"env-steps/s MyoDM TrackEnv (myohand_object.xml + airplane) batch {B}", "value": B * args.steps / el, "unit": "env-steps/s",
-                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
-                      "dtype": "f32", "data": "synthetic", "vs_baseline": None,
-                      "config": {"workload": f"TrackEnv default RANDOM reference, {B} envs, n_frames=5 (dt=0.01), U(-1,1) actions, reward/done in torch on the device, auto-reset on done"},
-                      "kernel": env.batch.last_kernel_name(), "flagged_envs": int((env.status() != 0).sum())}))
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,13 +106,12 @@ def main():
     ap.add_argument("--repeats", type=int, default=1, help="repeat the timed region R times and report the median run (SURVEY 8d config 2: 5); default 1 = the plain contract")
     ap.add_argument("--env", default=ENV_ID, help="env id (default: the BASELINE.json headline workload); other ids are extra measurements")
     args = ap.parse_args()
-    env_id = args.env
-    if env_id == "MyoDM-TrackEnv":
-        return track_bench(args)
+    env_id = "MyoHandAirplaneRandom-v0" if args.env == TRACK_ALIAS else args.env
 
     import torch
     from myosuite_mjx_amd import capi
-    from myosuite_mjx_amd.envs import BatchedMyoEnv
+    from myosuite_mjx_amd.envs import REGISTRY, make
+    is_track = REGISTRY.get(env_id, {}).get("task") == "track"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -157,7 +133,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP stepper has no CPU fallback")
     torch.cuda.set_device(local)
     B = args.batch
-    env = BatchedMyoEnv(env_id, num_envs=B, device=local, seed=0, env_offset=rank * B)
+    if is_track:   # MyoDM TrackEnv (mjx/myodm_v0.py): the whole env step, reward / done / masked reset included, is one launch of the step kernel
+        env = make(env_id, num_envs=B, device=local, seed=0, autoreset=True)
+        env.batch.set_env_offset(rank * B)
+    else:
+        env = make(env_id, num_envs=B, device=local, seed=0, env_offset=rank * B)
     env.reset(seed=0)
     stream = torch.cuda.current_stream(local).cuda_stream
     mode = capi.BENCH_OBS | capi.BENCH_FRESH_ACTIONS | capi.BENCH_AUTORESET
@@ -214,12 +194,12 @@ def main():
     # the committed rocprofv3 measurement of the same kernel / batch (profiles/, separate FETCH_SIZE / WRITE_SIZE passes)
     traffic = None
     valu_insts = None
+    PMC_FILE = PMC_FILES.get((env_id, B))
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
             pmc = json.load(f)
-        if B == B_PER_GPU and env_id == ENV_ID:
-            traffic = pmc["traffic"]["hbm_bytes_per_launch_raw"]
-            valu_insts = pmc["counters"]["SQ_INSTS_VALU"]["mean_per_launch"]
+        traffic = pmc["traffic"]["hbm_bytes_per_launch_raw"]
+        valu_insts = pmc["counters"]["SQ_INSTS_VALU"]["mean_per_launch"]
     except Exception:
         pass
     # measured VALU issue peak of THIS chip at the step kernel's occupancy (4 waves per SIMD): a 20 ms v_fma_f32 probe after the timed region
@@ -249,7 +229,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{env_id}, {B} envs per GPU, frame_skip={env.frame_skip} (dt={env.dt:g}), U(-1,1) device-generated actions, "
-                                   f"obs+reward+TimeLimit({env.max_episode_steps})/done auto-reset inside the timed region"
+                                   + ("reference lookup + obs + reward + done + masked reset fused into the step launch (MYO_TASK_TRACK)" if is_track else
+                                      f"obs+reward+TimeLimit({env.max_episode_steps})/done auto-reset inside the timed region"
+                                      + (f"; {args.warmup + args.steps} env steps from reset: " + ("a TimeLimit reset of every env falls inside the timed region"
+                                          if args.warmup < env.max_episode_steps <= args.warmup + args.steps else "NO TimeLimit reset inside the timed region (done-resets only)")))
                                    + (", RCCL obs all-gather per step (overlapped with the next step)" if world > 1 else ""),
                        "global_batch": world * B, "parallelism": f"env-shard x{world}", "lanes_per_env": 64,
                        "substeps_per_s": value * env.frame_skip},

@@ -70,6 +70,7 @@ typedef enum myo_field {
   MYO_F_LINKX,       /* [B][12*nlink] world frame (pos 3 + rotation 9, row-major) of every kinematic link as the LAST substep's position stage
                         computed it, i.e. at the state before that substep's integration: what an MJX pipeline_state holds in xpos / xmat
                         after mjx.step (forward, then integrate; mjx/myodm_v0.py:201-232 reads it).  Models of the TrackEnv class only */
+  MYO_F_METRICS,     /* [B][4] reward terms of the track task: pose, object, bonus, penalty (mjx/myodm_v0.py:243-262 `rwd_dict`) */
   MYO_F_COUNT
 } myo_field;
 
@@ -81,13 +82,16 @@ enum {
   MYO_ACTMAP_NONE = 0,
   MYO_ACTMAP_MUSCLE_SIGMOID = 1,
   MYO_ACTMAP_SIGMOID_FATIGUE = 2,          /* + muscle condition "fatigue": 3CC-r model, envs/myo/fatigue.py:61-108, base_v0.py:100-104 */
-  MYO_ACTMAP_SIGMOID_REAFFERENTATION = 3   /* + EIP -> EPL tendon transfer, base_v0.py:105-109 (ids set with myo_batch_set_condition) */
+  MYO_ACTMAP_SIGMOID_REAFFERENTATION = 3,  /* + EIP -> EPL tendon transfer, base_v0.py:105-109 (ids set with myo_batch_set_condition) */
+  MYO_ACTMAP_CTRLRANGE = 4                 /* TrackEnv.step, mjx/myodm_v0.py:272-275: ctrl = (a + 1) (hi - lo) / 2 + lo over actuator_ctrlrange; with
+                                              MYO_TASK_TRACK configured this map also switches the task's fused prologue / epilogue on */
 };
 
 /* tasks understood by myo_obs / myo_reset */
 typedef enum myo_task { MYO_TASK_NONE = 0, MYO_TASK_POSE = 1, MYO_TASK_REACH = 2, MYO_TASK_WALK = 3,
                         MYO_TASK_STAND = 5, /* walk_v0.py:13-183 ReachEnvV0 (myoLegStandRandom-v0): reach with a site of the free root link; obs = qpos, qvel*dt,
                                                tip (3), target - tip (3), act; reward 10 - d - 10 |qvel dt| + bonus - 100 |act|/na - penalty */
+                        MYO_TASK_TRACK = 6, /* MyoDM TrackEnv (mjx/myodm_v0.py:14-304): see myo_track_config */
                         MYO_TASK_HOLD = 4 /* ObjHoldFixedEnvV0 (envs/myo/myobase/obj_hold_v0.py:13-118): the model's LAST joint is the free
                                              object; obs = hand qpos, hand qvel*dt, object position, goal - object, act; target = goal (3) */
 } myo_task;
@@ -136,6 +140,35 @@ typedef struct myo_walk_config {
   const float* init_qvel_alt;                                  /* host, nv floats or NULL */
   float reset_noise_std;                                       /* 0.02 in the reference */
 } myo_walk_config;
+/* MyoDM TrackEnv (mjx/myodm_v0.py:14-304; the env the reference runs on MJX), models of the TrackEnv class (myohand_object_*).  With this
+ * task configured, ONE myo_step(action, MYO_ACTMAP_CTRLRANGE, n_frames) is a whole env step:
+ *   ctrl = (action + 1) (hi - lo) / 2 + lo (:272-275); reference row looked up at the pre-step time + motion_start_time (:278-279,
+ *   mjx/reference_motion.py:7-313 == logger/reference_motion.py, its arithmetic kept: see `interpolation_linear`); n_frames substeps;
+ *   MYO_F_OBS = [qpos, qvel] (:297-304); MYO_F_REWARD / DONE / METRICS = compute_reward on the stepped state with the body frames of the last
+ *   substep's position stage (:185-267); with `autoreset`, envs that are done go back to init_qpos / zero velocity, activation, time and
+ *   their observation row is the first one of the new episode.
+ * myo_reset puts envs at init_qpos (TrackEnv.reset :152-173); myo_obs writes [qpos, qvel] without stepping. */
+typedef struct myo_track_config {
+  int n_frames;                            /* physics substeps per env step (5, :41-46) */
+  int ref_type;                            /* 0 FIXED (1 row), 1 RANDOM (2 rows: low / high), 2 TRACK (> 2 rows) (reference_motion.py:64-75) */
+  int horizon, robot_horizon, object_horizon, robot_dim, object_dim;
+  int motion_extrapolation;                /* hold the last frame beyond the motion's end */
+  int interpolation_linear;                /* 0: the reference's between-frame arithmetic, (1 - b) ** x[i] + b x[i+1] with b = t - T[i] / dt; 1: linear */
+  double motion_start_time;
+  const double *ref_time, *ref_robot, *ref_robot_vel /* or NULL */, *ref_object;   /* host; [horizon], [robot_horizon][robot_dim] x2, [object_horizon][object_dim] */
+  const float* init_qpos;                  /* host, nq */
+  const float *ctrl_lo, *ctrl_hi;          /* host, nu: actuator_ctrlrange */
+  int object_link, wrist_link;             /* kinematic links carrying the object body and the wrist (lunate) body */
+  float object_ipos[3], object_imat[9], wrist_ipos[3];   /* the bodies' inertial frames (xipos / ximat) inside those links */
+  float lift_z;                            /* object height that earns the lift bonus (:137-139) */
+  float obj_err_scale, base_err_scale, lift_bonus_mag, qpos_reward_weight, qpos_err_scale, qvel_reward_weight, qvel_err_scale;   /* :104-128 */
+  float obj_fail_thresh, base_fail_thresh, qpos_fail_thresh;
+  int terminate_obj_fail, terminate_pose_fail;
+  float w_pose, w_object, w_bonus, w_penalty;   /* DEFAULT_RWD_KEYS_AND_WEIGHTS :16-21 */
+  int autoreset;
+  uint64_t seed;                           /* RANDOM references: draws keyed by (seed, global env id, env step) */
+} myo_track_config;
+
 typedef enum myo_terrain { MYO_TERRAIN_NONE = 0, MYO_TERRAIN_ROUGH = 1, MYO_TERRAIN_HILLY = 2, MYO_TERRAIN_STAIRS = 3 } myo_terrain;
 
 const char* myo_last_error(void);
@@ -152,6 +185,7 @@ void myo_batch_free(myo_batch*);
 int myo_batch_size(const myo_batch*);
 int myo_batch_configure(myo_batch*, const myo_task_config* cfg);
 int myo_batch_configure_walk(myo_batch*, const myo_walk_config* cfg);
+int myo_batch_configure_track(myo_batch*, const myo_track_config* cfg);
 /* muscle conditions (envs/myo/base_v0.py:61-80): time step of the fatigue model (frame_skip * timestep) and the actuator ids of
  * the EIP -> EPL tendon transfer (-1: none).  Sarcopenia is a model edit (peak force of gainprm halved) made before myo_model_load. */
 int myo_batch_set_condition(myo_batch*, int frame_skip, int epl_actuator, int eip_actuator);

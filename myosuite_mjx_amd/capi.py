@@ -14,13 +14,14 @@ SRC_PATH = os.path.join(_HERE, "csrc", "myo_hip.hip")
 
 # field ids (myo_field)
 (F_QPOS, F_QVEL, F_ACT, F_CTRL, F_WARMSTART, F_TIME, F_TARGET, F_OBS, F_REWARD, F_DONE, F_SOLVED, F_FLAGS, F_DIAG,
- F_QACC, F_TENLEN, F_ACTFORCE, F_SITEXPOS, F_ELAPSED, F_ACTION, F_FATIGUE, F_HFIELD, F_GEOMSIZE, F_LINKX) = range(23)
+ F_QACC, F_TENLEN, F_ACTFORCE, F_SITEXPOS, F_ELAPSED, F_ACTION, F_FATIGUE, F_HFIELD, F_GEOMSIZE, F_LINKX, F_METRICS) = range(24)
 INT_FIELDS = (F_FLAGS, F_DIAG, F_ELAPSED)
 BENCH_OBS, BENCH_FRESH_ACTIONS, BENCH_AUTORESET = 1, 2, 4
-ACTMAP_NONE, ACTMAP_MUSCLE_SIGMOID, ACTMAP_SIGMOID_FATIGUE, ACTMAP_SIGMOID_REAFFERENTATION = 0, 1, 2, 3
+ACTMAP_NONE, ACTMAP_MUSCLE_SIGMOID, ACTMAP_SIGMOID_FATIGUE, ACTMAP_SIGMOID_REAFFERENTATION, ACTMAP_CTRLRANGE = 0, 1, 2, 3, 4
 TASK_NONE, TASK_POSE, TASK_REACH = 0, 1, 2
 TASK_HOLD = 4
 TASK_STAND = 5
+TASK_TRACK = 6
 FLAG_BAD_STATE, FLAG_BAD_QACC, FLAG_CONTACT_OVERFLOW, FLAG_CAND_OVERFLOW = 1, 2, 4, 8
 
 
@@ -54,6 +55,24 @@ class WalkConfig(C.Structure):
 
 
 TERRAIN_NONE, TERRAIN_ROUGH, TERRAIN_HILLY, TERRAIN_STAIRS = 0, 1, 2, 3
+
+
+class TrackConfig(C.Structure):
+    """ctypes mirror of `myo_track_config` (include/myo_hip.h)."""
+    _fields_ = [("n_frames", C.c_int), ("ref_type", C.c_int), ("horizon", C.c_int), ("robot_horizon", C.c_int), ("object_horizon", C.c_int),
+                ("robot_dim", C.c_int), ("object_dim", C.c_int), ("motion_extrapolation", C.c_int), ("interpolation_linear", C.c_int),
+                ("motion_start_time", C.c_double),
+                ("ref_time", C.POINTER(C.c_double)), ("ref_robot", C.POINTER(C.c_double)), ("ref_robot_vel", C.POINTER(C.c_double)),
+                ("ref_object", C.POINTER(C.c_double)),
+                ("init_qpos", C.POINTER(C.c_float)), ("ctrl_lo", C.POINTER(C.c_float)), ("ctrl_hi", C.POINTER(C.c_float)),
+                ("object_link", C.c_int), ("wrist_link", C.c_int),
+                ("object_ipos", C.c_float * 3), ("object_imat", C.c_float * 9), ("wrist_ipos", C.c_float * 3),
+                ("lift_z", C.c_float), ("obj_err_scale", C.c_float), ("base_err_scale", C.c_float), ("lift_bonus_mag", C.c_float),
+                ("qpos_reward_weight", C.c_float), ("qpos_err_scale", C.c_float), ("qvel_reward_weight", C.c_float), ("qvel_err_scale", C.c_float),
+                ("obj_fail_thresh", C.c_float), ("base_fail_thresh", C.c_float), ("qpos_fail_thresh", C.c_float),
+                ("terminate_obj_fail", C.c_int), ("terminate_pose_fail", C.c_int),
+                ("w_pose", C.c_float), ("w_object", C.c_float), ("w_bonus", C.c_float), ("w_penalty", C.c_float),
+                ("autoreset", C.c_int), ("seed", C.c_uint64)]
 
 
 # -mllvm -disable-machine-licm: the post-ISel loop-invariant code motion hoists constant materialisations (polynomial coefficients, masks) out
@@ -155,6 +174,7 @@ def lib():
         L.myo_set_balance.argtypes = [C.c_void_p, C.c_int]
         L.myo_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.myo_batch_configure_walk.argtypes = [C.c_void_p, C.POINTER(WalkConfig)]
+        L.myo_batch_configure_track.argtypes = [C.c_void_p, C.POINTER(TrackConfig)]
         L.myo_obs_reset_only.argtypes = [C.c_void_p, C.c_void_p]
         L.myo_batch_set_condition.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.myo_batch_set_fatigue_reset.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -262,6 +282,42 @@ class HipBatch:
         c.init_qvel_alt = iv2.ctypes.data_as(C.POINTER(C.c_float)) if iv2 is not None else None
         c.reset_noise_std = float(reset_noise_std)
         _chk(lib().myo_batch_configure_walk(self.h, C.byref(c)))
+
+    def configure_track(self, *, n_frames, reference, ref_type, init_qpos, ctrl_range, object_link, wrist_link, object_ipos, object_imat, wrist_ipos,
+                        lift_z, motion_start_time=0.0, motion_extrapolation=True, interpolation_linear=False, terminate_obj_fail=True,
+                        terminate_pose_fail=False, weights=(0.0, 1.0, 1.0, -2.0), autoreset=False, seed=0,
+                        obj_err_scale=50.0, base_err_scale=40.0, lift_bonus_mag=1.0, qpos_reward_weight=0.35, qpos_err_scale=5.0,
+                        qvel_reward_weight=0.05, qvel_err_scale=0.1, obj_fail_thresh=0.25, base_fail_thresh=0.25, qpos_fail_thresh=0.75):
+        """MyoDM TrackEnv as a fused task of the step kernel (myo_track_config).  reference = dict(time [H], robot [Hr, nr], robot_vel | None,
+        object [Ho, no]) in float64 (the reference's own arrays); ref_type 0 FIXED / 1 RANDOM / 2 TRACK; weights = (pose, object, bonus, penalty)."""
+        f64 = lambda a: np.ascontiguousarray(a, np.float64)
+        pd = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        pf = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        T, Rb, Ob = f64(reference["time"]), f64(reference["robot"]), f64(reference["object"])
+        Rv = f64(reference["robot_vel"]) if reference.get("robot_vel") is not None else None
+        c = TrackConfig()
+        c.n_frames, c.ref_type = int(n_frames), int(ref_type)
+        c.horizon, c.robot_horizon, c.object_horizon = max(Rb.shape[0], Ob.shape[0]), Rb.shape[0], Ob.shape[0]
+        assert T.shape[0] >= c.horizon or ref_type != 2, "reference time axis shorter than the motion"
+        c.robot_dim, c.object_dim = Rb.shape[1], Ob.shape[1]
+        c.motion_extrapolation, c.interpolation_linear, c.motion_start_time = int(motion_extrapolation), int(interpolation_linear), float(motion_start_time)
+        c.ref_time, c.ref_robot, c.ref_object = pd(T), pd(Rb), pd(Ob)
+        c.ref_robot_vel = pd(Rv) if Rv is not None else None
+        iq = np.ascontiguousarray(init_qpos, np.float32)
+        cr = np.asarray(ctrl_range, np.float64)
+        lo, hi = np.ascontiguousarray(cr[:, 0], np.float32), np.ascontiguousarray(cr[:, 1], np.float32)
+        c.init_qpos, c.ctrl_lo, c.ctrl_hi = pf(iq), pf(lo), pf(hi)
+        c.object_link, c.wrist_link = int(object_link), int(wrist_link)
+        c.object_ipos = (C.c_float * 3)(*[float(x) for x in object_ipos])
+        c.object_imat = (C.c_float * 9)(*[float(x) for x in np.asarray(object_imat).ravel()])
+        c.wrist_ipos = (C.c_float * 3)(*[float(x) for x in wrist_ipos])
+        c.lift_z, c.obj_err_scale, c.base_err_scale, c.lift_bonus_mag = float(lift_z), float(obj_err_scale), float(base_err_scale), float(lift_bonus_mag)
+        c.qpos_reward_weight, c.qpos_err_scale, c.qvel_reward_weight, c.qvel_err_scale = float(qpos_reward_weight), float(qpos_err_scale), float(qvel_reward_weight), float(qvel_err_scale)
+        c.obj_fail_thresh, c.base_fail_thresh, c.qpos_fail_thresh = float(obj_fail_thresh), float(base_fail_thresh), float(qpos_fail_thresh)
+        c.terminate_obj_fail, c.terminate_pose_fail = int(terminate_obj_fail), int(terminate_pose_fail)
+        c.w_pose, c.w_object, c.w_bonus, c.w_penalty = [float(x) for x in weights]
+        c.autoreset, c.seed = int(autoreset), int(seed)
+        _chk(lib().myo_batch_configure_track(self.h, C.byref(c)))
 
     def set_condition(self, frame_skip, epl_actuator=-1, eip_actuator=-1):
         _chk(lib().myo_batch_set_condition(self.h, int(frame_skip), int(epl_actuator), int(eip_actuator)))

@@ -85,6 +85,37 @@ struct DevModel {
   Lay lay;
 };
 
+// counter-based RNG (splitmix64 of (seed, stream, counter)) -> U[0,1)
+__device__ __host__ inline float u01(uint64_t seed, uint64_t a, uint64_t b) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (a + 1) + 0xBF58476D1CE4E5B9ull * (b + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// MyoDM TrackEnv as a task of the TRK step kernel (mjx/myodm_v0.py:185-304; myo_batch_configure_track): action scaling onto the
+// actuator control ranges and the reference lookup in the kernel's prologue, observation / reward / done / metrics / masked reset in its
+// epilogue.  The reference tables are float64 like the reference's own arrays (the lookup compares rounded times for equality).
+struct DevTrack {
+  int ref_type;                         // 0 FIXED (one row), 1 RANDOM (two rows: low / high), 2 TRACK (a motion)
+  int horizon, robot_horizon, object_horizon, robot_dim, object_dim, has_vel;
+  int extrapolate, linear;              // motion_extrapolation; interpolation "linear" instead of the reference's arithmetic
+  int autoreset, term_obj, term_pose;
+  double start_time;
+  const double *T, *robot, *robot_vel, *object;
+  const float *init_qpos, *lo, *hi;     // [nq] reset pose; [nu] actuator_ctrlrange
+  int obj_link, wrist_link;             // links carrying the object body and the wrist (lunate) body
+  float obj_p[3], obj_R[9], wrist_p[3]; // xipos / ximat of those bodies inside their link frames
+  float lift_z, obj_err_scale, base_err_scale, lift_bonus_mag, qpos_w, qpos_err_scale, qvel_w, qvel_err_scale;
+  float obj_fail2, base_fail2, qpos_fail;   // squared thresholds (:236-241 squares the already-unsquared errors once more)
+  float w_pose, w_object, w_bonus, w_penalty;
+  float* ref;                           // [B][ref_pitch] robot | robot_vel | object rows of the current env step (prologue -> epilogue)
+  int ref_pitch;
+  float* metrics;                       // [B][4] pose, object, bonus, penalty
+  uint64_t seed;                        // RANDOM references: counter RNG keyed by (seed, global env id, env step)
+};
+
 // per-batch device pointers (env-major, pitch = row length)
 struct DevBatch {
   int B;
@@ -103,6 +134,8 @@ struct DevBatch {
   int* ovf_cand;           // [B][NCANDX]
   int ovf_row;             // floats per overflow row (0: no overflow storage, the LDS table is the capacity)
   float* linkx;            // [B][12 * nl] link frames of the last substep's position stage (TRK models; NULL otherwise)
+  const DevTrack* track;   // MYO_TASK_TRACK configured (TRK models): prologue / epilogue of the step kernel; NULL otherwise
+  int env_offset;          // global id of env 0 (RNG streams are keyed by global env id)
 };
 #define NCX 48      // overflow contact rows ALLOCATED per env; a kernel with NC LDS slots uses 64 - NC of them: 64 contacts in all, one per lane
 #define NCANDX 256  // overflow candidates per env (MyoHand has 289 pairs: NCAND + NCANDX covers every pair)

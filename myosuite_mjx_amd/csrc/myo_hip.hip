@@ -3,6 +3,7 @@
 // One translation unit, split over csrc/ for readability:
 //   myo_common.h        limits, device-side structs (model tables, per-env batch arrays, task records), vector math
 //   myo_physics.h       tendon wrapping, muscle model, action map (+ muscle conditions), impedance, contact frames, MPR
+//   myo_task_track.h    MyoDM TrackEnv as a fused task of the TRK step kernel: reference lookup, reward / done, masked reset
 //   myo_kernel_lanes.h  step_kernel<G>: the first kernel, G = 16 / 32 / 64 lanes per env, all state in LDS (cross-check / fallback)
 //   myo_kernel_wave.h   step_kernel_w: one env per 64-lane wavefront (default), substep scheduler, size-specialised instantiations
 //   myo_kernels_aux.h   RNG, placement hint, random actions, policy inference, reset, observation kernels
@@ -18,6 +19,7 @@
 // collision -> limit / equality / contact rows -> Newton solver -> semi-implicit Euler with implicit joint damping.
 #include "myo_common.h"
 #include "myo_physics.h"
+#include "myo_task_track.h"
 #include "myo_kernel_lanes.h"
 #include "myo_kernel_wave.h"
 #include "myo_kernels_aux.h"
@@ -70,6 +72,9 @@ struct myo_batch {
   float *d_init2 = nullptr, *d_initv2 = nullptr, *d_fatvec = nullptr;   // walk reset "random": second keyframe; fatigue reset vector
   const char* last_kernel = "step_kernel";   // name of the step-kernel instantiation of the last myo_step / bench launch
   DevWalk* d_walk = nullptr;
+  DevTrack* d_track = nullptr;    // MYO_TASK_TRACK: device copy of the task record (tables hang off it)
+  float* d_metrics = nullptr;     // [B][4]
+  int track_frames = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   uint64_t bench_step = 0;
   long long* d_stamps = nullptr;
@@ -385,7 +390,7 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   BA(b->d_action, (size_t)B * nu)
   BA(d.fatigue, (size_t)B * 3 * nu)
   d.hfield = nullptr; d.gsize = nullptr; d.gsize_cg = -1;
-  d.ovf = nullptr; d.ovf_cand = nullptr; d.ovf_row = 0; d.linkx = nullptr;
+  d.ovf = nullptr; d.ovf_cand = nullptr; d.ovf_row = 0; d.linkx = nullptr; d.track = nullptr; d.env_offset = 0;
   if (m->trk) { BA(d.linkx, (size_t)B * 12 * m->dm.nl) }
   if (m->wave_ok) {   // contact-table overflow rows of the wave kernel (instantiations <24,8,...> and <36,20,...>)
     const int kc = m->wave_cfg == 0 ? 8 : 20, nj = m->trk ? 4 : 3;
@@ -552,6 +557,66 @@ int myo_batch_configure_walk(myo_batch* b, const myo_walk_config* c) {
   return MYO_OK;
 }
 
+int myo_batch_configure_track(myo_batch* b, const myo_track_config* c) {
+  if (!b || !c) return fail(MYO_E_ARG, "myo_batch_configure_track: null");
+  const myo_model* m = b->model;
+  if (!(m->wave_ok && m->trk)) return fail(MYO_E_UNSUPPORTED, "track task: models of the TrackEnv class only (condim-4 / friction-loss / hull geoms)");
+  const int nq = m->nq, nv = m->dm.nv, nu = m->dm.nu;
+  if (c->n_frames <= 0 || c->ref_type < 0 || c->ref_type > 2 || c->horizon < 1 || c->robot_dim < 0 || c->object_dim < 0 || c->robot_dim > 64 ||
+      c->robot_dim + c->object_dim > 64 || c->robot_dim > nq || !c->ref_time || !c->init_qpos || !c->ctrl_lo || !c->ctrl_hi)
+    return fail(MYO_E_ARG, "myo_batch_configure_track: bad reference / pose arguments");
+  if ((c->robot_dim > 0 && (!c->ref_robot || c->robot_horizon < 1)) || (c->object_dim > 0 && (!c->ref_object || c->object_horizon < 1)))
+    return fail(MYO_E_ARG, "myo_batch_configure_track: reference rows missing");
+  if (c->ref_type == 1 && ((c->robot_dim > 0 && c->robot_horizon < 2) || (c->object_dim > 0 && c->object_horizon < 2))) return fail(MYO_E_ARG, "RANDOM reference needs two rows");
+  if (c->object_link < 0 || c->object_link >= m->dm.nl || c->wrist_link < 0 || c->wrist_link >= m->dm.nl) return fail(MYO_E_ARG, "myo_batch_configure_track: link out of range");
+  if (nq + nv > b->obs_alloc) return fail(MYO_E_ARG, "obs_dim too large");
+  HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipDeviceSynchronize());
+  const int B = b->db.B;
+  DevTrack K{};
+  K.ref_type = c->ref_type; K.horizon = c->horizon; K.robot_horizon = c->robot_horizon; K.object_horizon = c->object_horizon;
+  K.robot_dim = c->robot_dim; K.object_dim = c->object_dim; K.has_vel = c->ref_robot_vel != nullptr;
+  K.extrapolate = c->motion_extrapolation; K.linear = c->interpolation_linear; K.autoreset = c->autoreset;
+  K.term_obj = c->terminate_obj_fail; K.term_pose = c->terminate_pose_fail; K.start_time = c->motion_start_time;
+  int rc;
+  auto up = [&](const void* src, size_t nbytes, const void** dst) -> int {
+    void* p = nullptr;
+    if ((rc = balloc(b, &p, nbytes ? nbytes : 8))) return rc;
+    if (nbytes) HIPCHK(hipMemcpy(p, src, nbytes, hipMemcpyHostToDevice));
+    *dst = p;
+    return 0;
+  };
+  if ((rc = up(c->ref_time, (size_t)c->horizon * 8, (const void**)&K.T))) return rc;
+  if ((rc = up(c->ref_robot, (size_t)c->robot_horizon * c->robot_dim * 8, (const void**)&K.robot))) return rc;
+  if (K.has_vel) { if ((rc = up(c->ref_robot_vel, (size_t)c->robot_horizon * c->robot_dim * 8, (const void**)&K.robot_vel))) return rc; } else K.robot_vel = nullptr;
+  if ((rc = up(c->ref_object, (size_t)c->object_horizon * c->object_dim * 8, (const void**)&K.object))) return rc;
+  if ((rc = up(c->init_qpos, (size_t)nq * 4, (const void**)&K.init_qpos)) || (rc = up(c->ctrl_lo, (size_t)nu * 4, (const void**)&K.lo)) ||
+      (rc = up(c->ctrl_hi, (size_t)nu * 4, (const void**)&K.hi))) return rc;
+  K.obj_link = c->object_link; K.wrist_link = c->wrist_link;
+  for (int k = 0; k < 3; k++) { K.obj_p[k] = c->object_ipos[k]; K.wrist_p[k] = c->wrist_ipos[k]; }
+  for (int k = 0; k < 9; k++) K.obj_R[k] = c->object_imat[k];
+  K.lift_z = c->lift_z; K.obj_err_scale = c->obj_err_scale; K.base_err_scale = c->base_err_scale; K.lift_bonus_mag = c->lift_bonus_mag;
+  K.qpos_w = c->qpos_reward_weight; K.qpos_err_scale = c->qpos_err_scale; K.qvel_w = c->qvel_reward_weight; K.qvel_err_scale = c->qvel_err_scale;
+  K.obj_fail2 = c->obj_fail_thresh * c->obj_fail_thresh; K.base_fail2 = c->base_fail_thresh * c->base_fail_thresh; K.qpos_fail = c->qpos_fail_thresh;
+  K.w_pose = c->w_pose; K.w_object = c->w_object; K.w_bonus = c->w_bonus; K.w_penalty = c->w_penalty;
+  K.ref_pitch = 2 * c->robot_dim + c->object_dim;
+  K.seed = c->seed;
+  { void* p = nullptr; if ((rc = balloc(b, &p, (size_t)B * K.ref_pitch * 4))) return rc; K.ref = (float*)p; }
+  if (!b->d_metrics) { void* p = nullptr; if ((rc = balloc(b, &p, (size_t)B * 4 * 4))) return rc; b->d_metrics = (float*)p; }
+  K.metrics = b->d_metrics;
+  if (!b->d_track) { void* p = nullptr; if ((rc = balloc(b, &p, sizeof(DevTrack)))) return rc; b->d_track = (DevTrack*)p; }
+  HIPCHK(hipMemcpy(b->d_track, &K, sizeof(DevTrack), hipMemcpyHostToDevice));
+  b->db.track = b->d_track;
+  b->track_frames = c->n_frames;
+  // the generic reset / observation plumbing: TrackEnv.reset puts every env at init_qpos with zero velocity, activation, control and time
+  TaskDev& T = b->task;
+  T = TaskDev{};
+  T.task = MYO_TASK_TRACK; T.frame_skip = c->n_frames; T.nq = nq; T.obs_dim = nq + nv;
+  HIPCHK(hipMemcpy(b->d_init, c->init_qpos, (size_t)nq * 4, hipMemcpyHostToDevice));
+  T.init_qpos = b->d_init; T.jnt_lo = b->d_jlo; T.jnt_hi = b->d_jhi; T.target_lo = b->d_tlo; T.target_hi = b->d_thi;
+  return MYO_OK;
+}
+
 static int field_info(myo_batch* b, int f, void** p, size_t* pitch, size_t* width) {
   const DevModel& dm = b->model->dm;
   DevBatch& d = b->db;
@@ -585,6 +650,9 @@ static int field_info(myo_batch* b, int f, void** p, size_t* pitch, size_t* widt
     case MYO_F_HFIELD:
       if (!d.hfield) return fail(MYO_E_ARG, "MYO_F_HFIELD: the model has no colliding height field");
       *p = d.hfield; *pitch = *width = b->model->dw.hf.nrow * b->model->dw.hf.ncol; break;
+    case MYO_F_METRICS:
+      if (!b->d_metrics) return fail(MYO_E_ARG, "MYO_F_METRICS: the track task is not configured (myo_batch_configure_track)");
+      *p = b->d_metrics; *pitch = *width = 4; break;
     case MYO_F_SITEXPOS: *p = d.sitexpos; *pitch = *width = b->task.ntip > 0 ? 3 * b->task.ntip : 1; break;
     default: return fail(MYO_E_ARG, "unknown field");
   }
@@ -645,6 +713,7 @@ int myo_autoreset(myo_batch* b, int max_episode_steps, uint64_t seed, void* stre
 int myo_set_env_offset(myo_batch* b, int env_offset) {
   if (!b) return fail(MYO_E_ARG, "null batch");
   b->env_offset = env_offset;
+  b->db.env_offset = env_offset;
   return MYO_OK;
 }
 
@@ -796,7 +865,7 @@ static int launch_obs(myo_batch* b, hipStream_t s, int obs_only = 0, int reset_o
   if (b->task.task == MYO_TASK_WALK) {
     // the walk observation lives in the step kernel: run it with zero substeps as an observation-only pass
     return launch_step(b, nullptr, MYO_ACTMAP_NONE, 0, s, KF_AUX | (obs_only ? KF_OBS_ONLY : 0) | (reset_only ? KF_RESET_ONLY : 0));
-  } else if (b->task.task == MYO_TASK_POSE || b->task.task == MYO_TASK_HOLD || b->task.task == MYO_TASK_STAND) {
+  } else if (b->task.task == MYO_TASK_POSE || b->task.task == MYO_TASK_HOLD || b->task.task == MYO_TASK_STAND || b->task.task == MYO_TASK_TRACK) {
     hipLaunchKernelGGL(obs_kernel, dim3(B), dim3(64), 0, s, m->dm, b->db, b->task, obs_only, reset_only);
   } else if (b->task.task == MYO_TASK_REACH) {
     const int EPW = 4;
@@ -900,10 +969,11 @@ int myo_bench_rollout(myo_batch* b, int steps, int nsubsteps, uint64_t seed, int
   for (int i = 0; i < steps; i++) {
     if (mode & MYO_BENCH_FRESH_ACTIONS) { rc = myo_random_action(b, b->d_action, seed, b->bench_step++, b->env_offset, stream); if (rc) return rc; }
     HIPCHK(hipEventRecord(b->kev[2 * (base + i)], s));       // brackets the dominant kernel (+ its tiny placement kernel) on its own stream
-    rc = launch_step(b, b->d_action, MYO_ACTMAP_MUSCLE_SIGMOID, nsubsteps, s);
+    rc = launch_step(b, b->d_action, b->task.task == MYO_TASK_TRACK ? MYO_ACTMAP_CTRLRANGE : MYO_ACTMAP_MUSCLE_SIGMOID, nsubsteps, s);
     if (rc) return rc;
     HIPCHK(hipEventRecord(b->kev[2 * (base + i) + 1], s));
     const int tk = b->task.task;
+    if (tk == MYO_TASK_TRACK) continue;   // observation, reward, done and the masked reset are the step kernel's own epilogue
     if ((mode & MYO_BENCH_OBS) && (mode & MYO_BENCH_AUTORESET) && max_episode_steps > 0 && (tk == MYO_TASK_POSE || tk == MYO_TASK_HOLD || tk == MYO_TASK_STAND)) {
       // state-only observations: observation + auto-reset + first observation of the new episodes in ONE launch (post_kernel)
       hipLaunchKernelGGL(post_kernel, dim3(b->db.B), dim3(64), 0, s, b->model->dm, b->db, b->task, b->model->nq, b->model->dm.qpos0, seed, b->env_offset, max_episode_steps);

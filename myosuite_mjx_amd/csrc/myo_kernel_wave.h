@@ -486,6 +486,9 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     E[Y.ctrl + i] = c;
   }
   float time = uniformf(ldstate<SCHED>(Bt.time + env));
+  // MYO_TASK_TRACK (TRK models): this launch is a whole TrackEnv.step -- reference row of the pre-step time now, reward / done / reset at the end
+  const bool track_on = TRK && Bt.track != nullptr && action != nullptr && actmap == MYO_ACTMAP_CTRLRANGE && nsub > 0;
+  if constexpr (TRK) { if (track_on) track_lookup(*Bt.track, env, env + Bt.env_offset, time, Bt.elapsed[env], lane_id); }
   int flags = 0, d_nefc = 0, d_ncon = 0, d_iter = 0, d_cost = 0;
   int f_cand = 0, f_mpr = 0, f_ncon = 0, f_iter = 0, f_itcon = 0, f_ls = 0, f_fact = 0;   // work features of this env step (placement cost model)
   if (SCHED && s0 > 0) {   // accumulators of the earlier substeps of this env step
@@ -2124,6 +2127,26 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     for (int i = lane_id; i < nu; i += 64) { E[Y.act + i] = 0; E[Y.ctrl + i] = 0; }
     time = 0;
   }
+  bool track_reset = false;
+  if constexpr (TRK) {
+    if (track_on) {   // epilogue of TrackEnv.step (mjx/myodm_v0.py:185-267, 297-304): reward / done / metrics on the stepped state, masked reset, observation
+      SYNC();
+      const DevTrack& K = *Bt.track;
+      const float done = uniformf(track_reward(K, Bt, env, lane_id, E + Y.qpos, E + Y.qvel, E + Y.lpos, E + Y.lmat, M.origin, [](float v) { return wave_sum(v); }));
+      if (K.autoreset && done > 0.f) {   // (wave-uniform) TrackEnv.reset of this env: init_qpos, zero velocity / activation / control / warm start / time
+        SYNC();
+        if (lane_id < nq) E[Y.qpos + lane_id] = K.init_qpos[lane_id];
+        if (lane_id < nv) { E[Y.qvel + lane_id] = 0.f; warm_row[lane_id] = 0.f; }
+        for (int i = lane_id; i < nu; i += 64) { E[Y.act + i] = 0.f; E[Y.ctrl + i] = 0.f; }
+        time = 0.f;
+        track_reset = true;
+      }
+      SYNC();
+      float* o = Bt.obs + (size_t)env * (nq + nv);
+      if (lane_id < nq) o[lane_id] = E[Y.qpos + lane_id];
+      if (lane_id < nv) o[nq + lane_id] = E[Y.qvel + lane_id];
+    }
+  }
   if (lane_id < nq) Bt.qpos[(size_t)env * nq + lane_id] = E[Y.qpos + lane_id];
   if (lane_id < nv) {
     Bt.qvel[(size_t)env * nv + lane_id] = E[Y.qvel + lane_id];
@@ -2140,7 +2163,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   }
   if (lane_id == 0) {
     Bt.time[env] = time;
-    if (s1 == nsubtot) Bt.elapsed[env] += 1;
+    if (s1 == nsubtot) Bt.elapsed[env] = track_reset ? 0 : Bt.elapsed[env] + 1;
     if (SCHED) { if (flags) atomicOr(&Bt.flags[env], flags); } else Bt.flags[env] |= flags;
     Bt.diag[(size_t)env * 8 + 0] = d_nefc; Bt.diag[(size_t)env * 8 + 1] = d_ncon; Bt.diag[(size_t)env * 8 + 2] = d_iter;
     // predicted work of this env's NEXT step for the placement hint, in units of 1024 single-wave cycles: linear model of this

@@ -3,16 +3,6 @@
 #ifndef MYO_KERNELS_AUX_H
 #define MYO_KERNELS_AUX_H
 
-// ------------------------------------------------------------------------------------------------
-// counter-based RNG (splitmix64 of (seed, stream, counter)) -> U[0,1)
-__device__ __host__ inline float u01(uint64_t seed, uint64_t a, uint64_t b) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (a + 1) + 0xBF58476D1CE4E5B9ull * (b + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
-
 // Placement hint for the wave-per-env kernel.  All B envs are co-resident (4 waves per SIMD), so a launch ends when the
 // slowest SIMD ends; envs differ ~2x in work (contacts, Newton iterations) and that work is strongly correlated from one
 // env step to the next.  Sort envs by last step's cost (counting sort, one workgroup) and deal them out so that the waves
@@ -267,6 +257,13 @@ __device__ __forceinline__ void obs_body(const DevModel& M, const DevBatch& Bt, 
       Bt.solved[e] = dist < T.near_th ? 1.f : 0.f;
       Bt.done[e] = pen;
     }
+  } else if (T.task == MYO_TASK_TRACK) {
+    // TrackEnv.get_obs (mjx/myodm_v0.py:297-304): [qpos, qvel]; reward / done belong to the step kernel's epilogue (they need the reference row
+    // of the step and the body frames of its last substep) and are not recomputed here
+    const int nq = T.nq;
+    const float* qq = Bt.qpos + (size_t)e * nq;
+    for (int i = lane; i < nq; i += 64) o[i] = qq[i];
+    for (int i = lane; i < nv; i += 64) o[nq + i] = v[i];
   } else if (T.task == MYO_TASK_HOLD) {
     // obj_hold_v0.py:66-118.  The object's site sits at the origin of its free body, whose world position is the free joint's qpos
     // (free-floating models are not origin-shifted); the goal site is world-fixed = the target row

@@ -243,6 +243,11 @@ __device__ __forceinline__ float action_map(const DevBatch& Bt, const float* __r
   if (actmap == MYO_ACTMAP_SIGMOID_REAFFERENTATION) { if (i == Bt.reaf_epl) src = Bt.reaf_eip; else if (i == Bt.reaf_eip) return 0.f; }
   float c = action[(size_t)env * nu + src];
   if (actmap == MYO_ACTMAP_NONE) return c;
+  if (actmap == MYO_ACTMAP_CTRLRANGE) {   // TrackEnv.step (mjx/myodm_v0.py:272-275): [-1, 1] onto actuator_ctrlrange, every actuator alike
+    const DevTrack* K = Bt.track;
+    const float t = (c + 1.0f) * (K->hi[i] - K->lo[i]) * 0.5f;   // (two statements: no fused multiply-add, the reference rounds the product first)
+    return t + K->lo[i];
+  }
   // stateless (non-muscle) actuators: untouched when the model has muscles (base_v0.py:87-93 only re-projects the muscle entries),
   // re-projected from [-1, 1] onto their ctrlrange when it has none (Robot.process_actuator, robot/robot.py:773-782); the lowering
   // stores the applicable scale / offset in the record

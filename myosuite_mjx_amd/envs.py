@@ -136,6 +136,25 @@ for _id in [k for k in list(REGISTRY) if k.startswith("myo")]:
     REGISTRY[_id[:3] + "Fati" + _id[3:]] = dict(REGISTRY[_id], muscle_condition="fatigue")
     if _id.startswith("myoHand"):
         REGISTRY[_id[:3] + "Reaf" + _id[3:]] = dict(REGISTRY[_id], muscle_condition="reafferentation")
+# MyoDM (envs/myo/myodm/__init__.py:565-700), served by the MJX flavour of the env (mjx/myodm_v0.py TrackEnv -> track.TrackEnv, one fused
+# launch per env step) for the objects that have a compiled asset: MyoHand<Object>Fixed-v0 (a one-row reference), MyoHand<Object>Random-v0 (the
+# two-row randomisation range, also mjx/myodm_v0.py's module-level default) and the motion-tracking ids, whose motion file is the reference's
+# data/<motion>.npz: pass `reference=<path or dict>` or point MYODM_DATA at a directory holding it (the files are not redistributed here).
+MYODM_OBJECTS = ("airplane", "cup")
+_DOF_ROBOT = 29
+for _obj in MYODM_OBJECTS:
+    REGISTRY[f"MyoHand{_obj.title()}Fixed-v0"] = dict(task="track", object=_obj, max_episode_steps=50, reference=dict(
+        time=np.array([0.0, 4.0]), robot=np.zeros((1, _DOF_ROBOT)), robot_vel=np.zeros((1, _DOF_ROBOT)),
+        object_init=np.array([-0.2, -0.2, 0.1, 1.0, 0.0, 0.0, 0.0]), object=np.array([[0.2, 0.2, 0.1, 1.0, 0.0, 0.0, 0.1]])))
+    REGISTRY[f"MyoHand{_obj.title()}Random-v0"] = dict(task="track", object=_obj, max_episode_steps=50, reference=dict(
+        time=np.array([0.0, 4.0]), robot=np.zeros((2, _DOF_ROBOT)), robot_vel=np.zeros((2, _DOF_ROBOT)),
+        object_init=np.array([0.0, 0.0, 0.1, 1.0, 0.0, 0.0, 0.0]),
+        object=np.array([[-0.2, -0.2, 0.1, 1.0, 0.0, 0.0, -1.0], [0.2, 0.2, 0.1, 1.0, 0.0, 0.0, 1.0]])))
+for _id, _obj, _motion in (("MyoHandAirplaneFly-v0", "airplane", "MyoHand_airplane_fly1.npz"), ("MyoHandAirplaneLift-v0", "airplane", "MyoHand_airplane_lift.npz"),
+                           ("MyoHandAirplanePass-v0", "airplane", "MyoHand_airplane_pass1.npz"), ("MyoHandCupDrink-v0", "cup", "MyoHand_cup_drink1.npz"),
+                           ("MyoHandCupPass-v0", "cup", "MyoHand_cup_pass1.npz"), ("MyoHandCupPour-v0", "cup", "MyoHand_cup_pour1.npz")):
+    REGISTRY[_id] = dict(task="track", object=_obj, max_episode_steps=75, motion=_motion)
+
 # registered by the reference but not runnable on the HIP path (DESIGN.md "out of scope")
 UNSUPPORTED = {
     # (nothing of the walk family: the terrain envs run on the height-field instantiation of the leg kernel)
@@ -380,6 +399,26 @@ class BatchedMyoEnv:
         return self.batch.status()
 
 
+def _make_track(env_id, num_envs, reference=None, **kw):
+    import os
+    from .track import TrackEnv
+    spec = REGISTRY[env_id]
+    if reference is None:
+        reference = spec.get("reference")
+    if reference is None:                      # a motion-tracking id: the reference's own motion file
+        roots = [os.environ.get("MYODM_DATA"), "/root/reference/myosuite/envs/myo/myodm/data"]
+        hits = [os.path.join(r, spec["motion"]) for r in roots if r and os.path.exists(os.path.join(r, spec["motion"]))]
+        if not hits:
+            raise FileNotFoundError(f"{env_id}: motion file {spec['motion']} not found; pass reference=<path or dict> or set MYODM_DATA to the "
+                                    "directory of the reference's envs/myo/myodm/data")
+        reference = hits[0]
+    env = TrackEnv(num_envs=num_envs, object_name=spec["object"], reference=reference, **kw)
+    env.id, env.max_episode_steps = env_id, spec["max_episode_steps"]
+    return env
+
+
 def make(env_id, num_envs=1, **kw):
-    """gym.make counterpart for the batched envs (envs/myo/myobase/__init__.py registers the same ids)."""
+    """gym.make counterpart for the batched envs (envs/myo/myobase/__init__.py and envs/myo/myodm/__init__.py register the same ids)."""
+    if env_id in REGISTRY and REGISTRY[env_id].get("task") == "track":
+        return _make_track(env_id, num_envs, **kw)
     return BatchedMyoEnv(env_id, num_envs=num_envs, **kw)

@@ -171,6 +171,47 @@ def reference_motion_fixture():
     return len(meta["cases"])
 
 
+def reference_motion_all_fixture():
+    """Every motion file of envs/myo/myodm/data (95): the reference's answers at five sampled times each -- two exact frames, two times between
+    frames (the operator-precedence / power arithmetic of logger/reference_motion.py:271-300) and one past the end (held) -- plus what its
+    RANDOM-type constructor makes of a reference WITHOUT robot_init / object_init (logger/reference_motion.py:88-93: scalar means; the mjx twin,
+    mjx/reference_motion.py:86-90, takes the robot mean over axis 0)."""
+    rm = _load("myosuite/logger/reference_motion.py", "ref_reference_motion")
+    data_dir = os.path.join(REF, "myosuite/envs/myo/myodm/data")
+    out, stems, rejected = {}, [], []
+    for path in sorted(os.listdir(data_dir)):
+        if not path.endswith(".npz"):
+            continue
+        stem = path[:-4]
+        d = {k: v for k, v in np.load(os.path.join(data_dir, path)).items()}
+        T = d["time"]
+        n = len(T)
+        i, j = n // 3, (2 * n) // 3
+        times = [float(T[i]), float(0.5 * (T[i] + T[i + 1])), float(T[j]), float(T[j] + 0.25 * (T[j + 1] - T[j])), float(T[-1] + 0.3)]
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                ref = rm.ReferenceMotion(dict(d), motion_extrapolation=True)
+                rows = [ref.get_reference(t) for t in times]              # (the heuristic index cache only ever moves forward: times ascend)
+        except AssertionError as e:                                       # files the reference's own check_format refuses (object_init of 6 entries)
+            rejected.append(stem)
+            continue
+        out[stem + "__times"] = np.asarray(times)
+        out[stem + "__robot"] = np.stack([np.asarray(r.robot, float) for r in rows])
+        out[stem + "__object"] = np.stack([np.asarray(r.object, float) for r in rows])
+        stems.append(stem)
+    rnd = dict(time=np.array([0.0, 4.0]), robot=np.linspace(-0.3, 0.5, 58).reshape(2, 29), robot_vel=np.zeros((2, 29)),
+               object=np.array([[-0.2, -0.2, 0.1, 1.0, 0.0, 0.0, -1.0], [0.2, 0.2, 0.1, 1.0, 0.0, 0.0, 1.0]]))
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = rm.ReferenceMotion({k: v.copy() for k, v in rnd.items()}, motion_extrapolation=True, random_generator=np.random.default_rng(1))
+        ri, oi = ref.get_init()
+    for k, v in rnd.items():
+        out["noinit__in__" + k] = v
+    out["noinit__robot_init_numpy_twin"], out["noinit__object_init"] = np.asarray(ri, float), np.asarray(oi, float)
+    out["stems"], out["rejected"] = np.array(stems), np.array(rejected)
+    np.savez_compressed(os.path.join(OUT, "ref_motion_all.npz"), **out)
+    return len(stems)
+
+
 # ------------------------------------------------------------------------------------------------ MyoHand model files: goldens + edit history
 HAND_ASSETS = "myosuite/simhive/myo_sim/hand/assets/myohand_assets.xml"
 HAND_BODY = "myosuite/simhive/myo_sim/hand/assets/myohand_body.xml"
@@ -281,4 +322,5 @@ if __name__ == "__main__":
     print("quat_math arrays:", quat_math_fixture())
     print("obsvec cases:", obsvec_fixture())
     print("reference-motion cases:", reference_motion_fixture())
+    print("reference-motion files:", reference_motion_all_fixture())
     print("hand model (former sites, sites, wrap geoms):", hand_model_fixture())

@@ -7,6 +7,7 @@ D=/tmp/one_kernel; mkdir -p $D; cd $D
 cat > k.hip <<EOT
 #include "/root/repo/myosuite_mjx_amd/csrc/myo_common.h"
 #include "/root/repo/myosuite_mjx_amd/csrc/myo_physics.h"
+#include "/root/repo/myosuite_mjx_amd/csrc/myo_task_track.h"
 #include "/root/repo/myosuite_mjx_amd/csrc/myo_kernel_wave.h"
 template __global__ void step_kernel_w<$ARGS>(const DevModel*, const DevModelW*, DevBatch, const float*, int, int, long long*, const int*, const DevWalk*, int, SchedDev);
 EOT
