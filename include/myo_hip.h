@@ -166,6 +166,8 @@ typedef struct myo_track_config {
   int terminate_obj_fail, terminate_pose_fail;
   float w_pose, w_object, w_bonus, w_penalty;   /* DEFAULT_RWD_KEYS_AND_WEIGHTS :16-21 */
   int autoreset;
+  int max_episode_steps;                   /* gym TimeLimit of the registered MyoDM ids (envs/myo/myodm/__init__.py:571,649; 0: none): MYO_F_SOLVED = 1 when the
+                                              episode is truncated by it (and not done); with `autoreset` such envs are reset as well */
   uint64_t seed;                           /* RANDOM references: draws keyed by (seed, global env id, env step) */
 } myo_track_config;
 

@@ -72,7 +72,7 @@ class TrackConfig(C.Structure):
                 ("obj_fail_thresh", C.c_float), ("base_fail_thresh", C.c_float), ("qpos_fail_thresh", C.c_float),
                 ("terminate_obj_fail", C.c_int), ("terminate_pose_fail", C.c_int),
                 ("w_pose", C.c_float), ("w_object", C.c_float), ("w_bonus", C.c_float), ("w_penalty", C.c_float),
-                ("autoreset", C.c_int), ("seed", C.c_uint64)]
+                ("autoreset", C.c_int), ("max_episode_steps", C.c_int), ("seed", C.c_uint64)]
 
 
 # -mllvm -disable-machine-licm: the post-ISel loop-invariant code motion hoists constant materialisations (polynomial coefficients, masks) out
@@ -285,7 +285,7 @@ class HipBatch:
 
     def configure_track(self, *, n_frames, reference, ref_type, init_qpos, ctrl_range, object_link, wrist_link, object_ipos, object_imat, wrist_ipos,
                         lift_z, motion_start_time=0.0, motion_extrapolation=True, interpolation_linear=False, terminate_obj_fail=True,
-                        terminate_pose_fail=False, weights=(0.0, 1.0, 1.0, -2.0), autoreset=False, seed=0,
+                        terminate_pose_fail=False, weights=(0.0, 1.0, 1.0, -2.0), autoreset=False, seed=0, max_episode_steps=0,
                         obj_err_scale=50.0, base_err_scale=40.0, lift_bonus_mag=1.0, qpos_reward_weight=0.35, qpos_err_scale=5.0,
                         qvel_reward_weight=0.05, qvel_err_scale=0.1, obj_fail_thresh=0.25, base_fail_thresh=0.25, qpos_fail_thresh=0.75):
         """MyoDM TrackEnv as a fused task of the step kernel (myo_track_config).  reference = dict(time [H], robot [Hr, nr], robot_vel | None,
@@ -316,7 +316,7 @@ class HipBatch:
         c.obj_fail_thresh, c.base_fail_thresh, c.qpos_fail_thresh = float(obj_fail_thresh), float(base_fail_thresh), float(qpos_fail_thresh)
         c.terminate_obj_fail, c.terminate_pose_fail = int(terminate_obj_fail), int(terminate_pose_fail)
         c.w_pose, c.w_object, c.w_bonus, c.w_penalty = [float(x) for x in weights]
-        c.autoreset, c.seed = int(autoreset), int(seed)
+        c.autoreset, c.max_episode_steps, c.seed = int(autoreset), int(max_episode_steps), int(seed)
         _chk(lib().myo_batch_configure_track(self.h, C.byref(c)))
 
     def set_condition(self, frame_skip, epl_actuator=-1, eip_actuator=-1):

@@ -102,6 +102,7 @@ struct DevTrack {
   int horizon, robot_horizon, object_horizon, robot_dim, object_dim, has_vel;
   int extrapolate, linear;              // motion_extrapolation; interpolation "linear" instead of the reference's arithmetic
   int autoreset, term_obj, term_pose;
+  int max_steps;                        // gym TimeLimit of the registered ids (0: none): truncation flag in the `solved` row, reset with autoreset
   double start_time;
   const double *T, *robot, *robot_vel, *object;
   const float *init_qpos, *lo, *hi;     // [nq] reset pose; [nu] actuator_ctrlrange

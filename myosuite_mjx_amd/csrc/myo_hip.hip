@@ -288,6 +288,72 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
           (rc = load_f(m, blob, "hip_mesh_rec", &w.mesh_rec)) || (rc = load_f(m, blob, "hip_mesh_startrec", &w.mesh_startrec)) || (rc = load_f(m, blob, "hip_mesh_aabb", &w.mesh_aabb))) { myo_model_free(m); return rc; }
       m->trk = tk[0] || tk[1] || tk[2];
     }
+    {  // self-contained per-lane records (DevModelW::seg_rec, dl_pk, ...): denormalised copies of the tables loaded above
+      auto BI = [&](const char* n) { std::vector<int> v; const BlobRec* r = blob_find(blob, n); if (r && r->dtype == 1) { v.resize(r->nbytes / 4); memcpy(v.data(), blob + r->offset, r->nbytes); } return v; };
+      auto BF = [&](const char* n) { std::vector<float> v; const BlobRec* r = blob_find(blob, n); if (r && r->dtype == 0) { v.resize(r->nbytes / 8); const double* sp = (const double*)(blob + r->offset); for (size_t i = 0; i < v.size(); i++) v[i] = (float)sp[i]; } return v; };
+      const std::vector<int> seg = BI("hip_seg"), seg_order = BI("hip_seg_order"), seg_tendon = BI("hip_seg_tendon"), site_link = BI("hip_site_link"), wg_link = BI("hip_wg_link"),
+                             dl = BI("hip_dl"), dof_type = BI("hip_dof_type");
+      const std::vector<float> seg_div = BF("hip_seg_div"), site_lpos = BF("hip_site_lpos"), wg_lpos = BF("hip_wg_lpos"), wg_lmat = BF("hip_wg_lmat"), wg_radius = BF("hip_wg_radius");
+      auto fi = [](int v) { float f; memcpy(&f, &v, 4); return f; };
+      std::vector<float> rec((size_t)std::max(d.nseg, 1) * SEGR * 4, 0.f);
+      for (int idx = 0; idx < d.nseg; idx++) {
+        const int si = seg_order[idx];
+        const int* S = &seg[12 * (size_t)si];
+        float* R = &rec[(size_t)idx * SEGR * 4];
+        for (int k = 0; k < 2; k++) { R[4 * k] = fi(site_link[S[k]]); for (int c = 0; c < 3; c++) R[4 * k + 1 + c] = site_lpos[3 * (size_t)S[k] + c]; }
+        R[8] = fi(S[2]); R[9] = fi(S[3] >= 0 ? site_link[S[3]] : -2); R[10] = 1.0f / seg_div[si]; R[11] = fi(seg_tendon[si]);
+        for (int k = 0; k < 3; k++) {
+          if (S[4 + 2 * k] >= (1 << 20) || S[5 + 2 * k] >= (1 << 11)) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "tendon moment-arm lists too long for the packed segment record"); }
+          R[12 + k] = fi(S[4 + 2 * k] | (S[5 + 2 * k] << 20));
+        }
+        R[15] = fi(S[10]);
+        if (S[2] >= 0) {
+          const int g = S[2];
+          if (S[3] >= 0) for (int c = 0; c < 3; c++) R[16 + c] = site_lpos[3 * (size_t)S[3] + c];
+          R[19] = wg_radius[g];
+          R[20] = fi(wg_link[g]); for (int c = 0; c < 3; c++) R[21 + c] = wg_lpos[3 * (size_t)g + c];
+          for (int c = 0; c < 9; c++) R[24 + c] = wg_lmat[9 * (size_t)g + c];
+        }
+      }
+      std::vector<int> dlp(std::max<size_t>(dl.size() / 3, 1), 0);
+      for (size_t i = 0; i < dl.size() / 3; i++) {
+        const int dd = dl[3 * i], sg = dl[3 * i + 1], slot = dl[3 * i + 2];
+        if (dd < 0 || dd > 127 || slot < 0 || slot > 255 || sg < -32768 || sg > 32767) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "moment-arm list entry does not fit the packed word"); }
+        dlp[i] = dd | ((dof_type[dd] == 3 ? 1 : 0) << 7) | (slot << 8) | (int)((unsigned)sg << 16);
+      }
+      const float* tf4 = nullptr; const int* ti4 = nullptr;
+      if ((rc = upload<float>(m, rec, &tf4)) || (rc = upload<int>(m, dlp, &ti4))) { myo_model_free(m); return rc; }
+      w.seg_rec = (decltype(w.seg_rec))tf4; w.dl_pk = (decltype(w.dl_pk))ti4;
+      // collision geoms, pairs and the pairs' dof lists
+      const std::vector<int> cg_link = BI("hip_cg_link"), cg_type = BI("hip_cg_type"), pair_i = BI("hip_pair_i"), pair_dl = BI("hip_pair_dl");
+      const std::vector<float> cg_lpos = BF("hip_cg_lpos"), cg_lmat = BF("hip_cg_lmat"), cg_size = BF("hip_cg_size"), cg_rb = BF("hip_cg_rbound"), pair_f = BF("hip_pair_f");
+      std::vector<float> grec((size_t)std::max(d.ncg, 1) * 16, 0.f), prec((size_t)std::max(d.npair, 1) * 16, 0.f);
+      for (int g = 0; g < d.ncg; g++) {
+        float* R = &grec[(size_t)g * 16];
+        R[0] = fi(cg_link[g]); for (int c = 0; c < 3; c++) R[1 + c] = cg_lpos[3 * (size_t)g + c];
+        for (int c = 0; c < 9; c++) R[4 + c] = cg_lmat[9 * (size_t)g + c];
+        R[13] = fi(cg_type[g]); R[14] = cg_rb[g];
+      }
+      for (int q = 0; q < d.npair; q++) {
+        const int* P = &pair_i[6 * (size_t)q];
+        const float* F = &pair_f[12 * (size_t)q];
+        if (P[0] > 255 || P[1] > 255 || P[3] > 255 || P[4] > 15 || P[5] > 15) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "collision pair does not fit the packed pair record"); }
+        float* R = &prec[(size_t)q * 16];
+        R[0] = fi(P[0] | (P[1] << 8) | (P[4] << 16) | (P[5] << 20) | (P[3] << 24)); R[1] = F[0]; R[2] = F[1]; R[3] = fi(P[2]);
+        for (int c = 0; c < 3; c++) { R[4 + c] = cg_size[3 * (size_t)P[0] + c]; R[8 + c] = cg_size[3 * (size_t)P[1] + c]; }
+        R[7] = cg_rb[P[0]]; R[11] = cg_rb[P[1]];
+        R[12] = fi(cg_type[P[0]] | (cg_type[P[1]] << 8));
+      }
+      std::vector<int> pdl(std::max<size_t>(pair_dl.size() / 2, 1), 0);
+      for (size_t i = 0; i < pair_dl.size() / 2; i++) {
+        const int dd = pair_dl[2 * i], sg = pair_dl[2 * i + 1];
+        if (dd < 0 || dd > 127 || sg < -(1 << 22) || sg > (1 << 22)) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "contact dof-list entry does not fit the packed word"); }
+        pdl[i] = dd | ((dof_type[dd] == 3 ? 1 : 0) << 7) | (int)((unsigned)sg << 8);
+      }
+      const float *tg4 = nullptr, *tp4 = nullptr; const int* tq4 = nullptr;
+      if ((rc = upload<float>(m, grec, &tg4)) || (rc = upload<float>(m, prec, &tp4)) || (rc = upload<int>(m, pdl, &tq4))) { myo_model_free(m); return rc; }
+      w.cg_rec = (decltype(w.cg_rec))tg4; w.pair_rec = (decltype(w.pair_rec))tp4; w.pair_dl_pk = (decltype(w.pair_dl_pk))tq4;
+    }
     const bool common = d.nl <= 64 && d.ncg <= 64 && w.nq <= 64 && w.neq <= 64 && d.maxnnz <= 20;
     const bool needs_full = w.has_free || w.neq > 0 || plane_pairs || condim1 || m->trk;
     if (m->trk) {
@@ -577,7 +643,7 @@ int myo_batch_configure_track(myo_batch* b, const myo_track_config* c) {
   K.ref_type = c->ref_type; K.horizon = c->horizon; K.robot_horizon = c->robot_horizon; K.object_horizon = c->object_horizon;
   K.robot_dim = c->robot_dim; K.object_dim = c->object_dim; K.has_vel = c->ref_robot_vel != nullptr;
   K.extrapolate = c->motion_extrapolation; K.linear = c->interpolation_linear; K.autoreset = c->autoreset;
-  K.term_obj = c->terminate_obj_fail; K.term_pose = c->terminate_pose_fail; K.start_time = c->motion_start_time;
+  K.term_obj = c->terminate_obj_fail; K.term_pose = c->terminate_pose_fail; K.start_time = c->motion_start_time; K.max_steps = c->max_episode_steps;
   int rc;
   auto up = [&](const void* src, size_t nbytes, const void** dst) -> int {
     void* p = nullptr;

@@ -71,7 +71,18 @@ struct DevModelW {
   gpf eq_f;
   gpf mesh_rec, mesh_startrec, mesh_aabb;   // hull vertex graphs as float4 records (lowering.py hip_mesh_rec / hip_mesh_startrec); [nmesh][6] vertex bounding boxes
   gpf fl, mesh_vert;    // TRK models: friction-loss rows [nv][4] = loss, D, B, -; hull vertices of the mesh geoms
+  // Self-contained per-lane records (built by myo_model_load from the tables above, 16-byte rows): what a lane needs for its item arrives
+  // in a few independent 16-byte loads instead of a chain of index -> table -> table reads of single words (round 2: 3.1 k vector and 4.2 k
+  // scalar loads per wave and env step, nearly every one with its latency exposed).
+  gpf4 seg_rec;         // [nseg, in seg_order][SEGR]: site 0 (link, lpos) | site 1 | wrap geom, side link, 1 / divisor, tendon | three dof-list words,
+                        //   wrap type | side lpos, radius | wrap geom link, lpos | its rotation (9)
+  gpi dl_pk;            // [ndl] moment-arm list entries in one word: dof | hinge << 7 | row slot << 8 | sign << 16
+  gpf4 cg_rec;          // [ncg][4]: link, lpos | rotation (9) | type, bounding radius
+  gpf4 pair_rec;        // [npair][4]: g1 | g2 << 8 | narrow-phase type << 16 | condim << 20 | dofs << 24, margin, gap, dof-list start |
+                        //   size 1, bounding radius 1 | size 2, bounding radius 2 | type 1 | type 2 << 8
+  gpi pair_dl_pk;       // contact dof lists in one word per entry: dof | hinge << 7 | sign << 8
 };
+#define SEGR 9
 
 __device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ int rdlanei(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
@@ -205,31 +216,38 @@ template <class LY> __device__ __forceinline__ void site_world_w(const DevModel&
   out[1] = P[1] + R[3] * a + R[4] * b + R[5] * c;
   out[2] = P[2] + R[6] * a + R[7] * b + R[8] * c;
 }
-template <class LY> __device__ __forceinline__ void geom_world_pos(const DevModel& M, const LY& Y, const float* E, int g, float* out) {
-  int l = M.cg_link[g];
-  const float* lp = M.cg_lpos + 3 * g;
-  float a = lp[0], b = lp[1], c = lp[2];
-  if (l < 0) { out[0] = a; out[1] = b; out[2] = c; return; }
+// world position of a point given in a link's frame (link < 0: world-fixed)
+template <class LY> __device__ __forceinline__ void frame_point(const LY& Y, const float* E, int l, const float* lp, float* out) {
+  if (l < 0) { out[0] = lp[0]; out[1] = lp[1]; out[2] = lp[2]; return; }
   const float* R = E + Y.lmat + 9 * l;
   const float* P = E + Y.lpos + 3 * l;
-  out[0] = P[0] + R[0] * a + R[1] * b + R[2] * c;
-  out[1] = P[1] + R[3] * a + R[4] * b + R[5] * c;
-  out[2] = P[2] + R[6] * a + R[7] * b + R[8] * c;
+  out[0] = P[0] + R[0] * lp[0] + R[1] * lp[1] + R[2] * lp[2];
+  out[1] = P[1] + R[3] * lp[0] + R[4] * lp[1] + R[5] * lp[2];
+  out[2] = P[2] + R[6] * lp[0] + R[7] * lp[1] + R[8] * lp[2];
 }
-template <class LY> __device__ __forceinline__ void geom_world_mat(const DevModel& M, const LY& Y, const float* E, int g, float* R) {
-  int l = M.cg_link[g];
+// world centre / rotation of collision geom g from its record (DevModelW::cg_rec: link, lpos | rotation | type, bounding radius)
+template <class LY> __device__ __forceinline__ void geom_world_pos(const DevModelW& W, const LY& Y, const float* E, int g, float* out) {
+  const float4 r0 = W.cg_rec[4 * g];
+  const float lp[3] = {r0.y, r0.z, r0.w};
+  frame_point(Y, E, __float_as_int(r0.x), lp, out);
+}
+template <class LY> __device__ __forceinline__ void geom_world_mat(const DevModelW& W, const LY& Y, const float* E, int g, float* R) {
+  const gpf4 G = W.cg_rec + 4 * g;
+  const float4 r0 = G[0], r1 = G[1], r2 = G[2], r3 = G[3];
+  const int l = __float_as_int(r0.x);
+  const float lm[9] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x};
   if (l < 0) {
 #pragma unroll
-    for (int k = 0; k < 9; k++) R[k] = M.cg_lmat[9 * g + k];
+    for (int k = 0; k < 9; k++) R[k] = lm[k];
   } else {
-    matmul3(R, E + Y.lmat + 9 * l, M.cg_lmat + 9 * g);
+    matmul3(R, E + Y.lmat + 9 * l, lm);
   }
 }
 // moment-arm entries of one straight tendon piece
 // Jt = this tendon's sparse jacobian row in LDS (zeroed before the segment rounds): the entries are accumulated with LDS float atomics
 // by the segment lanes themselves (one wave: deterministic order) instead of being gathered entry by entry by the tendon's lane
-template <class LY> __device__ __forceinline__ float straight_w(const DevModel& M, const LY& Y, float* E, float* Jt, const float* pa, const float* pb, int adr, int n,
-                                            float invdiv, bool active) {
+template <class LY> __device__ __forceinline__ float straight_w(const DevModelW& W, const LY& Y, float* E, float* Jt, const float* pa, const float* pb, int adr, int n,
+                                                              float invdiv, bool active) {
   float dif[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
   float dist = norm3(dif);
   float inv = dist > MINVALF ? 1.0f / dist : 0.f;
@@ -238,17 +256,17 @@ template <class LY> __device__ __forceinline__ float straight_w(const DevModel& 
   // the longest dof list among the lanes that DO keep it, and zero when none does
   const int nn = active ? n : 0;
   for (int k = 0; k < nn; k++) {
-    const int* e = M.dl + 3 * (adr + k);
-    int d = e[0];
+    const int e = W.dl_pk[adr + k];            // dof | hinge << 7 | row slot << 8 | sign << 16: one word instead of three plus dof_type[dof]
+    const int d = e & 127;
     const float* ax = E + Y.axis + 3 * d;
     float col;
-    if (M.dof_type[d] == 3) {
+    if (e & 128) {
       const float* an = E + Y.anchor + 3 * d;
       float r[3] = {pb[0] - an[0], pb[1] - an[1], pb[2] - an[2]}, c[3];
       cross3(c, ax, r);
       col = dot3(dif, c);
     } else col = dot3(dif, ax);
-    atomicAdd(&Jt[e[2]], (float)e[1] * col * invdiv);
+    atomicAdd(&Jt[(e >> 8) & 255], (float)(e >> 16) * col * invdiv);
   }
   return active ? dist * invdiv : 0.f;
 }
@@ -500,8 +518,23 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   // per-env size of one collision geom (DevBatch.gsize), generic FULL instantiations only: the size-specialised and hand kernels keep
   // reading the model tables unconditionally
   constexpr bool OVR = FULL && SPEC == 0 && !HF;
-  auto cgsz = [&](int g) -> const float* { return (OVR && Bt.gsize && g == Bt.gsize_cg) ? (const float*)(Bt.gsize + 4 * (size_t)env) : M.cg_size + 3 * g; };
-  auto cgrb = [&](int g) -> float { return (OVR && Bt.gsize && g == Bt.gsize_cg) ? Bt.gsize[4 * (size_t)env + 3] : M.cg_rbound[g]; };
+  // pair record -> locals.  (OVR: one geom's size / bounding radius may be a per-env value, DevBatch.gsize)
+  struct PairL { int g1, g2, dl, kc, pt, cd, t1, t2; float margin, gap, rb1, rb2, s1[3], s2[3]; };
+  auto pair_load = [&](int p) -> PairL {
+    const gpf4 Q = W.pair_rec + 4 * (size_t)p;
+    const float4 q0 = Q[0], q1 = Q[1], q2 = Q[2], q3 = Q[3];
+    const int w = __float_as_int(q0.x), tt = __float_as_int(q3.x);
+    PairL L;
+    L.g1 = w & 255; L.g2 = (w >> 8) & 255; L.pt = (w >> 16) & 15; L.cd = (w >> 20) & 15; L.kc = (w >> 24) & 255; L.dl = __float_as_int(q0.w);
+    L.margin = q0.y; L.gap = q0.z; L.t1 = tt & 255; L.t2 = (tt >> 8) & 255;
+    L.s1[0] = q1.x; L.s1[1] = q1.y; L.s1[2] = q1.z; L.rb1 = q1.w; L.s2[0] = q2.x; L.s2[1] = q2.y; L.s2[2] = q2.z; L.rb2 = q2.w;
+    if (OVR && Bt.gsize) {
+      const float* G = Bt.gsize + 4 * (size_t)env;
+      if (L.g1 == Bt.gsize_cg) { L.s1[0] = G[0]; L.s1[1] = G[1]; L.s1[2] = G[2]; L.rb1 = G[3]; }
+      if (L.g2 == Bt.gsize_cg) { L.s2[0] = G[0]; L.s2[1] = G[1]; L.s2[2] = G[2]; L.rb2 = G[3]; }
+    }
+    return L;
+  };
   // contacts NC .. NC + NCX - 1 live in this env's HBM overflow rows [dist, pos3, normal3, pair, cJ[3 KC], dof words]; lane = contact still holds
   // for all 64.  The first NC contacts (all of them for > 99.5 % of the states) never leave LDS.
   constexpr int NCXK = (64 - NC) < NCX ? (64 - NC) : NCX;   // overflow rows this instantiation uses: one lane per contact, 64 in all
@@ -672,39 +705,44 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     for (int base = 0; base < nseg_; base += 64) {
       int idx = base + lane;
       if (idx < nseg_) {
-        int si = W.seg_order[idx];
-        const int* S = M.seg + 12 * si;
-        float invdiv = 1.0f / M.seg_div[si];
+        // the segment's record: four independent 16-byte loads (five more for a wrapping segment) carry everything the old chain
+        // seg_order -> seg -> site_link / site_lpos / wg_* read word by word
+        const gpf4 SR = W.seg_rec + (size_t)idx * SEGR;
+        const float4 r0 = SR[0], r1 = SR[1], r2 = SR[2], r3 = SR[3];
+        const int g = __float_as_int(r2.x), side_l = __float_as_int(r2.y), gts = __float_as_int(r2.w);
+        const float invdiv = r2.z;
         float p0[3], p1[3];
-        site_world_w(M, Y, E, S[0], p0);
-        site_world_w(M, Y, E, S[1], p1);
+        { const float lp[3] = {r0.y, r0.z, r0.w}; frame_point(Y, E, __float_as_int(r0.x), lp, p0); }
+        { const float lp[3] = {r1.y, r1.z, r1.w}; frame_point(Y, E, __float_as_int(r1.x), lp, p1); }
         float wlen = -1, wp[6];
-        if (S[2] >= 0) {
-          int g = S[2], gl = M.wg_link[g];
+        if (g >= 0) {
+          const float4 r4 = SR[4], r5 = SR[5], r6 = SR[6], r7 = SR[7], r8 = SR[8];
+          const int gl = __float_as_int(r5.x);
+          const float glp[3] = {r5.y, r5.z, r5.w}, glm[9] = {r6.x, r6.y, r6.z, r6.w, r7.x, r7.y, r7.z, r7.w, r8.x};
           float gpos[3], gmat[9], side[3] = {0, 0, 0};
           if (gl < 0) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) gpos[k] = M.wg_lpos[3 * g + k];
+            for (int k = 0; k < 3; k++) gpos[k] = glp[k];
 #pragma unroll
-            for (int k = 0; k < 9; k++) gmat[k] = M.wg_lmat[9 * g + k];
+            for (int k = 0; k < 9; k++) gmat[k] = glm[k];
           } else {
             float v[3];
-            matvec(v, E + Y.lmat + 9 * gl, M.wg_lpos + 3 * g);
+            matvec(v, E + Y.lmat + 9 * gl, glp);
 #pragma unroll
             for (int k = 0; k < 3; k++) gpos[k] = E[Y.lpos + 3 * gl + k] + v[k];
-            matmul3(gmat, E + Y.lmat + 9 * gl, M.wg_lmat + 9 * g);
+            matmul3(gmat, E + Y.lmat + 9 * gl, glm);
           }
-          if (S[3] >= 0) site_world_w(M, Y, E, S[3], side);
-          wlen = wrap_geom_inl(wp, p0, p1, gpos, gmat, M.wg_radius[g], S[10] != 0, side, S[3] >= 0);   // always inline: an out-of-line copy passes its arrays through scratch memory
+          if (side_l != -2) { const float lp[3] = {r4.x, r4.y, r4.z}; frame_point(Y, E, side_l, lp, side); }
+          wlen = wrap_geom_inl(wp, p0, p1, gpos, gmat, r4.w, __float_as_int(r3.w) != 0, side, side_l != -2);   // always inline: an out-of-line copy passes its arrays through scratch memory
         }
         SUB(7);
         bool wr = wlen >= 0;
-        const int gts = W.seg_tendon[si];
         float* Jt = E + Y.tJ + gts * maxnnz_;
-        float L = straight_w(M, Y, E, Jt, p0, p1, S[4], S[5], invdiv, !wr);
-        if (S[2] >= 0) {
-          L += straight_w(M, Y, E, Jt, p0, wp, S[6], S[7], invdiv, wr);
-          L += straight_w(M, Y, E, Jt, wp + 3, p1, S[8], S[9], invdiv, wr);
+        const int wa = __float_as_int(r3.x), wb = __float_as_int(r3.y), wc = __float_as_int(r3.z);
+        float L = straight_w(W, Y, E, Jt, p0, p1, wa & 0xFFFFF, wa >> 20, invdiv, !wr);
+        if (g >= 0) {
+          L += straight_w(W, Y, E, Jt, p0, wp, wb & 0xFFFFF, wb >> 20, invdiv, wr);
+          L += straight_w(W, Y, E, Jt, wp + 3, p1, wc & 0xFFFFF, wc >> 20, invdiv, wr);
           if (wr) L += wlen * invdiv;
         }
         atomicAdd(&E[Y.tlen + gts], L);
@@ -960,8 +998,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       int* cand = (int*)(E + Y.cand);
       if (lane < ncg_) {   // world centre and long axis (3rd column) of every collision geom
         float x[3], R[9];
-        geom_world_pos(M, Y, E, lane, x);
-        geom_world_mat(M, Y, E, lane, R);
+        geom_world_pos(W, Y, E, lane, x);
+        geom_world_mat(W, Y, E, lane, R);
         E[Y.gpos + 3 * lane] = x[0]; E[Y.gpos + 3 * lane + 1] = x[1]; E[Y.gpos + 3 * lane + 2] = x[2];
         E[Y.gax + 3 * lane] = R[2]; E[Y.gax + 3 * lane + 1] = R[5]; E[Y.gax + 3 * lane + 2] = R[8];
       }
@@ -972,15 +1010,16 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         int nh = 0, hr0 = 0, hr1 = 0, hc0 = 0, hc1 = 0;   // height-field pair: cell range under the geom, prisms that can touch it
         float hzcut = 0.f;
         if (p < npair_) {
-          const int* P = M.pair_i + 6 * p;
+          const PairL Q = pair_load(p);   // one record: four independent 16-byte loads (was pair_i -> cg_rbound / cg_type / cg_size -> pair_f, word by word)
+          const int P[6] = {Q.g1, Q.g2, Q.dl, Q.kc, Q.pt, Q.cd};
           if (HF && P[4] == 4) {
-            const int g2 = P[1], ty = M.cg_type[g2];
-            const float *x2 = E + Y.gpos + 3 * g2, *ax = E + Y.gax + 3 * g2, *sz = M.cg_size + 3 * g2;
-            const float rel[3] = {x2[0] - W.hf.pos[0], x2[1] - W.hf.pos[1], x2[2] - W.hf.pos[2]}, margin = M.pair_f[12 * p];
+            const int g2 = P[1], ty = Q.t2;
+            const float *x2 = E + Y.gpos + 3 * g2, *ax = E + Y.gax + 3 * g2, *sz = Q.s2;
+            const float rel[3] = {x2[0] - W.hf.pos[0], x2[1] - W.hf.pos[1], x2[2] - W.hf.pos[2]}, margin = Q.margin;
             float ext[3];
             if (ty == GEOM_ELLIPSOID) {
               float R[9];
-              geom_world_mat(M, Y, E, g2, R);
+              geom_world_mat(W, Y, E, g2, R);
 #pragma unroll
               for (int k = 0; k < 3; k++) { const float a = R[3 * k] * sz[0], b = R[3 * k + 1] * sz[1], c = R[3 * k + 2] * sz[2]; ext[k] = sqrtf(a * a + b * b + c * c); }
             } else {
@@ -989,7 +1028,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
                 ext[k] = ty == GEOM_SPHERE ? sz[0] : (ty == GEOM_CAPSULE ? sz[0] + sz[1] * fabsf(ax[k]) : sz[1] * fabsf(ax[k]) + sz[0] * sqrtf(fmaxf(0.f, 1.f - ax[k] * ax[k])));
             }
             float zmin;
-            if (hf_range(W.hf, rel, ext, M.cg_rbound[g2], margin, hr0, hr1, hc0, hc1, zmin)) {
+            if (hf_range(W.hf, rel, ext, Q.rb2, margin, hr0, hr1, hc0, hc1, zmin)) {
               hzcut = zmin - margin;
               nh = hf_walk(W.hf, Bt.hfield + (size_t)env * W.hf.nrow * W.hf.ncol, hr0, hr1, hc0, hc1, hzcut, p, nullptr, 0, 0);
             }
@@ -997,22 +1036,22 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             int g1 = P[0], g2 = P[1];
             const float *x1 = E + Y.gpos + 3 * g1, *x2 = E + Y.gpos + 3 * g2;
             float dif[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
-            float bound = cgrb(g1) + cgrb(g2) + M.pair_f[12 * p];
-            if (FULL && P[4] >= 2) hit = dot3(dif, E + Y.gax + 3 * g1) <= cgrb(g2) + M.pair_f[12 * p];   // plane: signed distance of the bounding sphere
+            float bound = Q.rb1 + Q.rb2 + Q.margin;
+            if (FULL && P[4] >= 2) hit = dot3(dif, E + Y.gax + 3 * g1) <= Q.rb2 + Q.margin;   // plane: signed distance of the bounding sphere
             else hit = dot3(dif, dif) <= bound * bound;
             if constexpr (TRK) {
               // a box (table top: bounding sphere 0.7 m) is tested as a box, a hull as the bounding box of its vertices in the mesh frame
               // (lowering.py hip_mesh_aabb: centre | half sizes): distance from the other geom's centre to that box against the other
               // geom's bounding sphere + margin.  The airplane's outer hull has a 0.10 m bounding sphere and thin wings.
-              const int t1 = M.cg_type[g1], t2 = M.cg_type[g2];
+              const int t1 = Q.t1, t2 = Q.t2;
               if (hit && P[4] == 5) {   // plane - hull: the lowest corner of the hull's vertex bounding box along the plane normal
                 float R2[9], nl[3];
                 const float* n = E + Y.gax + 3 * g1;
-                geom_world_mat(M, Y, E, g2, R2);
+                geom_world_mat(W, Y, E, g2, R2);
                 matTvec(nl, R2, n);
-                gpf bx = W.mesh_aabb + 6 * (int)M.cg_size[3 * g2 + 2];
+                gpf bx = W.mesh_aabb + 6 * (int)Q.s2[2];
                 const float low = dot3(dif, n) + nl[0] * bx[0] + nl[1] * bx[1] + nl[2] * bx[2] - (fabsf(nl[0]) * bx[3] + fabsf(nl[1]) * bx[4] + fabsf(nl[2]) * bx[5]);
-                hit = low <= M.pair_f[12 * p];
+                hit = low <= Q.margin;
               }
               if (hit && (t1 >= 6 || t2 >= 6) && P[4] == 0) {
 #pragma unroll
@@ -1020,13 +1059,13 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
                   const int gb = side ? g2 : g1, go = side ? g1 : g2, tb = side ? t2 : t1;
                   if (tb < 6 || !hit) continue;
                   float Rb[9], cl[3], dd[3] = {E[Y.gpos + 3 * go] - E[Y.gpos + 3 * gb], E[Y.gpos + 3 * go + 1] - E[Y.gpos + 3 * gb + 1], E[Y.gpos + 3 * go + 2] - E[Y.gpos + 3 * gb + 2]};
-                  geom_world_mat(M, Y, E, gb, Rb);
+                  geom_world_mat(W, Y, E, gb, Rb);
                   matTvec(cl, Rb, dd);
-                  const float* sb = M.cg_size + 3 * gb;
+                  const float* sb = side ? Q.s2 : Q.s1;
                   float hx = sb[0], hy = sb[1], hz = sb[2];
                   if (tb == 7) { gpf bx = W.mesh_aabb + 6 * (int)sb[2]; cl[0] -= bx[0]; cl[1] -= bx[1]; cl[2] -= bx[2]; hx = bx[3]; hy = bx[4]; hz = bx[5]; }
                   const float ex = fmaxf(fabsf(cl[0]) - hx, 0.f), ey = fmaxf(fabsf(cl[1]) - hy, 0.f), ez = fmaxf(fabsf(cl[2]) - hz, 0.f);
-                  const float lim = M.cg_rbound[go] + M.pair_f[12 * p];
+                  const float lim = (side ? Q.rb1 : Q.rb2) + Q.margin;
                   hit = ex * ex + ey * ey + ez * ez <= lim * lim;
                 }
               }
@@ -1034,23 +1073,23 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             if (hit && !P[4]) {
               // conservative refinement before the expensive MPR: replace a capsule's bounding sphere by the distance
               // from the other geom's centre to the capsule's SEGMENT (a bound on the true distance, never excludes a contact)
-              float b1 = cgrb(g1), b2 = cgrb(g2);
+              float b1 = Q.rb1, b2 = Q.rb2;
               float c1[3] = {x1[0], x1[1], x1[2]}, c2[3] = {x2[0], x2[1], x2[2]};
-              if (M.cg_type[g1] == GEOM_CAPSULE) {
+              if (Q.t1 == GEOM_CAPSULE) {
                 const float* a = E + Y.gax + 3 * g1;
-                float hh = cgsz(g1)[1], t = clipf(dot3(dif, a), -hh, hh);
+                float hh = Q.s1[1], t = clipf(dot3(dif, a), -hh, hh);
                 c1[0] += t * a[0]; c1[1] += t * a[1]; c1[2] += t * a[2];
-                b1 = cgsz(g1)[0];
+                b1 = Q.s1[0];
               }
-              if (M.cg_type[g2] == GEOM_CAPSULE) {
+              if (Q.t2 == GEOM_CAPSULE) {
                 const float* a = E + Y.gax + 3 * g2;
                 float nd[3] = {c1[0] - x2[0], c1[1] - x2[1], c1[2] - x2[2]};
-                float hh = cgsz(g2)[1], t = clipf(dot3(nd, a), -hh, hh);
+                float hh = Q.s2[1], t = clipf(dot3(nd, a), -hh, hh);
                 c2[0] += t * a[0]; c2[1] += t * a[1]; c2[2] += t * a[2];
-                b2 = cgsz(g2)[0];
+                b2 = Q.s2[0];
               }
               float d2[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
-              float bb = b1 + b2 + M.pair_f[12 * p];
+              float bb = b1 + b2 + Q.margin;
               hit = dot3(d2, d2) <= bb * bb;
               if (hit) {
                 // separating-axis test along the centre line: the two (margin-inflated) convex shapes cannot touch if their
@@ -1058,18 +1097,18 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
                 // exactly these pairs, after a dozen support evaluations; this costs one support width per shape
                 float dn = norm3(dif);
                 if (dn > MINVALF) {
-                  float inv = 1.0f / dn, ax[3] = {dif[0] * inv, dif[1] * inv, dif[2] * inv}, wsum = M.pair_f[12 * p];
+                  float inv = 1.0f / dn, ax[3] = {dif[0] * inv, dif[1] * inv, dif[2] * inv}, wsum = Q.margin;
 #pragma unroll
                   for (int side = 0; side < 2; side++) {
                     const int g = side ? g2 : g1;
-                    const float* sz = cgsz(g);
-                    const int ty = M.cg_type[g];
+                    const float* sz = side ? Q.s2 : Q.s1;
+                    const int ty = side ? Q.t2 : Q.t1;
                     if (TRK && ty >= 6) wsum += 1e9f;   // box / hull: no cheap support width here, the pair goes to MPR
                     else if (ty == GEOM_CAPSULE) wsum += sz[0] + sz[1] * fabsf(dot3(E + Y.gax + 3 * g, ax));
                     else if (ty == GEOM_SPHERE) wsum += sz[0];
                     else {
                       float R[9], dl[3];
-                      geom_world_mat(M, Y, E, g, R);
+                      geom_world_mat(W, Y, E, g, R);
                       matTvec(dl, R, ax);
                       if (ty == GEOM_ELLIPSOID) { float sv[3] = {sz[0] * dl[0], sz[1] * dl[1], sz[2] * dl[2]}; wsum += norm3(sv); }
                       else wsum += sz[0] * sqrtf(dl[0] * dl[0] + dl[1] * dl[1]) + sz[1] * fabsf(dl[2]);   // cylinder
@@ -1115,11 +1154,12 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         if (ci < ncand) {
           const int cw = (ci < NCAND) ? cand[ci] : ovf_cand[ci - NCAND];
           p = HF ? (cw & 1023) : cw;
-          const int* P = M.pair_i + 6 * p;
+          const PairL Q = pair_load(p);
+          const int P[6] = {Q.g1, Q.g2, Q.dl, Q.kc, Q.pt, Q.cd};
           int g1 = P[0], g2 = P[1];
-          float margin = M.pair_f[12 * p];
+          float margin = Q.margin;
           const float *x1 = E + Y.gpos + 3 * g1, *x2 = E + Y.gpos + 3 * g2;
-          const float *sz1 = cgsz(g1), *sz2 = cgsz(g2);
+          const float *sz1 = Q.s1, *sz2 = Q.s2;
           if (P[4] == 1) {
             const float *a1 = E + Y.gax + 3 * g1, *a2 = E + Y.gax + 3 * g2;
             float dif[3] = {x1[0] - x2[0], x1[1] - x2[1], x1[2] - x2[2]};
@@ -1168,7 +1208,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           } else if (FULL && TRK && P[4] == 5) {   // plane - convex hull: deepest vertex along -normal (one contact)
             const float* n = E + Y.gax + 3 * g1;
             float R2[9], nl[3], pw[3];
-            geom_world_mat(M, Y, E, g2, R2);
+            geom_world_mat(W, Y, E, g2, R2);
             matTvec(nl, R2, n);
             CObj oh;
             cobj_shape_poly(oh, 7, sz2);
@@ -1188,7 +1228,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           } else if (FULL && P[4] == 3) {   // plane - ellipsoid (mjc_PlaneConvex): deepest support point along -normal
             const float* n = E + Y.gax + 3 * g1;
             float R2[9], nl[3], sp[3], pw[3];
-            geom_world_mat(M, Y, E, g2, R2);
+            geom_world_mat(W, Y, E, g2, R2);
             matTvec(nl, R2, n);
             float sv[3] = {sz2[0] * nl[0], sz2[1] * nl[1], sz2[2] * nl[2]};
             float nn = norm3(sv), inv = nn > MINVALF ? -1.0f / nn : 0.f;
@@ -1222,15 +1262,15 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
               o1.S[0] = -W.hf.size[3] - cen[2]; o1.S[1] = o1.S[2] = 0.f; o1.h = -1.f;
 #pragma unroll
               for (int k = 0; k < 9; k++) R1[k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
-              geom_world_mat(M, Y, E, g2, o2.mat);
+              geom_world_mat(W, Y, E, g2, o2.mat);
 #pragma unroll
               for (int k = 0; k < 3; k++) o2.pos[k] = x2[k] - x1[k] - cen[k];
-              cobj_shape(o2, M.cg_type[g2], sz2);
+              cobj_shape(o2, Q.t2, sz2);
             } else {
-            geom_world_mat(M, Y, E, g1, R1);
+            geom_world_mat(W, Y, E, g1, R1);
             {
               float R2[9], rel[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
-              geom_world_mat(M, Y, E, g2, R2);
+              geom_world_mat(W, Y, E, g2, R2);
 #pragma unroll
               for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -1241,7 +1281,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             for (int k = 0; k < 9; k++) o1.mat[k] = (k == 0 || k == 4 || k == 8) ? 1.f : 0.f;
 #pragma unroll
             for (int k = 0; k < 3; k++) o1.pos[k] = 0.f;
-            cobj_shape(o1, M.cg_type[g1], sz1); cobj_shape(o2, M.cg_type[g2], sz2);
+            cobj_shape(o1, Q.t1, sz1); cobj_shape(o2, Q.t2, sz2);
             }
             o1.margin = o2.margin = 0.5f * margin;
             float depth, dir[3], pos[3], nw[3] = {0.f, 0.f, 0.f};
@@ -1269,11 +1309,11 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             // MPR in geom1's own frame: obj1 needs no rotation / translation at all (identity frame), obj2 carries the
             // relative pose R1^T R2, R1^T (x2 - x1); normal and position are rotated back afterwards
             float R1[9];
-            geom_world_mat(M, Y, E, g1, R1);
+            geom_world_mat(W, Y, E, g1, R1);
             CObj o1, o2;
             {
               float R2[9], rel[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
-              geom_world_mat(M, Y, E, g2, R2);
+              geom_world_mat(W, Y, E, g2, R2);
 #pragma unroll
               for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -1285,10 +1325,10 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
 #pragma unroll
             for (int k = 0; k < 3; k++) o1.pos[k] = 0.f;
             if constexpr (TRK) {
-              cobj_shape_poly(o1, M.cg_type[g1], sz1);
-              cobj_shape_poly(o2, M.cg_type[g2], sz2);
+              cobj_shape_poly(o1, Q.t1, sz1);
+              cobj_shape_poly(o2, Q.t2, sz2);
             }
-            else { cobj_shape(o1, M.cg_type[g1], sz1); cobj_shape(o2, M.cg_type[g2], sz2); }
+            else { cobj_shape(o1, Q.t1, sz1); cobj_shape(o2, Q.t2, sz2); }
             o1.margin = o2.margin = 0.5f * margin;
             float depth, dir[3], pos[3], nw[3] = {0.f, 0.f, 0.f};
             bool have_nw = false;
@@ -1302,7 +1342,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
               normalize3(dir);
               mpr_hit = true; mpr_n[0] = dir[0]; mpr_n[1] = dir[1]; mpr_n[2] = dir[2];
               float dw[3], pw[3], R1b[9];
-              geom_world_mat(M, Y, E, g1, R1b);   // recomputed (9 LDS reads + a 3x3 product) instead of kept live across the portal refinement
+              geom_world_mat(W, Y, E, g1, R1b);   // recomputed (9 LDS reads + a 3x3 product) instead of kept live across the portal refinement
               matvec(dw, R1b, dir);
               matvec(pw, R1b, pos);
 #pragma unroll
@@ -1311,8 +1351,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             }
                       }
           }
-          if (hit && !(dist < margin - M.pair_f[12 * p + 1])) hit = false;
-          if (hit2 && !(dist2 < margin - M.pair_f[12 * p + 1])) hit2 = false;
+          if (hit && !(dist < margin - Q.gap)) hit = false;
+          if (hit2 && !(dist2 < margin - Q.gap)) hit2 = false;
         }
         {  // slowest lane of this round: MPR lanes cost ~8 + refinement steps, analytic pairs ~1
           int w = nsup + 8;
@@ -1397,7 +1437,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     // (generic lambda: instantiated once with LDS pointers and once with the HBM overflow row, so that each copy keeps its own address space)
     auto build_row = [&](const float* pdist, const float* ppos, const float* pnrm, const int* ppair, float* cJ, unsigned int* cdw) {
       int p = ppair[0];
-      const int* P = M.pair_i + 6 * p;
+      const float4 pq0_ = W.pair_rec[4 * (size_t)(p)]; const int pw_ = __float_as_int(pq0_.x); const int P[6] = {pw_ & 255, (pw_ >> 8) & 255, __float_as_int(pq0_.w), (pw_ >> 24) & 255, (pw_ >> 16) & 15, (pw_ >> 20) & 15};
       const float* F = M.pair_f + 12 * p;
       float n[3] = {pnrm[0], pnrm[1], pnrm[2]}, t1[3], t2[3];
       float cp[3] = {ppos[0], ppos[1], ppos[2]};
@@ -1422,18 +1462,19 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         float jn = 0, j1 = 0, j2 = 0, js = 0;
         int d = 0;
         if (k < ckc) {
-          d = M.pair_dl[2 * (P[2] + k)];
-          float sg = (float)M.pair_dl[2 * (P[2] + k) + 1];
+          const int de_ = W.pair_dl_pk[P[2] + k];   // dof | hinge << 7 | sign << 8
+          d = de_ & 127;
+          float sg = (float)(de_ >> 8);
           const float* ax = E + Y.axis + 3 * d;
           float col[3];
-          if (M.dof_type[d] == 3) {
+          if (de_ & 128) {
             float r[3] = {cp[0] - E[Y.anchor + 3 * d], cp[1] - E[Y.anchor + 3 * d + 1], cp[2] - E[Y.anchor + 3 * d + 2]};
             cross3(col, ax, r);
           } else { col[0] = ax[0]; col[1] = ax[1]; col[2] = ax[2]; }
           jn = sg * dot3(n, col); j1 = sg * dot3(t1, col); j2 = sg * dot3(t2, col);
           float qv = E[Y.qvel + d];
           vn += jn * qv; vt1 += j1 * qv; vt2 += j2 * qv;
-          if constexpr (TRK) { js = M.dof_type[d] == 3 ? sg * dot3(n, ax) : 0.f; vs += js * qv; }   // relative angular velocity about the normal
+          if constexpr (TRK) { js = (de_ & 128) ? sg * dot3(n, ax) : 0.f; vs += js * qv; }   // relative angular velocity about the normal
         }
         cJ[k] = jn; cJ[KC + k] = j1; cJ[2 * KC + k] = j2;
         if constexpr (TRK) cJ[3 * KC + k] = js;
@@ -1469,18 +1510,19 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         const int c = c0 + rg;
         float pv0 = 0.f, pv1 = 0.f, pv2 = 0.f;
         auto row_cols = [&](const float* ppos, const float* pnrm, const int* ppair, float* cJ, unsigned int* cdw) {
-          const int* P = M.pair_i + 6 * ppair[0];
+          const float4 pq0_ = W.pair_rec[4 * (size_t)(ppair[0])]; const int pw_ = __float_as_int(pq0_.x); const int P[6] = {pw_ & 255, (pw_ >> 8) & 255, __float_as_int(pq0_.w), (pw_ >> 24) & 255, (pw_ >> 16) & 15, (pw_ >> 20) & 15};
           const float n[3] = {pnrm[0], pnrm[1], pnrm[2]}, cp[3] = {ppos[0], ppos[1], ppos[2]};
           float t1[3], t2[3];
           make_frame(n, t1, t2);
           float jn = 0.f, j1 = 0.f, j2 = 0.f;
           int d = 0;
           if (rk < P[3]) {
-            d = M.pair_dl[2 * (P[2] + rk)];
-            const float sg = (float)M.pair_dl[2 * (P[2] + rk) + 1];
+            const int de_ = W.pair_dl_pk[P[2] + rk];   // dof | hinge << 7 | sign << 8
+            d = de_ & 127;
+            const float sg = (float)(de_ >> 8);
             const float* ax = E + Y.axis + 3 * d;
             float col[3];
-            if (M.dof_type[d] == 3) {
+            if (de_ & 128) {
               const float r[3] = {cp[0] - E[Y.anchor + 3 * d], cp[1] - E[Y.anchor + 3 * d + 1], cp[2] - E[Y.anchor + 3 * d + 2]};
               cross3(col, ax, r);
             } else { col[0] = ax[0]; col[1] = ax[1]; col[2] = ax[2]; }
@@ -1506,7 +1548,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         const float* g = lane < NC ? nullptr : ovf_env + (lane - NC) * ovf_row;
         const int p = lane < NC ? ((const int*)(E + Y.cpair))[lane] : ((const int*)g)[7];
         const float dist = lane < NC ? E[Y.cdist + lane] : g[0];
-        const int* P = M.pair_i + 6 * p;
+        const float4 pq0_ = W.pair_rec[4 * (size_t)(p)]; const int pw_ = __float_as_int(pq0_.x); const int P[6] = {pw_ & 255, (pw_ >> 8) & 255, __float_as_int(pq0_.w), (pw_ >> 24) & 255, (pw_ >> 16) & 15, (pw_ >> 20) & 15};
         const float* F = M.pair_f + 12 * p;
         ckc = P[3];
         const float incl = F[0] - F[1];
@@ -1529,7 +1571,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         SYNC();
         const int c = c0 + rg;
         auto row_cols = [&](const float* ppos, const float* pnrm, const int* ppair, float* cJ, unsigned int* cdw) {
-          const int* P = M.pair_i + 6 * ppair[0];
+          const float4 pq0_ = W.pair_rec[4 * (size_t)(ppair[0])]; const int pw_ = __float_as_int(pq0_.x); const int P[6] = {pw_ & 255, (pw_ >> 8) & 255, __float_as_int(pq0_.w), (pw_ >> 24) & 255, (pw_ >> 16) & 15, (pw_ >> 20) & 15};
           const float n[3] = {pnrm[0], pnrm[1], pnrm[2]}, cp[3] = {ppos[0], ppos[1], ppos[2]};
           float t1[3], t2[3];
           make_frame(n, t1, t2);
@@ -1546,11 +1588,12 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           float jn = 0.f, j1 = 0.f, j2 = 0.f, js = 0.f;
           int d = 0;
           if (rk < P[3]) {
-            d = M.pair_dl[2 * (P[2] + rk)];
-            const float sg = (float)M.pair_dl[2 * (P[2] + rk) + 1];
+            const int de_ = W.pair_dl_pk[P[2] + rk];   // dof | hinge << 7 | sign << 8
+            d = de_ & 127;
+            const float sg = (float)(de_ >> 8);
             const float* ax = E + Y.axis + 3 * d;
             float col[3];
-            const bool hinge = M.dof_type[d] == 3;
+            const bool hinge = (de_ & 128) != 0;
             if (hinge) {
               const float r[3] = {cp[0] - E[Y.anchor + 3 * d], cp[1] - E[Y.anchor + 3 * d + 1], cp[2] - E[Y.anchor + 3 * d + 2]};
               cross3(col, ax, r);
@@ -1576,7 +1619,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         const float* g = lane < NC ? nullptr : ovf_env + (lane - NC) * ovf_row;
         const int p = lane < NC ? ((const int*)(E + Y.cpair))[lane] : ((const int*)g)[7];
         const float dist = lane < NC ? E[Y.cdist + lane] : g[0];
-        const int* P = M.pair_i + 6 * p;
+        const float4 pq0_ = W.pair_rec[4 * (size_t)(p)]; const int pw_ = __float_as_int(pq0_.x); const int P[6] = {pw_ & 255, (pw_ >> 8) & 255, __float_as_int(pq0_.w), (pw_ >> 24) & 255, (pw_ >> 16) & 15, (pw_ >> 20) & 15};
         const float* F = M.pair_f + 12 * p;
         ckc = P[3];
         const float incl = F[0] - F[1];
@@ -2133,7 +2176,9 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       SYNC();
       const DevTrack& K = *Bt.track;
       const float done = uniformf(track_reward(K, Bt, env, lane_id, E + Y.qpos, E + Y.qvel, E + Y.lpos, E + Y.lmat, M.origin, [](float v) { return wave_sum(v); }));
-      if (K.autoreset && done > 0.f) {   // (wave-uniform) TrackEnv.reset of this env: init_qpos, zero velocity / activation / control / warm start / time
+      const bool trunc = K.max_steps > 0 && !(done > 0.f) && Bt.elapsed[env] + 1 >= K.max_steps;   // gym TimeLimit of the registered ids
+      if (lane_id == 0) Bt.solved[env] = trunc ? 1.f : 0.f;
+      if (K.autoreset && (done > 0.f || trunc)) {   // (wave-uniform) TrackEnv.reset of this env: init_qpos, zero velocity / activation / control / warm start / time
         SYNC();
         if (lane_id < nq) E[Y.qpos + lane_id] = K.init_qpos[lane_id];
         if (lane_id < nv) { E[Y.qvel + lane_id] = 0.f; warm_row[lane_id] = 0.f; }

@@ -136,7 +136,7 @@ __device__ __forceinline__ float track_reward(const DevTrack& K, const DevBatch&
   rew = rew + K.w_bonus * m_bonus;
   rew = rew + K.w_penalty * done;
   if (lane == 0) {
-    Bt.reward[env] = rew; Bt.done[env] = done; Bt.solved[env] = 0.f;
+    Bt.reward[env] = rew; Bt.done[env] = done;
     float* mt = K.metrics + 4 * (size_t)env;
     mt[0] = m_pose; mt[1] = m_obj; mt[2] = m_bonus; mt[3] = done;
   }

@@ -412,8 +412,9 @@ def _make_track(env_id, num_envs, reference=None, **kw):
             raise FileNotFoundError(f"{env_id}: motion file {spec['motion']} not found; pass reference=<path or dict> or set MYODM_DATA to the "
                                     "directory of the reference's envs/myo/myodm/data")
         reference = hits[0]
-    env = TrackEnv(num_envs=num_envs, object_name=spec["object"], reference=reference, **kw)
-    env.id, env.max_episode_steps = env_id, spec["max_episode_steps"]
+    kw.setdefault("max_episode_steps", spec["max_episode_steps"])
+    env = TrackEnv(num_envs=num_envs, object_name=spec["object"], reference=reference, gym_api=True, **kw)
+    env.id = env_id
     return env
 
 
