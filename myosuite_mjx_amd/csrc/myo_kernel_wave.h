@@ -113,18 +113,22 @@ __device__ __forceinline__ int wave_lane() {
 #define CDOFP(W_, k_) ((int)(((W_)[(k_) >> 2] >> (8 * ((k_) & 3))) & 255u))
 
 // in: r[k] = H[lane][k] (k <= lane). out: r[k] = L[lane][k], returns 1/L[lane][lane].  All indices are compile-time.
+// Right-looking (outer-product) order: once column j is final, every later column k takes its update r[k] -= L[.][j] L[k][j] at once.  The
+// products are the same 276 as in the left-looking order, but the NVT - 1 - j updates of a step are independent of each other, where the
+// left-looking form chained the j products of a column through one accumulator: the dependent chain of a factorisation shrinks from
+// ~276 multiply-adds to NVT pivot steps -- what a wave that runs alone on its SIMD (the heavy envs at the end of a launch) is bound by.
 template <int NVT> __device__ __forceinline__ float chol_rows(float (&r)[NVT], int lane) {
   float invd = 1.0f;
 #pragma unroll
   for (int j = 0; j < NVT; j++) {
-    float s = r[j];
-#pragma unroll
-    for (int k = 0; k < j; k++) s -= r[k] * rdlane(r[k], j);
-    float pj = fmaxf(rdlane(s, j), MINVALF);
-    float inv = __builtin_amdgcn_rsqf(pj);   // v_rsq_f32 (1 ulp); pj >= 1e-15, no denormal handling needed
-    float dj = pj * inv;
-    r[j] = (lane == j) ? dj : s * inv;
+    const float pj = fmaxf(rdlane(r[j], j), MINVALF);
+    const float inv = __builtin_amdgcn_rsqf(pj);   // v_rsq_f32 (1 ulp); pj >= 1e-15, no denormal handling needed
+    const float dj = pj * inv;
+    const float lj = (lane == j) ? dj : r[j] * inv;
+    r[j] = lj;
     if (lane == j) invd = inv;
+#pragma unroll
+    for (int k = j + 1; k < NVT; k++) r[k] -= lj * rdlane(lj, k);     // (lanes < k carry garbage above their diagonal: never read)
   }
   return invd;
 }
@@ -144,26 +148,26 @@ template <int SPEC> __host__ __device__ constexpr bool tree_anc(int a, int d) {
   while (p >= 0) { if (p == a) return true; p = SpecTree<SPEC>::parent[p]; }
   return false;
 }
-// chol_rows on the leaves-first permuted matrix of a tree-structured model: the (j, k) products whose factor entry is structurally zero
-// are not emitted (`if constexpr` over index sequences: a run-time predicate inside `#pragma unroll` loops blocked the unrolling and put
-// the rows into scratch memory)
-template <int NVT, int SPEC, int J, int K> __device__ __forceinline__ void tree_term(float& s, const float (&r)[NVT]) {
+// chol_rows on the leaves-first permuted matrix of a tree-structured model: the updates whose factor entry L[K][J] is structurally zero
+// (dof of K is not an ancestor of the dof of J) are not emitted (`if constexpr` over index sequences: a run-time predicate inside
+// `#pragma unroll` loops blocked the unrolling and put the rows into scratch memory).  Right-looking like chol_rows.
+template <int NVT, int SPEC, int J, int K> __device__ __forceinline__ void tree_update(float (&r)[NVT], float lj) {
   constexpr int nv = SpecTree<SPEC>::nv;
-  if constexpr (J < nv && K < nv) {
-    if constexpr (tree_anc<SPEC>(nv - 1 - J, nv - 1 - K)) s -= r[K] * rdlane(r[K], J);
+  if constexpr (K > J && J < nv && K < nv) {
+    if constexpr (tree_anc<SPEC>(nv - 1 - K, nv - 1 - J)) r[K] -= lj * rdlane(lj, K);
   }
 }
-template <int NVT, int SPEC, int J, int... Ks> __device__ __forceinline__ void tree_col(float& s, const float (&r)[NVT], std::integer_sequence<int, Ks...>) {
-  (tree_term<NVT, SPEC, J, Ks>(s, r), ...);
+template <int NVT, int SPEC, int J, int... Ks> __device__ __forceinline__ void tree_col(float (&r)[NVT], float lj, std::integer_sequence<int, Ks...>) {
+  (tree_update<NVT, SPEC, J, Ks>(r, lj), ...);
 }
 template <int NVT, int SPEC, int J> __device__ __forceinline__ void tree_step(float (&r)[NVT], float& invd, int lane) {
-  float s = r[J];
-  tree_col<NVT, SPEC, J>(s, r, std::make_integer_sequence<int, J>{});
-  float pj = fmaxf(rdlane(s, J), MINVALF);
-  float inv = __builtin_amdgcn_rsqf(pj);
-  float dj = pj * inv;
-  r[J] = (lane == J) ? dj : s * inv;
+  const float pj = fmaxf(rdlane(r[J], J), MINVALF);
+  const float inv = __builtin_amdgcn_rsqf(pj);
+  const float dj = pj * inv;
+  const float lj = (lane == J) ? dj : r[J] * inv;
+  r[J] = lj;
   if (lane == J) invd = inv;
+  tree_col<NVT, SPEC, J>(r, lj, std::make_integer_sequence<int, NVT>{});
 }
 template <int NVT, int SPEC, int... Js> __device__ __forceinline__ void tree_all(float (&r)[NVT], float& invd, int lane, std::integer_sequence<int, Js...>) {
   (tree_step<NVT, SPEC, Js>(r, invd, lane), ...);
