@@ -803,13 +803,18 @@ static int launch_step(myo_batch* b, const float* action, int actmap, int nsub, 
   const int G = (g_lanes == 64 && !m->wave_ok) ? 16 : ((g_lanes != 64 && !m->generic_ok) ? 64 : g_lanes), EPW = 64 / G;
   int grid = (b->db.B + EPW - 1) / EPW;
   size_t lds = (size_t)EPW * m->env_lds_bytes;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIPCHK(hipFuncSetAttribute((const void*)step_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)step_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)step_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)reach_obs_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+  {  // kernel attributes are per device: one flag per device ordinal for the lanes kernels and the reach observation kernel too
+    static std::mutex attr_g_mu;
+    static bool attr_g_dev[64] = {};
+    std::lock_guard<std::mutex> attr_g_lock(attr_g_mu);
+    bool& attr_set = attr_g_dev[m->device & 63];
+    if (!attr_set) {
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)step_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(hipFuncSetAttribute((const void*)reach_obs_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
   }
   long long* st = b->d_stamps;
 #if MYO_POISON

@@ -65,19 +65,34 @@ class _HostData:
         self.qacc = np.zeros((B, m.nv), np.float32)
 
 
+def _dev_tensor_type():
+    """torch.Tensor subclass of the device views: `view[idx] = <numpy array / list>` uploads the value, so the reference's
+    `sim.data.ctrl[:] = ctrl` (Robot.step, robot/robot.py:880-882, NumPy on its side) works unchanged on device-resident data."""
+    import torch
+
+    class _DevTensor(torch.Tensor):
+        def __setitem__(self, idx, val):
+            if not torch.is_tensor(val) and not np.isscalar(val):
+                val = torch.as_tensor(np.asarray(val), device=self.device).to(self.dtype)
+            super().__setitem__(idx, val)
+    return _DevTensor
+
+
 class _DeviceData:
     """`sim.data.*` as zero-copy torch views of the library's device buffers ([B, n] float32): reading / writing them IS reading / writing
-    the simulation state, like the reference's NumPy views of MjData -- no upload or download around `advance`."""
+    the simulation state, like the reference's NumPy views of MjData -- no upload or download around `advance`.  NumPy values may be
+    assigned into them (they are uploaded); reading gives torch tensors on the device."""
 
     def __init__(self, batch, B, device):
         import torch
         from .envs import _DevArray
         self._keep = batch
+        T = _dev_tensor_type()
 
         def view(field):
             ptr, pitch, width = batch.field_ptr(field)
             ts = "<i4" if field in capi.INT_FIELDS else "<f4"
-            return torch.as_tensor(_DevArray(ptr, (B, width), ts, batch), device=f"cuda:{device}")
+            return torch.as_tensor(_DevArray(ptr, (B, width), ts, batch), device=f"cuda:{device}").as_subclass(T)
         self.qpos, self.qvel, self.act, self.ctrl = view(capi.F_QPOS), view(capi.F_QVEL), view(capi.F_ACT), view(capi.F_CTRL)
         self.time, self.qacc, self.qacc_warmstart = view(capi.F_TIME), view(capi.F_QACC), view(capi.F_WARMSTART)
         self.actuator_length, self.actuator_force = view(capi.F_TENLEN), view(capi.F_ACTFORCE)
@@ -118,7 +133,8 @@ class HipSimScene:
         self.renderer = self._create_renderer(self.sim)
         self.init_qpos = np.asarray(self.model.qpos0, np.float64).copy()
         self.init_qvel = np.zeros(self.model.nv)
-        self.last_flags = np.zeros(self.num_envs, np.int32)
+        self._last_flags = np.zeros(self.num_envs, np.int32)
+        self._flags_stale = False
         self._dirty = not as_torch
         self._disabled = [0, 0, 0]
 
@@ -209,18 +225,29 @@ class HipSimScene:
     def advance(self, substeps: int = 1, render: bool = False):
         if self.as_torch:                      # device-resident: the controls and the state are already where the kernel reads them
             self._batch.step(None, capi.ACTMAP_NONE, int(substeps), self._stream())
+            self._flags_stale = True           # (in-kernel resets of bad states are reported when `last_flags` is next read: one device sync there)
             return
         if self._dirty:
             self._push_state()
         self._batch.write(capi.F_CTRL, self.data.ctrl)
         self._batch.step(None, capi.ACTMAP_NONE, int(substeps))
-        self.last_flags = self._batch.status()
+        self._last_flags = self._batch.status()
         self._pull_state()
 
+    @property
+    def last_flags(self):
+        """Per-env fault flags of the steps since they were last read (MYO_FLAG_*: envs whose state went bad were reset in place, like
+        DMSimScene.advance catching the physics error, mj_sim_scene.py:54-61).  Device-resident mode fetches them here, not inside advance."""
+        if getattr(self, "_flags_stale", False):
+            self._last_flags = self._last_flags | self._batch.status()
+            self._flags_stale = False
+        return self._last_flags
+
     def status(self):
-        """Per-env fault flags since the last call (device-resident mode does not poll them inside advance)."""
-        self.last_flags = self._batch.status()
-        return self.last_flags
+        """Per-env fault flags since the last call, then cleared."""
+        out = self.last_flags.copy()
+        self._last_flags = np.zeros(self.num_envs, np.int32)
+        return out
 
     def forward(self):
         """Derived quantities are recomputed inside every substep; state-only observations need no extra mj_forward."""

@@ -205,6 +205,31 @@ def test_hip_sim_scene_mirrors_the_backend_abc(hand, oracle64, as_torch, tmp_pat
     sim.close()
 
 
+def test_default_sim_scene_is_driven_with_numpy_like_robot_step(hand, oracle64):
+    """the default-constructed HipSimScene (device-resident data) must take the reference's own driving code unchanged --
+    Robot.step writes NumPy controls into `sim.data.ctrl` and calls `sim.advance` (robot/robot.py:880-882) -- and must not lose the report
+    of an in-kernel reset (`last_flags`, the counterpart of DMSimScene.advance's exception path, mj_sim_scene.py:54-61)."""
+    import myosuite_mjx_amd as myo
+    B = 4
+    sim = myo.HipSimScene("myohand_pose", num_envs=B)
+    rng = np.random.default_rng(2)
+    ctrl = rng.uniform(0, 1, (B, 39))                      # float64 NumPy, as the reference's robot hands it over
+    sim.data.ctrl[:] = ctrl
+    sim.data.ctrl[0, :3] = np.array([0.25, 0.5, 0.75])
+    ctrl[0, :3] = [0.25, 0.5, 0.75]
+    sim.advance(substeps=10)
+    assert (sim.last_flags == 0).all() and np.allclose(sim.data.ctrl.cpu().numpy(), ctrl.astype(np.float32))
+    oracle64.reset(); oracle64.set_state(ctrl=ctrl[1]); oracle64.step(10)
+    assert np.abs(oracle64.field("qpos") - sim.data.qpos[1].cpu().numpy()).max() < 1e-4
+    q = sim.data.qpos.cpu().numpy(); q[2, 5] = np.nan
+    sim.data.qpos[:] = q                                    # a NaN state: that env is reset inside the kernel ...
+    sim.advance(substeps=2)
+    fl = sim.last_flags                                     # ... and the reset is reported without an explicit status() call
+    assert fl[2] & 1 and (fl[[0, 1, 3]] == 0).all() and np.isfinite(sim.data.qpos.cpu().numpy()).all()
+    assert (sim.status()[2] & 1) and (sim.last_flags == 0).all()
+    sim.close()
+
+
 def test_every_registered_env_id_resets_steps_and_is_deterministic():
     """Counterpart of the reference's tests/test_myo.py -> test_envs.py loop over every registered id: construct, seed, reset, one
     small-action step (a = 0.01 * U like test_envs.py:61-64), shapes and finiteness, and the same seed twice gives the same obs / reward."""

@@ -436,3 +436,40 @@ def test_free_body_analytic_checks():
     f = o.field("efc_force")
     # pyramidal condim 3: the normal force is the sum of the four edge forces (the limit rows of the hand come first)
     assert abs(f[-4:].sum() - mass * 9.81) < 0.02 * mass * 9.81
+
+
+def test_legs_keyframes_all_fourteen_couplings_and_the_floor(legs):
+    """every keyframe of myolegs.xml against all 14 knee couplings (`polycoef`, both knees) and the floor.
+    What reproduces: keyframe 0 -- the one MuJoCo computed -- satisfies the seven RIGHT-knee polynomials to 4e-5, and its LEFT-knee values are
+    the right-knee values copied over: they satisfy the right polynomials to 4e-5 too, while two of the left polynomials (translation2,
+    rotation3) carry flipped signs and are missed by exactly twice the value.  Its feet rest on the floor (two contacts, 0.4-1.7 mm inside the
+    margin-free surface).  Keyframes 1-3 were edited by hand: feet off the floor (root height 0.9-1.0), couplings violated by up to 0.74 rad --
+    the equality rows pull them in during the first steps (tests/test_gpu_fullsize.py)."""
+    from oracle.oracle import Oracle
+    o = Oracle(legs.blob())
+    K = np.asarray(legs.key_qpos).reshape(-1, legs.nq)
+    assert K.shape[0] == 4 and int(legs.sizes[12]) == 14
+    poly = lambda a, x: a[0] + x * (a[1] + x * (a[2] + x * (a[3] + x * a[4])))
+    worst = []
+    for k in range(4):
+        q = K[k]
+        res, res_as_right = [], []
+        for e in range(14):
+            j1, j2 = legs.eq_obj1id[e], legs.eq_obj2id[e]
+            x = q[legs.jnt_qposadr[j2]]
+            res.append(q[legs.jnt_qposadr[j1]] - poly(legs.eq_data[e], x))
+            res_as_right.append(q[legs.jnt_qposadr[j1]] - poly(legs.eq_data[e % 7], x))
+        res, res_as_right = np.abs(res), np.abs(res_as_right)
+        o.reset(); o.set_state(qpos=q, qvel=np.zeros(legs.nv)); o.forward()
+        dist = np.array([c[0] for c in o.contacts()])
+        if k == 0:
+            assert res[:7].max() < 1e-4 and res_as_right.max() < 1e-4
+            off = np.where(res[7:] > 1e-3)[0]
+            assert sorted(legs.names["joint"][legs.eq_obj1id[7 + i]] for i in off) == ["knee_angle_l_rotation3", "knee_angle_l_translation2"]
+            for i in off:
+                assert abs(res[7 + i] - 2 * abs(q[legs.jnt_qposadr[legs.eq_obj1id[7 + i]]])) < 1e-4
+            assert o.ncon == 2 and -2e-3 < dist.min() and dist.max() < 0
+        else:
+            assert o.ncon == 0 and q[2] >= 0.9
+        worst.append(float(res.max()))
+    assert worst[0] < 0.28 and 0.4 < max(worst[1:]) < 0.75

@@ -1,8 +1,12 @@
 """Oracle-side checks of the physics MyoDM's TrackEnv model adds (myohand_object.xml + object_sim/airplane):
 joint friction loss, condim-4 (torsional) pyramids, box and convex-hull mesh contacts, position actuators on the 6-dof arm base.
 No reference goldens exist for dynamics: analytic expectations only -- parity unpinned."""
+import os
+
 import numpy as np
 import pytest
+
+from conftest import ROOT
 
 
 @pytest.fixture(scope="module")
@@ -111,3 +115,35 @@ def test_position_actuators_hold_the_arm(track):
     for _ in range(400):
         assert o.step(5) == 0
     assert abs(o.field("qpos")[0] - 0.05) < 5e-3
+
+
+def test_resting_height_of_the_objects_against_every_motion_file():
+    """The only contact-statics golden the reference holds: each motion file starts with the object lying on the table,
+    at a height MuJoCo settled it to (`object_init` z; tests/golden/myodm_motion_inits.json holds the initial postures of all 95 files, copied
+    from envs/myo/myodm/data/*.npz).  The oracle, started from that pose, must keep the object there: measured 0.5-0.7 mm lower for both
+    compiled objects, on all six of their motion files (airplane -0.0098 -> -0.0104, cup +0.0161 -> +0.0156), i.e. contact softness level."""
+    import json
+    from myosuite_mjx_amd import model as M
+    from myosuite_mjx_amd.track import quat2euler
+    from oracle.oracle import Oracle
+    inits = json.load(open(os.path.join(ROOT, "tests", "golden", "myodm_motion_inits.json")))
+    assert len(inits) == 95
+    seen = 0
+    for obj in ("airplane", "cup"):
+        m = M.load_asset(f"myohand_object_{obj}")
+        o = Oracle(m.blob())
+        for stem, v in inits.items():
+            if f"_{obj}_" not in stem:
+                continue
+            oi = np.array(v["object_init"])
+            q = np.array(m.qpos0, float)
+            q[:29], q[29:32], q[32:35] = v["robot_init"], oi[:3], quat2euler(oi[3:])
+            ctrl = np.zeros(m.nu); ctrl[:6] = q[:6]                 # the arm base holds its pose (position actuators), muscles relaxed
+            o.reset(); o.set_state(qpos=q, qvel=np.zeros(m.nv), ctrl=ctrl)
+            assert o.step(150) == 0
+            z = o.field("qpos")[31]
+            assert o.ncon >= 3 and -1.0e-3 < z - oi[2] < -2.0e-4, (stem, oi[2], z)       # rests on the table, 0.2-1 mm below MuJoCo's height
+            v = np.abs(o.field("qvel")[29:35])
+            assert v[:3].max() < 1e-2 and v[3:].max() < 0.3, stem                        # ... and (but for a last bit of rocking) at rest
+            seen += 1
+    assert seen == 6
