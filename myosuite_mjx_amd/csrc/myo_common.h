@@ -134,11 +134,14 @@ struct DevBatch {
   float* ovf;              // [B][NCX][ovf_row] floats: dist, pos[3], normal[3], pair id, cJ[3 * KC], dof ids (byte-packed)
   int* ovf_cand;           // [B][NCANDX]
   int ovf_row;             // floats per overflow row (0: no overflow storage, the LDS table is the capacity)
+  int ovf_rows;            // rows per env: NCX, or NCX2 for the TRK models whose contacts 64 .. 127 form a second bank (one lane carries two contacts)
   float* linkx;            // [B][12 * nl] link frames of the last substep's position stage (TRK models; NULL otherwise)
   const DevTrack* track;   // MYO_TASK_TRACK configured (TRK models): prologue / epilogue of the step kernel; NULL otherwise
   int env_offset;          // global id of env 0 (RNG streams are keyed by global env id)
 };
-#define NCX 48      // overflow contact rows ALLOCATED per env; a kernel with NC LDS slots uses 64 - NC of them: 64 contacts in all, one per lane
+#define NCX 48      // overflow contact rows ALLOCATED per env; a kernel with NC LDS slots uses 64 - NC of them: 64 contacts in all
+#define NCX2 96     // TRK models: 128 contacts, 32 in LDS + 96 rows; rows of the second bank also hold that contact's solver state
+#define TRK_STATE 36  // floats of solver state at the end of a TRK overflow row: aref[6] | D mu mu_t D_t kc | jar[6] | jv[6] | 4 force + 7 Hessian coefficients | active-set word | pad, one per lane
 #define NCANDX 256  // overflow candidates per env (MyoHand has 289 pairs: NCAND + NCANDX covers every pair)
 
 struct TaskDev {

@@ -456,12 +456,13 @@ int myo_batch_create(const myo_model* m, int B, myo_batch** out) {
   BA(b->d_action, (size_t)B * nu)
   BA(d.fatigue, (size_t)B * 3 * nu)
   d.hfield = nullptr; d.gsize = nullptr; d.gsize_cg = -1;
-  d.ovf = nullptr; d.ovf_cand = nullptr; d.ovf_row = 0; d.linkx = nullptr; d.track = nullptr; d.env_offset = 0;
+  d.ovf = nullptr; d.ovf_cand = nullptr; d.ovf_row = 0; d.ovf_rows = 0; d.linkx = nullptr; d.track = nullptr; d.env_offset = 0;
   if (m->trk) { BA(d.linkx, (size_t)B * 12 * m->dm.nl) }
   if (m->wave_ok) {   // contact-table overflow rows of the wave kernel (instantiations <24,8,...> and <36,20,...>)
     const int kc = m->wave_cfg == 0 ? 8 : 20, nj = m->trk ? 4 : 3;
-    d.ovf_row = 8 + nj * kc + (kc + 3) / 4;
-    BA(d.ovf, (size_t)B * NCX * d.ovf_row) BA(d.ovf_cand, (size_t)B * NCANDX)
+    d.ovf_row = 8 + nj * kc + (kc + 3) / 4 + (m->trk ? TRK_STATE : 0);
+    d.ovf_rows = m->trk ? NCX2 : NCX;
+    BA(d.ovf, (size_t)B * d.ovf_rows * d.ovf_row) BA(d.ovf_cand, (size_t)B * NCANDX)
   }
   if (m->dw.hf.on) { BA(d.hfield, (size_t)B * m->dw.hf.nrow * m->dw.hf.ncol) }   // zero-filled: flat terrain at the geom's height
   BA(b->d_initv, nv) BA(b->d_init2, nq) BA(b->d_initv2, nv) BA(b->d_fatvec, nu)

@@ -541,8 +541,9 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   };
   // contacts NC .. NC + NCX - 1 live in this env's HBM overflow rows [dist, pos3, normal3, pair, cJ[3 KC], dof words]; lane = contact still holds
   // for all 64.  The first NC contacts (all of them for > 99.5 % of the states) never leave LDS.
-  constexpr int NCXK = (64 - NC) < NCX ? (64 - NC) : NCX;   // overflow rows this instantiation uses: one lane per contact, 64 in all
-  float* const ovf_env = Bt.ovf ? Bt.ovf + (size_t)env * NCX * Bt.ovf_row : nullptr;
+  // TRK: a second bank of 64 (contacts 64 .. 127: lane = contact - 64), whose per-contact solver state lives in the contact's row as well
+  constexpr int NCXK = TRK ? (128 - NC) : ((64 - NC) < NCX ? (64 - NC) : NCX);   // overflow rows this instantiation uses
+  float* const ovf_env = Bt.ovf ? Bt.ovf + (size_t)env * Bt.ovf_rows * Bt.ovf_row : nullptr;
   const int ovf_row = Bt.ovf_row;
   const int nct = ovf_env ? NC + NCXK : NC;
   // narrow-phase round width: the MPR's per-lane LDS scratch (9 floats) lives in the contact-jacobian area, which holds 64 lanes' worth only
@@ -1438,6 +1439,17 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     for (int k = 0; k < NR; k++) caref[k] = 0.f;
     float cmut = 0.f, cD2 = 0.f;   // TRK: torsional coefficient and the weight of the two torsional rows (0 for a condim-3 contact)
     int ckc = 0;
+    // TRK, more than 64 contacts: contact c in [64, 128) belongs to lane c - 64 ("second bank").  Its per-contact solver state -- what bank 0
+    // keeps in the registers above -- lives in a block at the end of the contact's overflow row, is loaded where a stage needs it and stored
+    // back; loops over (contact, dof slot) read a bank-1 contact's coefficients from that block instead of shuffling them out of registers.
+    // Everything of it sits behind `bank1` (wave-uniform, ncon > 64): the common case pays a scalar test per stage.
+    constexpr int ROWS = 8 + NJ * KC + CDW;      // offset of the state block in an overflow row
+    enum { S_AREF = 0, S_D = NR, S_MU = NR + 1, S_MUT = NR + 2, S_D2 = NR + 3, S_KC = NR + 4, S_JAR = NR + 5, S_JV = 2 * NR + 5, S_FC = 3 * NR + 5, S_HC = 3 * NR + 9, S_SIG = 3 * NR + 16 };
+    static_assert(!TRK || 3 * NR + 17 <= TRK_STATE, "state block of a second-bank contact");
+    const bool bank1 = TRK && ncon > 64;
+    auto st1 = [&](int c) -> float* { return ovf_env + (size_t)(c - NC) * ovf_row + ROWS; };
+    const bool b1lane = bank1 && lane + 64 < ncon;   // this lane also owns a bank-1 contact
+    int nefc_b1 = 0;
     // (generic lambda: instantiated once with LDS pointers and once with the HBM overflow row, so that each copy keeps its own address space)
     auto build_row = [&](const float* pdist, const float* ppos, const float* pnrm, const int* ppair, float* cJ, unsigned int* cdw) {
       int p = ppair[0];
@@ -1570,6 +1582,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       // velocity sums of a contact meet in LDS atomics on the (still unused) search-vector scratch
       const int rg = lane / KC, rk = lane - rg * KC;
       float vn_c = 0.f, vt1_c = 0.f, vt2_c = 0.f, vs_c = 0.f;
+      float vn_1 = 0.f, vt1_1 = 0.f, vt2_1 = 0.f, vs_1 = 0.f;   // (TRK: the lane's bank-1 contact)
       for (int c0 = 0; c0 < ncon; c0 += 3) {
         if (lane < 12) E[Y.xv + lane] = 0.f;
         SYNC();
@@ -1617,9 +1630,15 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         }
         SYNC();
         if (lane >= c0 && lane < c0 + 3) { const int g = lane - c0; vn_c = E[Y.xv + 4 * g]; vt1_c = E[Y.xv + 4 * g + 1]; vt2_c = E[Y.xv + 4 * g + 2]; vs_c = E[Y.xv + 4 * g + 3]; }
+        if constexpr (TRK) {
+          if (b1lane && lane + 64 >= c0 && lane + 64 < c0 + 3) { const int g = lane + 64 - c0; vn_1 = E[Y.xv + 4 * g]; vt1_1 = E[Y.xv + 4 * g + 1]; vt2_1 = E[Y.xv + 4 * g + 2]; vs_1 = E[Y.xv + 4 * g + 3]; }
+        }
         SYNC();
       }
-      if (lane < ncon) {
+      // row constants of contact c from its velocity sums (lane = contact & 63)
+      auto row_consts = [&](const int cc, const float vn_c, const float vt1_c, const float vt2_c, const float vs_c, float (&caref)[NR], float& cD, float& cmu, float& cmut,
+                            float& cD2, int& ckc) {
+        const int lane = cc;     // (the body below is the one-bank code: it indexes the contact tables with `lane`)
         const float* g = lane < NC ? nullptr : ovf_env + (lane - NC) * ovf_row;
         const int p = lane < NC ? ((const int*)(E + Y.cpair))[lane] : ((const int*)g)[7];
         const float dist = lane < NC ? E[Y.cdist + lane] : g[0];
@@ -1644,6 +1663,21 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         if constexpr (TRK) {
           if (P[5] == 4) { cmut = F[11]; cD2 = cD; caref[4] = -B * (vn_c + cmut * vs_c) + pos; caref[5] = -B * (vn_c - cmut * vs_c) + pos; }
         }
+      };
+      if (lane < ncon) row_consts(lane, vn_c, vt1_c, vt2_c, vs_c, caref, cD, cmu, cmut, cD2, ckc);
+      if constexpr (TRK) {
+        float a1[NR], D1 = 0.f, mu1 = 0.f, mut1 = 0.f, D21 = 0.f;
+        int kc1 = 0;
+#pragma unroll
+        for (int k = 0; k < NR; k++) a1[k] = 0.f;
+        if (b1lane) {
+          row_consts(lane + 64, vn_1, vt1_1, vt2_1, vs_1, a1, D1, mu1, mut1, D21, kc1);
+          float* S = st1(lane + 64);
+#pragma unroll
+          for (int k = 0; k < NR; k++) S[S_AREF + k] = a1[k];
+          S[S_D] = D1; S[S_MU] = mu1; S[S_MUT] = mut1; S[S_D2] = D21; ((int*)S)[S_KC] = kc1; ((int*)S)[S_SIG] = -1;
+        }
+        if (bank1) nefc_b1 = 2 * __popcll(__ballot(b1lane && D21 != 0.f)) - 3 * __popcll(__ballot(b1lane && mu1 == 0.f));
       }
     } else
     if (lane < ncon) {
@@ -1657,6 +1691,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     float flf = 0.f, flD = 0.f, flaref = 0.f, fljar = 0.f, fljv = 0.f, flrf = 0.f;
     if constexpr (TRK) {
       nefc += 2 * __popcll(__ballot(lane < ncon && cD2 != 0.f));
+      nefc += nefc_b1;
       if (lane < nv) {
         const float* FL = W.fl + 4 * lane;
         flf = FL[0];
@@ -1693,8 +1728,10 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       }
       unsigned long long bal = __ballot(tact);
       int slot = nt + __popcll(bal & ((1ull << lane) - 1ull));
-      if (tact && slot < NC) {
-        float* cJ = E + Y.cJ + slot * NJ * KC;
+      const int ntcap = min(nct, 64);     // tendon-limit rows share the 64 lanes with the contacts; slots beyond the LDS table live in the overflow rows like contacts
+      if (tact && slot < ntcap) {
+        float* const row = slot < NC ? nullptr : ovf_env + (slot - NC) * ovf_row;
+        float* cJ = slot < NC ? E + Y.cJ + slot * NJ * KC : row + 8;
         unsigned int dpk[CDW];
 #pragma unroll
         for (int k = 0; k < CDW; k++) dpk[k] = 0;
@@ -1708,18 +1745,23 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           if constexpr (TRK) cJ[3 * KC + k] = 0.f;
           dpk[k >> 2] |= (unsigned int)d << (8 * (k & 3));
         }
+        unsigned int* const dw = slot < NC ? (unsigned int*)(E + Y.cdofs) + CDW * slot : (unsigned int*)(row + 8 + NJ * KC);
 #pragma unroll
-        for (int k = 0; k < CDW; k++) ((unsigned int*)(E + Y.cdofs))[CDW * slot + k] = dpk[k];
-        E[Y.cdist + slot] = t_aref; E[Y.cpos + 3 * slot] = t_D; E[Y.cpos + 3 * slot + 1] = (float)kc;
+        for (int k = 0; k < CDW; k++) dw[k] = dpk[k];
+        if (slot < NC) { E[Y.cdist + slot] = t_aref; E[Y.cpos + 3 * slot] = t_D; E[Y.cpos + 3 * slot + 1] = (float)kc; }
+        else { row[0] = t_aref; row[1] = t_D; row[2] = (float)kc; }
       }
       nt += __popcll(bal);
       }
-      if (nt > NC) { flags |= MYO_FLAG_CONTACT_OVERFLOW; nt = NC; if (ncon > NC) ncon = NC; }   // (tendon-limit rows use LDS slots only: the models that have them have < 10 geoms)
+      // only a tendon-limit row that found no slot is a loss (a has_tl model with more than NC contacts used to be cut back to NC
+      // and flagged even when no tendon limit was active)
+      if (nt > min(nct, 64)) { flags |= MYO_FLAG_CONTACT_OVERFLOW; nt = min(nct, 64); }
       SYNC();
       if (lane >= ncon && lane < nt) {
-        float a = E[Y.cdist + lane];
+        const float* const row = lane < NC ? nullptr : ovf_env + (lane - NC) * ovf_row;
+        const float a = lane < NC ? E[Y.cdist + lane] : row[0];
         caref[0] = caref[1] = caref[2] = caref[3] = a;   // (TRK: cD2 stays 0 for these rows)
-        cD = 0.25f * E[Y.cpos + 3 * lane]; cmu = 0.f; ckc = (int)E[Y.cpos + 3 * lane + 1];
+        cD = 0.25f * (lane < NC ? E[Y.cpos + 3 * lane] : row[1]); cmu = 0.f; ckc = (int)(lane < NC ? E[Y.cpos + 3 * lane + 1] : row[2]);
       }
       nefc += nt - ncon;
       ncon = nt;
@@ -1783,6 +1825,18 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         if (lane < NC) row_jar(E + Y.cJ + lane * NJ * KC, (const unsigned int*)(E + Y.cdofs) + CDW * lane);
         else { const float* g = ovf_env + (lane - NC) * ovf_row; row_jar(g + 8, (const unsigned int*)(g + 8 + NJ * KC)); }
       }
+      if constexpr (TRK) {
+        if (b1lane) {   // J * warm - aref of the lane's bank-1 contact, into its state block
+          const float* g = ovf_env + (lane + 64 - NC) * ovf_row;
+          const unsigned int* cdw = (const unsigned int*)(g + 8 + NJ * KC);
+          float* S = st1(lane + 64);
+          float an = 0, a1 = 0, a2 = 0, a3 = 0;
+          for (int k = 0; k < KC; k++) { const float xv = E[Y.xv + CDOFP(cdw, k)]; an += g[8 + k] * xv; a1 += g[8 + KC + k] * xv; a2 += g[8 + 2 * KC + k] * xv; a3 += g[8 + 3 * KC + k] * xv; }
+          const float mu = S[S_MU], mut = S[S_MUT];
+          S[S_JAR] = an + mu * a1 - S[S_AREF]; S[S_JAR + 1] = an - mu * a1 - S[S_AREF + 1]; S[S_JAR + 2] = an + mu * a2 - S[S_AREF + 2]; S[S_JAR + 3] = an - mu * a2 - S[S_AREF + 3];
+          S[S_JAR + 4] = an + mut * a3 - S[S_AREF + 4]; S[S_JAR + 5] = an - mut * a3 - S[S_AREF + 5];
+        }
+      }
       if (eact) ejar = E[Y.xv + ed1] + eJ2 * E[Y.xv + ed2] - earef;
     }
     SUB(6);
@@ -1809,6 +1863,29 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             else { flforce = -flD * fljar; flcost = 0.5f * flD * fljar * fljar; flquad = true; }
           }
         }
+        float cst_b1 = 0.f;      // TRK second bank: cost of the lane's bank-1 contact; its force / Hessian coefficients go to its state block
+        bool sig_b1_changed = false;
+        if constexpr (TRK) {
+          if (b1lane) {
+            float* S = st1(lane + 64);
+            const float D = S[S_D], D2 = S[S_D2], mu = S[S_MU], mut = S[S_MUT];
+            float w[NR], f[NR];
+            int sg = 0;
+#pragma unroll
+            for (int k = 0; k < NR; k++) {
+              const float jr = S[S_JAR + k];
+              w[k] = jr < 0 ? (k < 4 ? D : D2) : 0.f;
+              f[k] = -w[k] * jr;
+              cst_b1 += 0.5f * w[k] * jr * jr;
+              sg |= (w[k] != 0.f ? 2 : 0) << k;
+            }
+            S[S_FC] = f[0] + f[1] + f[2] + f[3] + f[4] + f[5]; S[S_FC + 1] = mu * (f[0] - f[1]); S[S_FC + 2] = mu * (f[2] - f[3]); S[S_FC + 3] = mut * (f[4] - f[5]);
+            S[S_HC] = w[0] + w[1] + w[2] + w[3] + w[4] + w[5]; S[S_HC + 1] = mu * (w[0] - w[1]); S[S_HC + 2] = mu * (w[2] - w[3]);
+            S[S_HC + 3] = mu * mu * (w[0] + w[1]); S[S_HC + 4] = mu * mu * (w[2] + w[3]); S[S_HC + 5] = mut * (w[4] - w[5]); S[S_HC + 6] = mut * mut * (w[4] + w[5]);
+            sig_b1_changed = ((const int*)S)[S_SIG] != sg;
+            ((int*)S)[S_SIG] = sg;
+          }
+        }
         if (lane < nv) E[Y.qfc + lane] = (lact ? -lsign * lD * ljar : 0.f) + flforce;
         SYNC();
         if constexpr (KC == 8 || TRK) {
@@ -1821,8 +1898,11 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             const int c = c0 + fg;
             const bool on = fg < FG && c < ncon;
             const int cs = on ? c : 0;
-            const float sFn = __shfl(Fn, cs), sF1 = __shfl(Ft1, cs), sF2 = __shfl(Ft2, cs), sF3 = TRK ? __shfl(Ft3, cs) : 0.f;
-            const int kc = __shfl(ckc, cs);
+            float sFn = __shfl(Fn, cs & 63), sF1 = __shfl(Ft1, cs & 63), sF2 = __shfl(Ft2, cs & 63), sF3 = TRK ? __shfl(Ft3, cs & 63) : 0.f;
+            int kc = __shfl(ckc, cs & 63);
+            if constexpr (TRK) {
+              if (on && c >= 64) { const float* S = st1(c); sFn = S[S_FC]; sF1 = S[S_FC + 1]; sF2 = S[S_FC + 2]; sF3 = S[S_FC + 3]; kc = ((const int*)S)[S_KC]; }
+            }
             if (on && fk < kc) {
               if (c < NC) {
                 const float* cJ = E + Y.cJ + c * NJ * KC;
@@ -1851,7 +1931,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         float cst = lact ? 0.5f * lD * ljar * ljar : 0.f;
         cst += 0.5f * eD * ejar * ejar;
         cst += 0.5f * (w0 * cjar[0] * cjar[0] + w1 * cjar[1] * cjar[1] + w2 * cjar[2] * cjar[2] + w3 * cjar[3] * cjar[3]);
-        if constexpr (TRK) cst += 0.5f * (w4 * cjar[4] * cjar[4] + w5 * cjar[5] * cjar[5]) + flcost;
+        if constexpr (TRK) cst += 0.5f * (w4 * cjar[4] * cjar[4] + w5 * cjar[5] * cjar[5]) + flcost + cst_b1;
         cst += 0.5f * qacc * Ma - qacc * smooth;          // Gauss term up to a constant
         float newcost = wave_sum(cst);
         grad = Ma - smooth - qfc;
@@ -1873,7 +1953,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           // H = M + J^T D J depends on the state only through the set of active rows: same set as last time -> same factor
           const int sig = (lact ? 1 : 0) | (w0 != 0.f ? 2 : 0) | (w1 != 0.f ? 4 : 0) | (w2 != 0.f ? 8 : 0) | (w3 != 0.f ? 16 : 0) |
                           (TRK ? ((w4 != 0.f ? 32 : 0) | (w5 != 0.f ? 64 : 0) | (flquad ? 128 : 0)) : 0);
-          refactor = first || __any(sig != sig_prev);
+          refactor = first || __any(sig != sig_prev || sig_b1_changed);
           sig_prev = sig;
           if (refactor) {
             f_fact++;
@@ -1894,9 +1974,15 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
                 const int c = c0 + hg;
                 const bool on = hg < HG && c < ncon;
                 const int cs = on ? c : 0;
-                const float sW = __shfl(Wn, cs), sA1 = __shfl(A1, cs), sA2 = __shfl(A2, cs), sB1 = __shfl(B1, cs), sB2 = __shfl(B2, cs);
-                const float sA3 = TRK ? __shfl(A3, cs) : 0.f, sB3 = TRK ? __shfl(B3, cs) : 0.f;
-                const int kc = __shfl(ckc, cs);
+                float sW = __shfl(Wn, cs & 63), sA1 = __shfl(A1, cs & 63), sA2 = __shfl(A2, cs & 63), sB1 = __shfl(B1, cs & 63), sB2 = __shfl(B2, cs & 63);
+                float sA3 = TRK ? __shfl(A3, cs & 63) : 0.f, sB3 = TRK ? __shfl(B3, cs & 63) : 0.f;
+                int kc = __shfl(ckc, cs & 63);
+                if constexpr (TRK) {
+                  if (on && c >= 64) {
+                    const float* S = st1(c);
+                    sW = S[S_HC]; sA1 = S[S_HC + 1]; sA2 = S[S_HC + 2]; sB1 = S[S_HC + 3]; sB2 = S[S_HC + 4]; sA3 = S[S_HC + 5]; sB3 = S[S_HC + 6]; kc = ((const int*)S)[S_KC];
+                  }
+                }
                 if (on && sW != 0.f && ha < kc) {
                   auto hrow = [&](const float* cJ, const unsigned int* cdw) {
                     const int da = CDOFP(cdw, ha);
@@ -2011,6 +2097,17 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         if (lane < NC) row_jv(E + Y.cJ + lane * NJ * KC, (const unsigned int*)(E + Y.cdofs) + CDW * lane);
         else { const float* g = ovf_env + (lane - NC) * ovf_row; row_jv(g + 8, (const unsigned int*)(g + 8 + NJ * KC)); }
       }
+      if constexpr (TRK) {
+        if (b1lane) {   // J * search of the lane's bank-1 contact, into its state block
+          const float* g = ovf_env + (lane + 64 - NC) * ovf_row;
+          const unsigned int* cdw = (const unsigned int*)(g + 8 + NJ * KC);
+          float* S = st1(lane + 64);
+          float an = 0, a1 = 0, a2 = 0, a3 = 0;
+          for (int k = 0; k < KC; k++) { const float xv = E[Y.xv + CDOFP(cdw, k)]; an += g[8 + k] * xv; a1 += g[8 + KC + k] * xv; a2 += g[8 + 2 * KC + k] * xv; a3 += g[8 + 3 * KC + k] * xv; }
+          const float mu = S[S_MU], mut = S[S_MUT];
+          S[S_JV] = an + mu * a1; S[S_JV + 1] = an - mu * a1; S[S_JV + 2] = an + mu * a2; S[S_JV + 3] = an - mu * a2; S[S_JV + 4] = an + mut * a3; S[S_JV + 5] = an - mut * a3;
+        }
+      }
       if (eact) ejv = E[Y.xv + ed1] + eJ2 * E[Y.xv + ed2];
       float g1 = wave_sum(search * (Ma - smooth)), g2 = wave_sum(0.5f * search * Mv), sn = sqrtf(wave_sum(search * search));
       SUB(4);
@@ -2031,6 +2128,12 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             if (xx <= -flrf) p1 -= flf * fljv;
             else if (xx >= flrf) p1 += flf * fljv;
             else { p1 += flD * xx * fljv; p2 += flD * fljv * fljv; }
+          }
+          if (b1lane) {   // (state block re-read per evaluation: a handful of L2 hits on a path that exists for > 64 contacts only)
+            const float* S = st1(lane + 64);
+            const float D = S[S_D], D2 = S[S_D2];
+#pragma unroll
+            for (int k = 0; k < NR; k++) { const float jv = S[S_JV + k], xx = S[S_JAR + k] + a * jv, Dk = k < 4 ? D : D2; if (xx < 0) { p1 += Dk * xx * jv; p2 += Dk * jv * jv; } }
           }
         }
         const float sp1 = wave_sum(p1);
@@ -2068,6 +2171,13 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       if constexpr (TRK) fljar += alpha * fljv;
 #pragma unroll
       for (int k = 0; k < NR; k++) cjar[k] += alpha * cjv[k];
+      if constexpr (TRK) {
+        if (b1lane) {
+          float* S = st1(lane + 64);
+#pragma unroll
+          for (int k = 0; k < NR; k++) S[S_JAR + k] += alpha * S[S_JV + k];
+        }
+      }
     }
     STAMP(7);
     d_nefc = nefc; d_ncon = ncon_real; d_iter = max(d_iter, iters);
