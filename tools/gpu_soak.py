@@ -1,6 +1,6 @@
 """Soak run on the GPU box: long rollouts of the main envs at full batch with U(-1,1) actions and auto-reset, counting every per-env fault
 flag (bad state / bad qacc resets, contact or candidate table overflows, scheduler time-outs) and checking the final states.
-Writes gpurun_out/r2_soak.json (copy to profiles/)."""
+Writes gpurun_out/r3_soak.json (copy to profiles/)."""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -60,4 +60,4 @@ try:
 except ImportError:
     pass
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open(os.path.join("gpurun_out", "r2_soak.json"), "w"), indent=1)
+json.dump(out, open(os.path.join("gpurun_out", "r3_soak.json"), "w"), indent=1)
