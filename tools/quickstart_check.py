@@ -12,8 +12,8 @@ np.savez("/tmp/policy.npz", obs_mean=np.zeros(108, np.float32), obs_std=np.ones(
          **{f"w{i}": rng.normal(0, 0.1, (sizes[i], sizes[i+1])).astype(np.float32) for i in range(5)}, **{f"b{i}": np.zeros(sizes[i+1], np.float32) for i in range(5)})
 policy = myo.BraxPolicy.from_npz("/tmp/policy.npz")
 policy.act(obs.data_ptr(), 4096, act.data_ptr(), deterministic=False, seed=1, step=0)
-from myosuite_mjx_amd.track import TrackEnv
-tenv = TrackEnv(num_envs=4096, seed=0); tobs = tenv.reset()
-tobs, trew, tdone, tinfo = tenv.step(torch.rand((4096, tenv.act_dim), device="cuda") * 2 - 1)
+tenv = myo.make("MyoHandAirplaneRandom-v0", num_envs=4096)
+tobs = tenv.reset()
+tobs, trew, tterm, ttrunc, tinfo = tenv.step(torch.rand((4096, tenv.act_dim), device="cuda") * 2 - 1)
 torch.cuda.synchronize()
 print("quickstart ok", obs.shape, qpos.shape, float(act.abs().max()), tobs.shape, float(trew.mean()))
