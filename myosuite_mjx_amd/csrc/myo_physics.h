@@ -59,7 +59,12 @@ __device__ float wrap_circle(float* pnt, const float* d, const float* sd, bool h
 // every substep (the library calls carry range reduction and special cases this solve never needs: asinf ~30, sincosf ~45 instructions).
 // asin on [0, 1]: pi/2 - sqrt(1 - x) P7(x) (Abramowitz & Stegun 4.4.46, |error| <= 2e-8 before float rounding); sin / cos on [0, pi/2]:
 // the single-precision minimax polynomials on [0, pi/4] with the complement swap above pi/4.  The solve stops at |f| <= 1e-6.
+// -DMYO_EXACT_TRIG=1 (A/B build, tools/gpu_trig_ab.py): the library functions instead, to attribute parity drift to these forms
+#ifndef MYO_EXACT_TRIG
+#define MYO_EXACT_TRIG 0
+#endif
 __device__ __forceinline__ float asin01f(float x) {
+  if (MYO_EXACT_TRIG) return asinf(fminf(x, 1.f));
   float p = -0.0012624911f;
   p = p * x + 0.0066700901f; p = p * x - 0.0170881256f; p = p * x + 0.0308918810f; p = p * x - 0.0501743046f;
   p = p * x + 0.0889789874f; p = p * x - 0.2145988016f; p = p * x + 1.5707963050f;
@@ -70,6 +75,7 @@ __device__ __forceinline__ float acos11f(float x) {       // acos on [-1, 1]
   return x >= 0.f ? 1.57079632679f - a : 1.57079632679f + a;
 }
 __device__ __forceinline__ void sincos_q1f(float th, float* sn, float* cs) {   // th in [0, pi/2]
+  if (MYO_EXACT_TRIG) { sincosf(th, sn, cs); return; }
   const bool hi = th > 0.785398163f;
   const float r = hi ? 1.57079632679f - th : th, z = r * r;
   const float s = r + r * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));

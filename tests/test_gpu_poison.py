@@ -1,10 +1,11 @@
 """The parity tests once more against the -DMYO_POISON=1 build of the same sources (libmyo_hip_poison.so, built by
-__graft_entry__.build()): every word of an env's LDS slice starts as a NaN there, and a helper kernel fills the private (scratch) memory of
-every wave slot with NaNs before each step launch.  A read of an LDS word the launch never wrote, a register spill stored under a partial
-exec mask and reloaded under a wider one, or a kernel whose addressing went wrong (as two variants of the kinematics pass did in round 2,
-order-dependently and without any plain test noticing reliably) then turns into wrong numbers or flagged envs instead of passing on
-whatever earlier workgroups and kernels left behind.  Runs in a child process because
-the library is chosen when it is first loaded (MYO_HIP_LIB)."""
+__graft_entry__.build()): every word of an env's LDS slice starts as a NaN there, and before each step launch helper kernels fill the private
+(scratch) memory of every wave slot, ALL vector registers of every SIMD and the scalar registers with NaN patterns (MYO_POISON_MODE, default 7).
+A read of an LDS word, a scratch word or a register (lane) that the launch never wrote then turns into wrong numbers or flagged envs instead
+of passing on whatever earlier workgroups and kernels left behind -- which is what two code shapes of round 2 did, order-dependently and
+without any plain test noticing reliably; round 3 reproduced one of them and traced it to the contents of the vector register file
+(profiles/r3_badshape_repro.txt).  Runs in a child process because the library is chosen when it is first loaded
+(MYO_HIP_LIB)."""
 import os
 import subprocess
 import sys
@@ -15,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_parity_suites_pass_on_the_lds_poisoned_build():
+def test_parity_suites_pass_on_the_poisoned_build():
     lib = os.path.join(ROOT, "myosuite_mjx_amd", "libmyo_hip_poison.so")
     assert os.path.exists(lib), "libmyo_hip_poison.so is missing: run __graft_entry__.build()"
     env = dict(os.environ, MYO_HIP_LIB=lib)
