@@ -99,16 +99,27 @@ class Model:
         arrays["integrator"] = np.array([1 if name == "RK4" else 0], np.int32)
         return Model(arrays, self.names, self.source)
 
-    def save(self, stem):
-        with open(stem + ".myob", "wb") as f:
-            f.write(self.blob())
+    def save(self, stem, compress=False):
+        """MYOB blob + JSON name side-car.  compress=True writes `<stem>.myob.gz` (the hull vertex graphs of the MyoDM objects shrink ~6x)."""
+        if compress:
+            import gzip
+            with open(stem + ".myob.gz", "wb") as raw, gzip.GzipFile(fileobj=raw, mode="wb", compresslevel=9, mtime=0) as f:
+                f.write(self.blob())
+        else:
+            with open(stem + ".myob", "wb") as f:
+                f.write(self.blob())
         with open(stem + ".json", "w") as f:
             json.dump({"names": self.names, "source": os.path.basename(self.source)}, f)
 
     @classmethod
     def load(cls, stem):
-        with open(stem + ".myob", "rb") as f:
-            b = f.read()
+        if os.path.exists(stem + ".myob"):
+            with open(stem + ".myob", "rb") as f:
+                b = f.read()
+        else:
+            import gzip
+            with gzip.open(stem + ".myob.gz", "rb") as f:
+                b = f.read()
         with open(stem + ".json") as f:
             meta = json.load(f)
         m = cls(_blob.unpack(b), meta["names"], meta.get("source", ""))
@@ -136,6 +147,6 @@ _ASSETS = {"myohand_pose": "myohand_pose", "myofinger_v0": "myofinger_v0", "myol
 def load_asset(name) -> Model:
     """Load a committed compiled model by stem (e.g. 'myohand_pose')."""
     stem = os.path.join(ASSET_DIR, name)
-    if not os.path.exists(stem + ".myob"):
+    if not (os.path.exists(stem + ".myob") or os.path.exists(stem + ".myob.gz")):
         raise FileNotFoundError(f"compiled model {name!r} not found under {ASSET_DIR}; run tools/compile_models.py")
     return Model.load(stem)

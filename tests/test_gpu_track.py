@@ -257,3 +257,53 @@ def test_a_second_myodm_object_cup():
         obs, reward, done, info = env.step(torch.rand((64, env.act_dim), device="cuda", generator=gen) * 2 - 1)
         assert torch.isfinite(obs).all() and torch.isfinite(reward).all()
     assert (env.status() == 0).all()
+
+
+@pytest.mark.parametrize("obj", ["apple", "cubesmall", "duck", "mug", "hammer", "bowl"])
+def test_more_myodm_objects_are_assets_only(obj):
+    """VERDICT r2 missing-4: "more MyoDM objects = more compiled assets, no new code" on six further objects of simhive/object_sim, one per shape family
+    (tools/compile_models.py; hulls of 16 .. 2 400 vertices, 37 .. 50 collision geoms, up to 1 030 candidate pairs).  (1) physics parity with the
+    oracle on twelve frames of one of the object's own motions (tests/golden/myodm_grasp_frames.npz: rows copied from the reference's
+    envs/myo/myodm/data/<motion>.npz), same criteria as for the airplane; (2) the registered id steps through `myo.make` without a flag."""
+    import torch
+    import myosuite_mjx_amd as myo
+    from myosuite_mjx_amd import capi, model as M, track as T
+    m = M.load_asset(f"myohand_object_{obj}")
+    hm = capi.HipModel(m.blob(), 0)
+    f = np.load(os.path.join(ROOT, "tests", "golden", "myodm_grasp_frames.npz"))
+    R, O = f[obj + "__robot"], f[obj + "__object"]
+    rng = np.random.default_rng(7)
+    n = len(R)
+    q = np.zeros((n, m.nq))
+    q[:, :29] = R + rng.normal(0, 0.01, (n, 29)) * (np.arange(29) >= 6)
+    q[:, 29:32] = O[:, :3]
+    q[:, 32:35] = np.stack([T.quat2euler(o[3:]) for o in O])
+    v = rng.normal(0, 0.2, (n, m.nv))
+    act = rng.uniform(0, 1, (n, m.nu)); act[:, :6] = 0
+    ctrl = rng.uniform(0, 1, (n, m.nu)); ctrl[:, :6] = q[:, :6]
+    g, r = _run(m, hm, q.astype(np.float32), v.astype(np.float32), act.astype(np.float32), ctrl.astype(np.float32), 5)
+    assert (g["flags"] == 0).all() and r["ncon_max"].max() <= 128, (g["flags"], r["ncon_max"])
+    same = (g["diag"][:, 1] == r["ncon"]) & ((g["diag"][:, 4] >> 16) == r["ncon_sum"])
+    eq = np.abs(g["qpos"] - r["qpos"]).max(1)
+    assert r["ncon"].max() >= 3 and same.sum() >= 0.75 * n, (same.sum(), r["ncon"])
+    # grasp frames of recorded motions interpenetrate by millimetres and rest polytope faces on polytope faces: some are ill-conditioned in
+    # single precision whoever computes them (mug frame 0: the float32 BUILD of the oracle is off by 5.0e-2, HIP by 4.8e-2; hammer handle frames
+    # 1e-3 .. 2e-3 vs 4e-3 .. 2.5e-2, tools/gpu_obj_probe.py).  So: where the float32 oracle itself stays within 1e-4 of the float64 one, HIP
+    # must stay within 5e-4 (measured: 2e-6 .. 3e-5, frames with 65 contacts included); everywhere it must stay bounded
+    from oracle.oracle import Oracle
+    o32 = Oracle(m.blob(), f32=True)
+    e32 = np.zeros(n)
+    for e in range(n):
+        o32.reset(); o32.set_state(qpos=q[e].astype(np.float32), qvel=v[e].astype(np.float32), act=act[e].astype(np.float32), ctrl=ctrl[e].astype(np.float32))
+        o32.step(5)
+        e32[e] = np.abs(o32.field("qpos") - r["qpos"][e]).max()
+    well = e32 < 1e-4
+    assert well.sum() >= 0.5 * n and eq[well].max() < 5e-4 and eq.max() < 0.1, (well.sum(), eq[well].max(), eq.max())
+    env = myo.make(f"MyoHand{obj.title()}Random-v0", num_envs=32, seed=0, autoreset=True)
+    obs = env.reset()
+    assert obs.shape == (32, 70)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    for _ in range(30):
+        obs, rew, term, trunc, info = env.step(torch.rand((32, env.act_dim), device="cuda", generator=gen) * 2 - 1)
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+    assert (env.status() == 0).all()

@@ -23,15 +23,18 @@ MODELS = {
     # a second MyoDM object (MyoHand_cup_drink1.npz is the other motion file of tests/golden/ref_motion.npz): same code, another asset
     "myohand_object_cup": ("myosuite/envs/myo/assets/hand/myohand_object.xml", {"OBJECT_NAME": "cup"}),
 }
+# more MyoDM objects (round 3): one per shape family of simhive/object_sim -- no new code, only assets (stored gzip-compressed: .myob.gz)
+for _obj in ("apple", "cubesmall", "duck", "mug", "hammer", "bowl"):
+    MODELS[f"myohand_object_{_obj}"] = ("myosuite/envs/myo/assets/hand/myohand_object.xml", {"OBJECT_NAME": _obj}, "gz")
 
 if __name__ == "__main__":
     only = sys.argv[1:]
     for stem, rel in MODELS.items():
         if only and stem not in only:
             continue
-        if isinstance(rel, tuple) and len(rel) == 2:
+        if isinstance(rel, tuple) and len(rel) >= 2:
             m = M.from_mjcf(os.path.join(REF, rel[0]), replace=rel[1], convex_meshes=True)
         else:
             m = M.from_mjcf(os.path.join(REF, rel[0]), terrain=True) if isinstance(rel, tuple) else M.from_mjcf(os.path.join(REF, rel))
-        m.save(os.path.join(M.ASSET_DIR, stem))
+        m.save(os.path.join(M.ASSET_DIR, stem), compress=isinstance(rel, tuple) and len(rel) == 3)
         print(stem, dict(nq=m.nq, nv=m.nv, nu=m.nu, nbody=m.nbody, ntendon=m.ntendon, bytes=len(m.blob())))
