@@ -78,8 +78,12 @@ class TrackConfig(C.Structure):
 # -mllvm -disable-machine-licm: the post-ISel loop-invariant code motion hoists constant materialisations (polynomial coefficients, masks) out
 # of the 10-substep loop into the kernel prologue, where a dozen of them stay live in VGPRs for the whole kernel and push other values into
 # scratch memory; with the pass off the headline kernel needs no register spill at all (35 before; tests/test_kernel_resources.py)
+# -fno-slp-vectorize: the SLP vectoriser pairs float operations into v_pk_fma_f32 / v_pk_mul_f32 (1 064 of them in the headline kernel), which need
+# 64-bit aligned register pairs: the static VALU count stays the same (the packed instructions are paid for in v_mov shuffles: 1 783 against 1 083
+# moves), the register pressure rises (MyoLeg kernel 227 -> 213 VGPRs without it, and the headline kernel's 127 turn into spills with any small
+# change), and the kernel is slower: measured +5.3 % at 4096 envs, +4.1 % at 32768 envs without the pass
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=on",
-               "-fgpu-flush-denormals-to-zero", "-mllvm", "-disable-machine-licm", *os.environ.get("MYO_HIPCC_EXTRA", "").split()]
+               "-fgpu-flush-denormals-to-zero", "-mllvm", "-disable-machine-licm", "-fno-slp-vectorize", *os.environ.get("MYO_HIPCC_EXTRA", "").split()]
 
 
 def build_library(force=False, verbose=False):

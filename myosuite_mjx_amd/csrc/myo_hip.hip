@@ -353,6 +353,46 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
       const float *tg4 = nullptr, *tp4 = nullptr; const int* tq4 = nullptr;
       if ((rc = upload<float>(m, grec, &tg4)) || (rc = upload<float>(m, prec, &tp4)) || (rc = upload<int>(m, pdl, &tq4))) { myo_model_free(m); return rc; }
       w.cg_rec = (decltype(w.cg_rec))tg4; w.pair_rec = (decltype(w.pair_rec))tp4; w.pair_dl_pk = (decltype(w.pair_dl_pk))tq4;
+      // tree words: one packed word per lane and round for the sweeps over the kinematic tree (DevModelW::kin_pk, link_desc, link_adof, dof_anc)
+      {
+        const std::vector<int> lpar = BI("hip_link_parent"), dlink = BI("hip_dof_link"), dpar = BI("dof_parentid"), kadr = BI("hip_kin_adr"), kvec = BI("hip_kin_vec"),
+                               chadr = BI("hip_link_chain_adr"), chain = BI("hip_link_chain");
+        if (d.nl > 64 || d.nv > 64) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "more than 64 links or dofs"); }
+        std::vector<int> kpk;
+        for (size_t L = 0; L + 1 < kadr.size(); L++) {
+          for (int e0 = kadr[L]; e0 < kadr[L + 1]; e0 += 64) {
+            for (int i = 0; i < 64; i++) {
+              const int e = e0 + i;
+              if (e >= kadr[L + 1]) { kpk.push_back(-1); continue; }
+              const int w0 = kvec[2 * (size_t)e], src = kvec[2 * (size_t)e + 1], l = w0 & 255, kind = (w0 >> 8) & 3, ix = w0 >> 16, par1 = lpar[l] + 1;
+              if (src < 0 || src >= 2048 || l >= 64 || ix < 0 || ix >= 64 || par1 < 0 || par1 > 64) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "kinematics entry does not fit the packed word"); }
+              kpk.push_back((int)((unsigned)src | ((unsigned)l << 11) | ((unsigned)kind << 17) | ((unsigned)ix << 19) | ((unsigned)par1 << 25)));
+            }
+          }
+        }
+        w.kin_nround = (int)(kpk.size() / 64);
+        kpk.resize(kpk.size() + 64, -1);                       // padding round: the loop prefetches one round ahead
+        std::vector<unsigned long long> desc(d.nl, 0), adof(d.nl, 0), anc(d.nv, 0);
+        for (int l = d.nl - 1; l >= 0; l--) { desc[l] |= 1ull << l; if (lpar[l] >= 0) { if (lpar[l] >= l) { myo_model_free(m); return fail(MYO_E_BLOB, "links are not in tree order"); } desc[lpar[l]] |= desc[l]; } }
+        for (int q = 0; q < d.nv; q++) { if (dpar[q] >= q) { myo_model_free(m); return fail(MYO_E_BLOB, "dofs are not in tree order"); } anc[q] = (1ull << q) | (dpar[q] >= 0 ? anc[dpar[q]] : 0ull); }
+        unsigned long long frot = 0, fj3 = 0;
+        for (int l = 0; l < d.nl; l++) {
+          int prev = -1;
+          for (int c = chadr[l]; c < chadr[l + 1]; c++) {
+            const int e = chain[c], q = e & 255, j = (e >> 8) & 7, fr = e >> 12;
+            if (q <= prev || q >= d.nv) { myo_model_free(m); return fail(MYO_E_BLOB, "link dof chain is not root-first"); }
+            prev = q;
+            adof[l] |= 1ull << q;
+            if (fr && j >= 3) frot |= 1ull << q;
+            if (fr && j == 3) fj3 |= 1ull << q;
+          }
+        }
+        w.free_rot[0] = (unsigned)frot; w.free_rot[1] = (unsigned)(frot >> 32); w.free_j3[0] = (unsigned)fj3; w.free_j3[1] = (unsigned)(fj3 >> 32);
+        auto split = [](const std::vector<unsigned long long>& v) { std::vector<int> o(std::max<size_t>(2 * v.size(), 2), 0); for (size_t i = 0; i < v.size(); i++) { o[2 * i] = (int)(unsigned)v[i]; o[2 * i + 1] = (int)(unsigned)(v[i] >> 32); } return o; };
+        const int *t0 = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;
+        if ((rc = upload<int>(m, kpk, &t0)) || (rc = upload<int>(m, split(desc), &t1)) || (rc = upload<int>(m, split(adof), &t2)) || (rc = upload<int>(m, split(anc), &t3))) { myo_model_free(m); return rc; }
+        w.kin_pk = (decltype(w.kin_pk))t0; w.link_desc = (decltype(w.link_desc))t1; w.link_adof = (decltype(w.link_adof))t2; w.dof_anc = (decltype(w.dof_anc))t3;
+      }
     }
     const bool common = d.nl <= 64 && d.ncg <= 64 && w.nq <= 64 && w.neq <= 64 && d.maxnnz <= 20;
     const bool needs_full = w.has_free || w.neq > 0 || plane_pairs || condim1 || m->trk;

@@ -81,6 +81,14 @@ struct DevModelW {
   gpf4 pair_rec;        // [npair][4]: g1 | g2 << 8 | narrow-phase type << 16 | condim << 20 | dofs << 24, margin, gap, dof-list start |
                         //   size 1, bounding radius 1 | size 2, bounding radius 2 | type 1 | type 2 << 8
   gpi pair_dl_pk;       // contact dof lists in one word per entry: dof | hinge << 7 | sign << 8
+  // Tree words (built by myo_model_load): the sweeps over the kinematic tree take one packed word per lane and round, loaded ahead of the stage,
+  // instead of walking level_adr -> child_adr -> child, link_chain_adr -> link_chain or dof_parent chains of dependent loads
+  gpi kin_pk;           // phase 2 of the kinematics: [round][64] scratch offset | link << 11 | kind << 17 | ix << 19 | (parent + 1) << 25; all ones = idle lane;
+  int kin_nround;       //   the rounds of a level are contiguous, one padding round closes the table (the loop prefetches a round ahead)
+  gpi link_desc;        // [nl][2] links in the subtree of link l, itself included (64-bit mask, low word first)
+  gpi link_adof;        // [nl][2] dofs on the path root -> link l, its own included
+  gpi dof_anc;          // [nv][2] dof d and its ancestors
+  unsigned int free_rot[2], free_j3[2];   // dofs that are rotations of a free joint / the first rotation of one
 };
 #define SEGR 9
 
@@ -587,6 +595,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     // cosines and the joint rotations of all links are evaluated side by side instead of level after level.  Free-joint links (roots)
     // take their world pose straight from qpos.  All 64 lanes run the arithmetic on a clamped link index and only the stores are
     // predicated (a variant with the trigonometry inside `if (lane < ...)` miscompiled in the generic instantiation).
+    unsigned int kw = (unsigned int)W.kin_pk[lane];   // phase 2, round 0 (its latency hides behind the joint trigonometry of phase 1)
     {
       const int l = lane < nl_ ? lane : 0;
       const bool mine = lane < nl_;
@@ -662,13 +671,13 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       }
     }
     SYNC();
-    // Phase 2, level by level, lane = (link of the level, vector): world = parent rotation x local vector (+ parent origin for points)
-    for (int L = 0; L < nlevel_; L++) {
-      const int e0 = W.kin_adr[L], e1 = W.kin_adr[L + 1];
-      for (int e = e0 + lane; e < e1; e += 64) {
-        const int w0 = W.kin_vec[2 * e], src = W.kin_vec[2 * e + 1];
-        const int l = w0 & 255, kind = (w0 >> 8) & 3, ix = w0 >> 16;
-        const int par = M.link_parent[l];
+    // Phase 2, level by level, lane = (link of the level, vector): world = parent rotation x local vector (+ parent origin for points).
+    // One packed word per lane and round (DevModelW::kin_pk), the next round's word in flight while this one is worked on.
+    for (int r = 0; r < W.kin_nround; r++) {
+      const unsigned int w0 = kw;
+      kw = (unsigned int)W.kin_pk[(r + 1) * 64 + lane];
+      if (w0 != 0xFFFFFFFFu) {
+        const int src = w0 & 2047, l = (w0 >> 11) & 63, kind = (w0 >> 17) & 3, ix = (w0 >> 19) & 63, par = (int)(w0 >> 25) - 1;
         const float v[3] = {E[Y.sq + src], E[Y.sq + src + 1], E[Y.sq + src + 2]};
         float w[3] = {v[0], v[1], v[2]};
         if (par >= 0) {
@@ -813,6 +822,17 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     SUB(9);
     STAMP(2);
     // ---------------------------------------------------------------- CRB + RNE (lane = link / dof)
+    // tree words of this lane's link / dof and of the subtree-sum tasks, loaded here so that the sweeps below find them in registers
+    typedef unsigned long long ull;
+    constexpr bool M64 = NVT > 32;      // link / dof masks of the small instantiations fit the low word
+    auto ld_mask = [&](gpi tab, int i) -> ull { const unsigned int lo = (unsigned int)tab[2 * i], hi = M64 ? (unsigned int)tab[2 * i + 1] : 0u; return (ull)lo | ((ull)hi << 32); };
+    constexpr int BKG = SPEC ? (16 * Z::nl + 63) / 64 : 4;   // rounds of subtree-sum tasks per group (size-specialised: all of them)
+    const ull adof_m = lane < nl_ ? ld_mask(W.link_adof, lane) : 0ull, anc_m = lane < nv ? ld_mask(W.dof_anc, lane) : 0ull;
+    ull desc_m[BKG];
+#pragma unroll
+    for (int u = 0; u < BKG; u++) { const int l = (u * 64 + lane) >> 4; desc_m[u] = l < nl_ ? ld_mask(W.link_desc, l) : 0ull; }
+    const int my_link = M.dof_link[lane < nv ? lane : 0];
+    const float my_arm = M.dof_armature[lane < nv ? lane : 0], my_damp = M.dof_damping[lane < nv ? lane : 0];
     if (lane < nl_) {
       int l = lane;
       const float* R = E + Y.lmat + 9 * l;
@@ -858,17 +878,18 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     if (lane < nl_) {
       const int l = lane;
       float cvel[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, cacc[6] = {0.f, 0.f, 0.f, -M.grav[0], -M.grav[1], -M.grav[2]}, cvel_rot[6];
-      for (int c = W.link_chain_adr[l]; c < W.link_chain_adr[l + 1]; c++) {
-        const int e = W.link_chain[c], d = e & 255, j = (e >> 8) & 7;
-        const bool isfree = has_free && (e >> 12);
+      const ull frot = has_free ? ((ull)W.free_rot[0] | ((ull)W.free_rot[1] << 32)) : 0ull, fj3 = has_free ? ((ull)W.free_j3[0] | ((ull)W.free_j3[1] << 32)) : 0ull;
+      for (ull am = adof_m; am; am &= am - 1ull) {   // dofs of the chain root-first = ascending (DevModelW::link_adof): no table read inside the loop
+        const int d = __builtin_ctzll(am);
+        const bool rotf = has_free && ((frot >> d) & 1ull), j3 = has_free && ((fj3 >> d) & 1ull);
         float cd[6], cdd[6], qv = E[Y.qvel + d];
 #pragma unroll
         for (int k = 0; k < 6; k++) cd[k] = E[Y.cdof + 6 * d + k];
-        if (isfree && j == 3) {
+        if (j3) {
 #pragma unroll
           for (int k = 0; k < 6; k++) cvel_rot[k] = cvel[k];   // velocity after the translations, before any of the 3 rotations
         }
-        cross_motion(cdd, (isfree && j >= 3) ? cvel_rot : cvel, cd);
+        cross_motion(cdd, rotf ? cvel_rot : cvel, cd);
 #pragma unroll
         for (int k = 0; k < 6; k++) { cacc[k] += cdd[k] * qv; cvel[k] += cd[k] * qv; }
       }
@@ -956,22 +977,35 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       }
       break;
     }
-    // backward accumulation of the link forces (6) and composite inertias (10), leaves to root: lane = (link of the level, component), so a
-    // link with five children (the wrist) costs five adds per lane instead of 80 read-add-writes in one lane
-    for (int L = nlevel_ - 2; L >= 0; L--) {
-      const int l0 = M.level_adr[L], nn = (M.level_adr[L + 1] - l0) * 16;
-      for (int idx = lane; idx < nn; idx += 64) {
-        const int l = l0 + (idx >> 4), k = idx & 15;
-        const int base = k < 6 ? Y.cfrc + k : Y.crb + (k - 6), str = k < 6 ? 6 : 10;
-        float acc = E[base + str * l];
-        for (int ci = M.child_adr[l]; ci < M.child_adr[l + 1]; ci++) acc += E[base + str * M.child[ci]];
-        E[base + str * l] = acc;
+    // subtree sums of the link forces (6) and composite inertias (10): lane = (link, component) adds up the link's whole subtree (DevModelW::link_desc)
+    // from the values the links wrote themselves, so no task waits for another one -- no level-by-level sweep with its chain of
+    // level_adr -> child_adr -> child reads.  In place: a group of rounds reads, then writes; a later group (higher links) only reads links above its
+    // own, which no earlier group has written.
+    {
+      const int nbk = (16 * nl_ + 63) >> 6;
+      for (int r0 = 0; r0 < nbk; r0 += BKG) {
+        float acc[BKG];
+#pragma unroll
+        for (int u = 0; u < BKG; u++) {
+          const int idx = (r0 + u) * 64 + lane, l = idx >> 4, k = idx & 15;
+          const int base = k < 6 ? Y.cfrc + k : Y.crb + (k - 6), str = k < 6 ? 6 : 10;
+          ull dm = r0 == 0 ? desc_m[u] : (l < nl_ ? ld_mask(W.link_desc, l) : 0ull);
+          float a = 0.f;
+          for (; dm; dm &= dm - 1ull) a += E[base + str * __builtin_ctzll(dm)];
+          acc[u] = a;
+        }
+        SYNC();
+#pragma unroll
+        for (int u = 0; u < BKG; u++) {
+          const int idx = (r0 + u) * 64 + lane, l = idx >> 4, k = idx & 15;
+          if (l < nl_) E[(k < 6 ? Y.cfrc + k : Y.crb + (k - 6)) + (k < 6 ? 6 : 10) * l] = acc[u];
+        }
+        SYNC();
       }
-      SYNC();
     }
     float smooth = 0.f;
     if (lane < nv) {
-      int d = lane, l = M.dof_link[d];
+      int d = lane, l = my_link;
       float cd[6], buf[6], crb[10];
 #pragma unroll
       for (int k = 0; k < 6; k++) cd[k] = E[Y.cdof + 6 * d + k];
@@ -981,17 +1015,17 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
 #pragma unroll
       for (int k = 0; k < 6; k++) bias += cd[k] * E[Y.cfrc + 6 * l + k];
       mul_inert_vec(buf, crb, cd);
-      int a = d;
-      while (a >= 0) {
+      for (ull am = anc_m; am;) {   // the dof and its ancestors (DevModelW::dof_anc), highest first
+        const int a = 63 - __builtin_clzll(am);
+        am ^= 1ull << a;
         float sdot = 0;
 #pragma unroll
         for (int k = 0; k < 6; k++) sdot += E[Y.cdof + 6 * a + k] * buf[k];
-        if (a == d) sdot += M.dof_armature[d];
+        if (a == d) sdot += my_arm;
         E[Y.sq + d * (NVT + 1) + a] = sdot;   // full symmetric copy: (d,a) and (a,d)
         E[Y.sq + a * (NVT + 1) + d] = sdot;
-        a = M.dof_parent[a];
       }
-      smooth = -M.dof_damping[d] * E[Y.qvel + d] - bias + qfa;
+      smooth = -my_damp * E[Y.qvel + d] - bias + qfa;
     }
     SYNC();  // region X changes owner: dynamics scratch -> collision / contact rows
     SUB(11);
