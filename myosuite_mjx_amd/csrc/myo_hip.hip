@@ -295,6 +295,14 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
                              dl = BI("hip_dl"), dof_type = BI("hip_dof_type");
       const std::vector<float> seg_div = BF("hip_seg_div"), site_lpos = BF("hip_site_lpos"), wg_lpos = BF("hip_wg_lpos"), wg_lmat = BF("hip_wg_lmat"), wg_radius = BF("hip_wg_radius");
       auto fi = [](int v) { float f; memcpy(&f, &v, 4); return f; };
+      std::vector<int> dlp(std::max<size_t>(dl.size() / 3, 1), 0);
+      for (size_t i = 0; i < dl.size() / 3; i++) {
+        const int dd = dl[3 * i], sg = dl[3 * i + 1], slot = dl[3 * i + 2];
+        if (dd < 0 || dd > 127 || slot < 0 || slot > 255 || sg < -32768 || sg > 32767) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "moment-arm list entry does not fit the packed word"); }
+        dlp[i] = dd | ((dof_type[dd] == 3 ? 1 : 0) << 7) | (slot << 8) | (int)((unsigned)sg << 16);
+      }
+      // (each segment's three lists are copied to 16-byte rows of their own: a lane reads a list four entries per load, the first row ahead of its use)
+      std::vector<int> dl4;
       std::vector<float> rec((size_t)std::max(d.nseg, 1) * SEGR * 4, 0.f);
       for (int idx = 0; idx < d.nseg; idx++) {
         const int si = seg_order[idx];
@@ -303,8 +311,11 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
         for (int k = 0; k < 2; k++) { R[4 * k] = fi(site_link[S[k]]); for (int c = 0; c < 3; c++) R[4 * k + 1 + c] = site_lpos[3 * (size_t)S[k] + c]; }
         R[8] = fi(S[2]); R[9] = fi(S[3] >= 0 ? site_link[S[3]] : -2); R[10] = 1.0f / seg_div[si]; R[11] = fi(seg_tendon[si]);
         for (int k = 0; k < 3; k++) {
-          if (S[4 + 2 * k] >= (1 << 20) || S[5 + 2 * k] >= (1 << 11)) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "tendon moment-arm lists too long for the packed segment record"); }
-          R[12 + k] = fi(S[4 + 2 * k] | (S[5 + 2 * k] << 20));
+          const int a0 = S[4 + 2 * k], n = S[5 + 2 * k], adr4 = (int)(dl4.size() / 4);
+          if (adr4 >= (1 << 20) || n < 0 || n >= (1 << 11) || (n > 0 && (a0 < 0 || (size_t)(a0 + n) > dl.size() / 3))) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "tendon moment-arm lists too long for the packed segment record"); }
+          for (int i = 0; i < n; i++) dl4.push_back(dlp[a0 + i]);
+          while (dl4.size() % 4 || dl4.size() == (size_t)adr4 * 4) dl4.push_back(0);     // whole rows; an empty list still owns one (the lane loads it unconditionally)
+          R[12 + k] = fi(adr4 | (n << 20));
         }
         R[15] = fi(S[10]);
         if (S[2] >= 0) {
@@ -315,14 +326,9 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
           for (int c = 0; c < 9; c++) R[24 + c] = wg_lmat[9 * (size_t)g + c];
         }
       }
-      std::vector<int> dlp(std::max<size_t>(dl.size() / 3, 1), 0);
-      for (size_t i = 0; i < dl.size() / 3; i++) {
-        const int dd = dl[3 * i], sg = dl[3 * i + 1], slot = dl[3 * i + 2];
-        if (dd < 0 || dd > 127 || slot < 0 || slot > 255 || sg < -32768 || sg > 32767) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "moment-arm list entry does not fit the packed word"); }
-        dlp[i] = dd | ((dof_type[dd] == 3 ? 1 : 0) << 7) | (slot << 8) | (int)((unsigned)sg << 16);
-      }
       const float* tf4 = nullptr; const int* ti4 = nullptr;
-      if ((rc = upload<float>(m, rec, &tf4)) || (rc = upload<int>(m, dlp, &ti4))) { myo_model_free(m); return rc; }
+      if (dl4.empty()) dl4.resize(4, 0);
+      if ((rc = upload<float>(m, rec, &tf4)) || (rc = upload<int>(m, dl4, &ti4))) { myo_model_free(m); return rc; }
       w.seg_rec = (decltype(w.seg_rec))tf4; w.dl_pk = (decltype(w.dl_pk))ti4;
       // collision geoms, pairs and the pairs' dof lists
       const std::vector<int> cg_link = BI("hip_cg_link"), cg_type = BI("hip_cg_type"), pair_i = BI("hip_pair_i"), pair_dl = BI("hip_pair_dl");
@@ -344,6 +350,8 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
         R[7] = cg_rb[P[0]]; R[11] = cg_rb[P[1]];
         R[12] = fi(cg_type[P[0]] | (cg_type[P[1]] << 8));
       }
+      // (a contact carries pair | dofs << 11 | dof-list start << 16 in one word: step kernel, narrow phase -> row stage)
+      if (d.npair > 2048 || pair_dl.size() / 2 >= (1u << 16) || d.maxkc > 31) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "more than 2048 collision pairs, 65535 contact dof-list entries or 31 dofs per contact"); }
       std::vector<int> pdl(std::max<size_t>(pair_dl.size() / 2, 1), 0);
       for (size_t i = 0; i < pair_dl.size() / 2; i++) {
         const int dd = pair_dl[2 * i], sg = pair_dl[2 * i + 1];

@@ -76,7 +76,7 @@ struct DevModelW {
   // scalar loads per wave and env step, nearly every one with its latency exposed).
   gpf4 seg_rec;         // [nseg, in seg_order][SEGR]: site 0 (link, lpos) | site 1 | wrap geom, side link, 1 / divisor, tendon | three dof-list words,
                         //   wrap type | side lpos, radius | wrap geom link, lpos | its rotation (9)
-  gpi dl_pk;            // [ndl] moment-arm list entries in one word: dof | hinge << 7 | row slot << 8 | sign << 16
+  gpi dl_pk;            // moment-arm lists, one word per entry: dof | hinge << 7 | row slot << 8 | sign << 16; every list of a segment starts a 16-byte row of its own
   gpf4 cg_rec;          // [ncg][4]: link, lpos | rotation (9) | type, bounding radius
   gpf4 pair_rec;        // [npair][4]: g1 | g2 << 8 | narrow-phase type << 16 | condim << 20 | dofs << 24, margin, gap, dof-list start |
                         //   size 1, bounding radius 1 | size 2, bounding radius 2 | type 1 | type 2 << 8
@@ -120,23 +120,25 @@ __device__ __forceinline__ int wave_lane() {
 // same from a pointer to the contact's own packed words (LDS row or HBM overflow row)
 #define CDOFP(W_, k_) ((int)(((W_)[(k_) >> 2] >> (8 * ((k_) & 3))) & 255u))
 
-// in: r[k] = H[lane][k] (k <= lane). out: r[k] = L[lane][k], returns 1/L[lane][lane].  All indices are compile-time.
-// Right-looking (outer-product) order: once column j is final, every later column k takes its update r[k] -= L[.][j] L[k][j] at once.  The
-// products are the same 276 as in the left-looking order, but the NVT - 1 - j updates of a step are independent of each other, where the
-// left-looking form chained the j products of a column through one accumulator: the dependent chain of a factorisation shrinks from
-// ~276 multiply-adds to NVT pivot steps -- what a wave that runs alone on its SIMD (the heavy envs at the end of a launch) is bound by.
+// Register factorisation H = L D L^T (unit lower L, D = pivots), lane = row.  in: r[k] = H[lane][k] for k <= lane and ZERO above the diagonal.
+// out: r[k] = L[lane][k] for k < lane and zero from the diagonal on; returns 1 / D[lane].  All indices are compile-time.
+// Right-looking (outer-product) order: once column j is final, every later column k takes its update r[k] -= L[.][j] (D_j L[k][j]) at once, so the
+// NVT - 1 - j updates of a step are independent of each other and the dependent chain of a factorisation is the NVT pivot steps.
+// Why L D L^T rather than Cholesky: no square root (v_rcp of the pivot), and both triangular solves run on the SAME unit-diagonal factor with no
+// division or scaling per step -- two instructions per forward step, three per backward step (ldl_solve_rows), against seven before.  The zeros from
+// the diagonal on are what lets the solves skip every lane test: a lane above the diagonal multiplies by an exact zero.
 template <int NVT> __device__ __forceinline__ float chol_rows(float (&r)[NVT], int lane) {
   float invd = 1.0f;
 #pragma unroll
   for (int j = 0; j < NVT; j++) {
     const float pj = fmaxf(rdlane(r[j], j), MINVALF);
-    const float inv = __builtin_amdgcn_rsqf(pj);   // v_rsq_f32 (1 ulp); pj >= 1e-15, no denormal handling needed
-    const float dj = pj * inv;
-    const float lj = (lane == j) ? dj : r[j] * inv;
-    r[j] = lj;
-    if (lane == j) invd = inv;
+    const float ip = __builtin_amdgcn_rcpf(pj);   // v_rcp_f32 (1 ulp); pj >= 1e-15, no denormal handling needed
+    const float col = lane > j ? r[j] : 0.f;      // D_j L[lane][j]; zero on and above the diagonal, so those lanes take no update below
+    const float lt = col * ip;
+    r[j] = lt;
+    if (lane == j) invd = ip;
 #pragma unroll
-    for (int k = j + 1; k < NVT; k++) r[k] -= lj * rdlane(lj, k);     // (lanes < k carry garbage above their diagonal: never read)
+    for (int k = j + 1; k < NVT; k++) r[k] -= lt * rdlane(col, k);
   }
   return invd;
 }
@@ -159,23 +161,23 @@ template <int SPEC> __host__ __device__ constexpr bool tree_anc(int a, int d) {
 // chol_rows on the leaves-first permuted matrix of a tree-structured model: the updates whose factor entry L[K][J] is structurally zero
 // (dof of K is not an ancestor of the dof of J) are not emitted (`if constexpr` over index sequences: a run-time predicate inside
 // `#pragma unroll` loops blocked the unrolling and put the rows into scratch memory).  Right-looking like chol_rows.
-template <int NVT, int SPEC, int J, int K> __device__ __forceinline__ void tree_update(float (&r)[NVT], float lj) {
+template <int NVT, int SPEC, int J, int K> __device__ __forceinline__ void tree_update(float (&r)[NVT], float lt, float col) {
   constexpr int nv = SpecTree<SPEC>::nv;
   if constexpr (K > J && J < nv && K < nv) {
-    if constexpr (tree_anc<SPEC>(nv - 1 - K, nv - 1 - J)) r[K] -= lj * rdlane(lj, K);
+    if constexpr (tree_anc<SPEC>(nv - 1 - K, nv - 1 - J)) r[K] -= lt * rdlane(col, K);
   }
 }
-template <int NVT, int SPEC, int J, int... Ks> __device__ __forceinline__ void tree_col(float (&r)[NVT], float lj, std::integer_sequence<int, Ks...>) {
-  (tree_update<NVT, SPEC, J, Ks>(r, lj), ...);
+template <int NVT, int SPEC, int J, int... Ks> __device__ __forceinline__ void tree_col(float (&r)[NVT], float lt, float col, std::integer_sequence<int, Ks...>) {
+  (tree_update<NVT, SPEC, J, Ks>(r, lt, col), ...);
 }
 template <int NVT, int SPEC, int J> __device__ __forceinline__ void tree_step(float (&r)[NVT], float& invd, int lane) {
   const float pj = fmaxf(rdlane(r[J], J), MINVALF);
-  const float inv = __builtin_amdgcn_rsqf(pj);
-  const float dj = pj * inv;
-  const float lj = (lane == J) ? dj : r[J] * inv;
-  r[J] = lj;
-  if (lane == J) invd = inv;
-  tree_col<NVT, SPEC, J>(r, lj, std::make_integer_sequence<int, NVT>{});
+  const float ip = __builtin_amdgcn_rcpf(pj);
+  const float col = lane > J ? r[J] : 0.f;
+  const float lt = col * ip;
+  r[J] = lt;
+  if (lane == J) invd = ip;
+  tree_col<NVT, SPEC, J>(r, lt, col, std::make_integer_sequence<int, NVT>{});
 }
 template <int NVT, int SPEC, int... Js> __device__ __forceinline__ void tree_all(float (&r)[NVT], float& invd, int lane, std::integer_sequence<int, Js...>) {
   (tree_step<NVT, SPEC, Js>(r, invd, lane), ...);
@@ -185,21 +187,16 @@ template <int NVT, int SPEC> __device__ __forceinline__ float chol_rows_tree(flo
   tree_all<NVT, SPEC>(r, invd, lane, std::make_integer_sequence<int, NVT>{});
   return invd;
 }
-// x <- (L L^T)^-1 b ; L rows in registers, L^T columns read from the LDS copy T[j*(NVT+1) + lane]
+// x <- (L D L^T)^-1 b ; rows of the unit lower L in registers (zero from the diagonal on), invd = 1 / D[lane], the columns of L^T read from the
+// LDS copy T[j * (NVT + 1) + lane] (row j of L: zero for lane >= j)
 template <int NVT> __device__ __forceinline__ float chol_solve_rows(const float (&r)[NVT], float invd, float b, const float* T, int lane) {
   float y = b;
 #pragma unroll
-  for (int j = 0; j < NVT; j++) {
-    float yj = rdlane(y, j) * rdlane(invd, j);
-    y = (lane == j) ? yj : (lane > j ? y - r[j] * yj : y);
-  }
+  for (int j = 0; j < NVT; j++) y = fmaf(-r[j], rdlane(y, j), y);
+  y *= invd;
   const float* Tc = T + (lane < NVT ? lane : 0);
 #pragma unroll
-  for (int j = NVT - 1; j >= 0; j--) {
-    float xj = rdlane(y, j) * rdlane(invd, j);
-    float cj = Tc[j * (NVT + 1)];
-    y = (lane == j) ? xj : (lane < j ? y - cj * xj : y);
-  }
+  for (int j = NVT - 1; j >= 0; j--) y = fmaf(-Tc[j * (NVT + 1)], rdlane(y, j), y);
   return y;
 }
 // y_lane = sum_k M[lane][k] x_k with M packed lower-triangular in LDS (rows beyond nv read as zero)
@@ -258,27 +255,40 @@ template <class LY> __device__ __forceinline__ void geom_world_mat(const DevMode
 // moment-arm entries of one straight tendon piece
 // Jt = this tendon's sparse jacobian row in LDS (zeroed before the segment rounds): the entries are accumulated with LDS float atomics
 // by the segment lanes themselves (one wave: deterministic order) instead of being gathered entry by entry by the tendon's lane
-template <class LY> __device__ __forceinline__ float straight_w(const DevModelW& W, const LY& Y, float* E, float* Jt, const float* pa, const float* pb, int adr, int n,
-                                                              float invdiv, bool active) {
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const int4 __attribute__((address_space(1)))* gpi4;
+#else
+typedef const int4* gpi4;
+#endif
+template <class LY> __device__ __forceinline__ float straight_w(const DevModelW& W, const LY& Y, float* E, float* Jt, const float* pa, const float* pb, int adr4, int n,
+                                                              float invdiv, bool active, const int4& first) {
   float dif[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
   float dist = norm3(dif);
   float inv = dist > MINVALF ? 1.0f / dist : 0.f;
   dif[0] *= inv; dif[1] *= inv; dif[2] *= inv;
   // a lane that does not keep this piece (wrapping segment vs direct piece, or the reverse) runs zero iterations: the wave's trip count is
-  // the longest dof list among the lanes that DO keep it, and zero when none does
+  // the longest dof list among the lanes that DO keep it, and zero when none does.  Four entries per 16-byte load; the first row was
+  // loaded by the caller ahead of the wrap geometry (`first`), so the usual list (<= 4 entries) costs no exposed load at all.
   const int nn = active ? n : 0;
-  for (int k = 0; k < nn; k++) {
-    const int e = W.dl_pk[adr + k];            // dof | hinge << 7 | row slot << 8 | sign << 16: one word instead of three plus dof_type[dof]
-    const int d = e & 127;
-    const float* ax = E + Y.axis + 3 * d;
-    float col;
-    if (e & 128) {
-      const float* an = E + Y.anchor + 3 * d;
-      float r[3] = {pb[0] - an[0], pb[1] - an[1], pb[2] - an[2]}, c[3];
-      cross3(c, ax, r);
-      col = dot3(dif, c);
-    } else col = dot3(dif, ax);
-    atomicAdd(&Jt[(e >> 8) & 255], (float)(e >> 16) * col * invdiv);
+  for (int k0 = 0; k0 < nn; k0 += 4) {
+    int4 q = first;
+    if (k0) q = ((gpi4)W.dl_pk)[adr4 + (k0 >> 2)];
+    const int qe[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (k0 + u >= nn) continue;
+      const int e = qe[u];            // dof | hinge << 7 | row slot << 8 | sign << 16: one word instead of three plus dof_type[dof]
+      const int d = e & 127;
+      const float* ax = E + Y.axis + 3 * d;
+      float col;
+      if (e & 128) {
+        const float* an = E + Y.anchor + 3 * d;
+        float r[3] = {pb[0] - an[0], pb[1] - an[1], pb[2] - an[2]}, c[3];
+        cross3(c, ax, r);
+        col = dot3(dif, c);
+      } else col = dot3(dif, ax);
+      atomicAdd(&Jt[(e >> 8) & 255], (float)(e >> 16) * col * invdiv);
+    }
   }
   return active ? dist * invdiv : 0.f;
 }
@@ -532,9 +542,10 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
   constexpr bool OVR = FULL && SPEC == 0 && !HF;
   // pair record -> locals.  (OVR: one geom's size / bounding radius may be a per-env value, DevBatch.gsize)
   struct PairL { int g1, g2, dl, kc, pt, cd, t1, t2; float margin, gap, rb1, rb2, s1[3], s2[3]; };
-  auto pair_load = [&](int p) -> PairL {
-    const gpf4 Q = W.pair_rec + 4 * (size_t)p;
-    const float4 q0 = Q[0], q1 = Q[1], q2 = Q[2], q3 = Q[3];
+  struct PairRaw { float4 q0, q1, q2, q3; };
+  auto pair_raw = [&](int p) -> PairRaw { const gpf4 Q = W.pair_rec + 4 * (size_t)p; return PairRaw{Q[0], Q[1], Q[2], Q[3]}; };
+  auto pair_decode = [&](const PairRaw& r) -> PairL {
+    const float4 q0 = r.q0, q1 = r.q1, q2 = r.q2, q3 = r.q3;
     const int w = __float_as_int(q0.x), tt = __float_as_int(q3.x);
     PairL L;
     L.g1 = w & 255; L.g2 = (w >> 8) & 255; L.pt = (w >> 16) & 15; L.cd = (w >> 20) & 15; L.kc = (w >> 24) & 255; L.dl = __float_as_int(q0.w);
@@ -547,6 +558,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     }
     return L;
   };
+  auto pair_load = [&](int p) -> PairL { return pair_decode(pair_raw(p)); };
   // contacts NC .. NC + NCX - 1 live in this env's HBM overflow rows [dist, pos3, normal3, pair, cJ[3 KC], dof words]; lane = contact still holds
   // for all 64.  The first NC contacts (all of them for > 99.5 % of the states) never leave LDS.
   // TRK: a second bank of 64 (contacts 64 .. 127: lane = contact - 64), whose per-contact solver state lives in the contact's row as well
@@ -723,14 +735,23 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         // seg_order -> seg -> site_link / site_lpos / wg_* read word by word
         const gpf4 SR = W.seg_rec + (size_t)idx * SEGR;
         const float4 r0 = SR[0], r1 = SR[1], r2 = SR[2], r3 = SR[3];
+        // (the wrapping segments come first in the order: in their rounds every lane asks for the whole record at once instead of waiting for
+        // `g` to arrive before the second half is requested)
+        float4 r4 = r0, r5 = r0, r6 = r0, r7 = r0, r8 = r0;
+        if (base < W.nwrapseg) { r4 = SR[4]; r5 = SR[5]; r6 = SR[6]; r7 = SR[7]; r8 = SR[8]; }
         const int g = __float_as_int(r2.x), side_l = __float_as_int(r2.y), gts = __float_as_int(r2.w);
         const float invdiv = r2.z;
         float p0[3], p1[3];
         { const float lp[3] = {r0.y, r0.z, r0.w}; frame_point(Y, E, __float_as_int(r0.x), lp, p0); }
         { const float lp[3] = {r1.y, r1.z, r1.w}; frame_point(Y, E, __float_as_int(r1.x), lp, p1); }
+        // first rows of the segment's moment-arm lists, in flight while the wrap geometry is worked out
+        const int wa = __float_as_int(r3.x), wb = __float_as_int(r3.y), wc = __float_as_int(r3.z);
+        const gpi4 DL = (gpi4)W.dl_pk;
+        const int4 ea = DL[wa & 0xFFFFF];
+        int4 eb = ea, ec = ea;
+        if (g >= 0) { eb = DL[wb & 0xFFFFF]; ec = DL[wc & 0xFFFFF]; }
         float wlen = -1, wp[6];
         if (g >= 0) {
-          const float4 r4 = SR[4], r5 = SR[5], r6 = SR[6], r7 = SR[7], r8 = SR[8];
           const int gl = __float_as_int(r5.x);
           const float glp[3] = {r5.y, r5.z, r5.w}, glm[9] = {r6.x, r6.y, r6.z, r6.w, r7.x, r7.y, r7.z, r7.w, r8.x};
           float gpos[3], gmat[9], side[3] = {0, 0, 0};
@@ -752,11 +773,10 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         SUB(7);
         bool wr = wlen >= 0;
         float* Jt = E + Y.tJ + gts * maxnnz_;
-        const int wa = __float_as_int(r3.x), wb = __float_as_int(r3.y), wc = __float_as_int(r3.z);
-        float L = straight_w(W, Y, E, Jt, p0, p1, wa & 0xFFFFF, wa >> 20, invdiv, !wr);
+        float L = straight_w(W, Y, E, Jt, p0, p1, wa & 0xFFFFF, wa >> 20, invdiv, !wr, ea);
         if (g >= 0) {
-          L += straight_w(W, Y, E, Jt, p0, wp, wb & 0xFFFFF, wb >> 20, invdiv, wr);
-          L += straight_w(W, Y, E, Jt, wp + 3, p1, wc & 0xFFFFF, wc >> 20, invdiv, wr);
+          L += straight_w(W, Y, E, Jt, p0, wp, wb & 0xFFFFF, wb >> 20, invdiv, wr, eb);
+          L += straight_w(W, Y, E, Jt, wp + 3, p1, wc & 0xFFFFF, wc >> 20, invdiv, wr, ec);
           if (wr) L += wlen * invdiv;
         }
         atomicAdd(&E[Y.tlen + gts], L);
@@ -1035,6 +1055,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     if (!M.disable_contact) {
       int ncand = 0;
       int* cand = (int*)(E + Y.cand);
+      PairRaw pnext = pair_raw(min(lane, npair_ > 0 ? npair_ - 1 : 0));   // broad phase, round 0: requested here, behind the geom frames
       if (lane < ncg_) {   // world centre and long axis (3rd column) of every collision geom
         float x[3], R[9];
         geom_world_pos(W, Y, E, lane, x);
@@ -1048,8 +1069,10 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         bool hit = false;
         int nh = 0, hr0 = 0, hr1 = 0, hc0 = 0, hc1 = 0;   // height-field pair: cell range under the geom, prisms that can touch it
         float hzcut = 0.f;
+        const PairRaw praw = pnext;                                   // this round's record was requested a round ago
+        pnext = pair_raw(min(p + 64, npair_ > 0 ? npair_ - 1 : 0));   // next round's, in flight while this one is tested
         if (p < npair_) {
-          const PairL Q = pair_load(p);   // one record: four independent 16-byte loads (was pair_i -> cg_rbound / cg_type / cg_size -> pair_f, word by word)
+          const PairL Q = pair_decode(praw);   // one record: four independent 16-byte loads (was pair_i -> cg_rbound / cg_type / cg_size -> pair_f, word by word)
           const int P[6] = {Q.g1, Q.g2, Q.dl, Q.kc, Q.pt, Q.cd};
           if (HF && P[4] == 4) {
             const int g2 = P[1], ty = Q.t2;
@@ -1189,11 +1212,12 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         float mpr_n[3] = {0.f, 0.f, 0.f};
         bool hit = false, hit2 = false;   // a plane-capsule pair can give two contacts (one per end sphere)
         float dist = 0, dist2 = 0, cpos[3] = {0, 0, 0}, cpos2[3] = {0, 0, 0}, nrm[3] = {1, 0, 0};
-        int p = -1;
+        int p = -1, cword = 0;            // cword: what the row stage needs of the pair without another table read (pair | dofs << 11 | dof-list start << 16)
         if (ci < ncand) {
           const int cw = (ci < NCAND) ? cand[ci] : ovf_cand[ci - NCAND];
           p = HF ? (cw & 1023) : cw;
           const PairL Q = pair_load(p);
+          cword = p | (Q.kc << 11) | (Q.dl << 16);
           const int P[6] = {Q.g1, Q.g2, Q.dl, Q.kc, Q.pt, Q.cd};
           int g1 = P[0], g2 = P[1];
           float margin = Q.margin;
@@ -1417,13 +1441,13 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           E[Y.cdist + pos] = dist;
 #pragma unroll
           for (int k = 0; k < 3; k++) { E[Y.cpos + 3 * pos + k] = cpos[k]; E[Y.cnrm + 3 * pos + k] = nrm[k]; }
-          ((int*)(E + Y.cpair))[pos] = p;
+          ((int*)(E + Y.cpair))[pos] = cword;
         } else if (hit && pos < nct) {
           float* g = ovf_env + (pos - NC) * ovf_row;
           g[0] = dist;
 #pragma unroll
           for (int k = 0; k < 3; k++) { g[1 + k] = cpos[k]; g[4 + k] = nrm[k]; }
-          ((int*)g)[7] = p;
+          ((int*)g)[7] = cword;
         }
         ncon += __popcll(bal);
         bal = FULL ? __ballot(hit2) : 0ull;
@@ -1433,13 +1457,13 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             E[Y.cdist + pos] = dist2;
 #pragma unroll
             for (int k = 0; k < 3; k++) { E[Y.cpos + 3 * pos + k] = cpos2[k]; E[Y.cnrm + 3 * pos + k] = nrm[k]; }
-            ((int*)(E + Y.cpair))[pos] = p;
+            ((int*)(E + Y.cpair))[pos] = cword;
           } else if (hit2 && pos < nct) {
             float* g = ovf_env + (pos - NC) * ovf_row;
             g[0] = dist2;
 #pragma unroll
             for (int k = 0; k < 3; k++) { g[1 + k] = cpos2[k]; g[4 + k] = nrm[k]; }
-            ((int*)g)[7] = p;
+            ((int*)g)[7] = cword;
           }
           ncon += __popcll(bal);
         }
@@ -1486,8 +1510,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     int nefc_b1 = 0;
     // (generic lambda: instantiated once with LDS pointers and once with the HBM overflow row, so that each copy keeps its own address space)
     auto build_row = [&](const float* pdist, const float* ppos, const float* pnrm, const int* ppair, float* cJ, unsigned int* cdw) {
-      int p = ppair[0];
-      const float4 pq0_ = W.pair_rec[4 * (size_t)(p)]; const int pw_ = __float_as_int(pq0_.x); const int P[6] = {pw_ & 255, (pw_ >> 8) & 255, __float_as_int(pq0_.w), (pw_ >> 24) & 255, (pw_ >> 16) & 15, (pw_ >> 20) & 15};
+      const int cw_ = ppair[0], p = cw_ & 2047;
+      const float4 pq0_ = W.pair_rec[4 * (size_t)(p)]; const int pw_ = __float_as_int(pq0_.x); const int P[6] = {pw_ & 255, (pw_ >> 8) & 255, (int)((unsigned int)cw_ >> 16), (cw_ >> 11) & 31, (pw_ >> 16) & 15, (pw_ >> 20) & 15};
       const float* F = M.pair_f + 12 * p;
       float n[3] = {pnrm[0], pnrm[1], pnrm[2]}, t1[3], t2[3];
       float cp[3] = {ppos[0], ppos[1], ppos[2]};
@@ -1560,7 +1584,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         const int c = c0 + rg;
         float pv0 = 0.f, pv1 = 0.f, pv2 = 0.f;
         auto row_cols = [&](const float* ppos, const float* pnrm, const int* ppair, float* cJ, unsigned int* cdw) {
-          const float4 pq0_ = W.pair_rec[4 * (size_t)(ppair[0])]; const int pw_ = __float_as_int(pq0_.x); const int P[6] = {pw_ & 255, (pw_ >> 8) & 255, __float_as_int(pq0_.w), (pw_ >> 24) & 255, (pw_ >> 16) & 15, (pw_ >> 20) & 15};
+          const int cw_ = ppair[0];
+          const int P[4] = {0, 0, (int)((unsigned int)cw_ >> 16), (cw_ >> 11) & 31};      // dof-list start and length travel with the contact: no pair-table read here
           const float n[3] = {pnrm[0], pnrm[1], pnrm[2]}, cp[3] = {ppos[0], ppos[1], ppos[2]};
           float t1[3], t2[3];
           make_frame(n, t1, t2);
@@ -1596,11 +1621,10 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       SYNC();
       if (lane < ncon) {
         const float* g = lane < NC ? nullptr : ovf_env + (lane - NC) * ovf_row;
-        const int p = lane < NC ? ((const int*)(E + Y.cpair))[lane] : ((const int*)g)[7];
+        const int cw_ = lane < NC ? ((const int*)(E + Y.cpair))[lane] : ((const int*)g)[7], p = cw_ & 2047;
         const float dist = lane < NC ? E[Y.cdist + lane] : g[0];
-        const float4 pq0_ = W.pair_rec[4 * (size_t)(p)]; const int pw_ = __float_as_int(pq0_.x); const int P[6] = {pw_ & 255, (pw_ >> 8) & 255, __float_as_int(pq0_.w), (pw_ >> 24) & 255, (pw_ >> 16) & 15, (pw_ >> 20) & 15};
         const float* F = M.pair_f + 12 * p;
-        ckc = P[3];
+        ckc = (cw_ >> 11) & 31;
         const float incl = F[0] - F[1];
         cmu = F[2];
         float imp = impedance(F + 6, dist, incl), K, B;
@@ -1622,7 +1646,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         SYNC();
         const int c = c0 + rg;
         auto row_cols = [&](const float* ppos, const float* pnrm, const int* ppair, float* cJ, unsigned int* cdw) {
-          const float4 pq0_ = W.pair_rec[4 * (size_t)(ppair[0])]; const int pw_ = __float_as_int(pq0_.x); const int P[6] = {pw_ & 255, (pw_ >> 8) & 255, __float_as_int(pq0_.w), (pw_ >> 24) & 255, (pw_ >> 16) & 15, (pw_ >> 20) & 15};
+          const int cw_ = ppair[0];
+          const float4 pq0_ = W.pair_rec[4 * (size_t)(cw_ & 2047)]; const int pw_ = __float_as_int(pq0_.x); const int P[6] = {pw_ & 255, (pw_ >> 8) & 255, (int)((unsigned int)cw_ >> 16), (cw_ >> 11) & 31, (pw_ >> 16) & 15, (pw_ >> 20) & 15};
           const float n[3] = {pnrm[0], pnrm[1], pnrm[2]}, cp[3] = {ppos[0], ppos[1], ppos[2]};
           float t1[3], t2[3];
           make_frame(n, t1, t2);
@@ -1674,7 +1699,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
                             float& cD2, int& ckc) {
         const int lane = cc;     // (the body below is the one-bank code: it indexes the contact tables with `lane`)
         const float* g = lane < NC ? nullptr : ovf_env + (lane - NC) * ovf_row;
-        const int p = lane < NC ? ((const int*)(E + Y.cpair))[lane] : ((const int*)g)[7];
+        const int cw_ = lane < NC ? ((const int*)(E + Y.cpair))[lane] : ((const int*)g)[7], p = cw_ & 2047;
         const float dist = lane < NC ? E[Y.cdist + lane] : g[0];
         const float4 pq0_ = W.pair_rec[4 * (size_t)(p)]; const int pw_ = __float_as_int(pq0_.x); const int P[6] = {pw_ & 255, (pw_ >> 8) & 255, __float_as_int(pq0_.w), (pw_ >> 24) & 255, (pw_ >> 16) & 15, (pw_ >> 20) & 15};
         const float* F = M.pair_f + 12 * p;
@@ -2074,6 +2099,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         if (lane < NVT) {
 #pragma unroll
           for (int k = 0; k < NVT; k++) E[Y.sq + lane * (NVT + 1) + k] = r[k];
+          E[Y.sq + lane * (NVT + 1) + NVT] = invd;
         }
         SYNC();
         SUB(2);
@@ -2095,6 +2121,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         if (lane < NVT) {
 #pragma unroll
           for (int k = 0; k < NVT; k++) E[Y.sq + lane * (NVT + 1) + k] = r[k];
+          E[Y.sq + lane * (NVT + 1) + NVT] = invd;      // 1 / D in the padding column, for the iterations that reuse the factor
         }
         SYNC();
       } else {
@@ -2102,7 +2129,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         const int ll = lane < NVT ? lane : 0;
 #pragma unroll
         for (int k = 0; k < NVT; k++) r[k] = E[Y.sq + ll * (NVT + 1) + k];
-        invd = 1.0f / E[Y.sq + ll * (NVT + 1) + ll];
+        invd = E[Y.sq + ll * (NVT + 1) + NVT];
       }
       SUB(2);
       x = chol_solve_rows<NVT>(r, invd, rhs, E + Y.sq, lane);
