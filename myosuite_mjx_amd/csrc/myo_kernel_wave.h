@@ -264,7 +264,7 @@ template <class LY> __device__ __forceinline__ float straight_w(const DevModelW&
                                                               float invdiv, bool active, const int4& first) {
   float dif[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
   float dist = norm3(dif);
-  float inv = dist > MINVALF ? 1.0f / dist : 0.f;
+  float inv = dist > MINVALF ? __builtin_amdgcn_rcpf(dist) : 0.f;   // (the intrinsic: `1.0f / dist` times three became three full divisions)
   dif[0] *= inv; dif[1] *= inv; dif[2] *= inv;
   // a lane that does not keep this piece (wrapping segment vs direct piece, or the reverse) runs zero iterations: the wave's trip count is
   // the longest dof list among the lanes that DO keep it, and zero when none does.  Four entries per 16-byte load; the first row was
@@ -1488,7 +1488,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           float R = fmaxf(MINVALF, (1 - imp) / imp * J[11]);
           kbi(J[4], J[5], J[7], M.timestep, &K, &B);
           laref = -B * (lsign * E[Y.qvel + lane]) - K * imp * (dist - margin);
-          lD = 1.0f / R;
+          lD = __builtin_amdgcn_rcpf(R);
         }
       }
     }
@@ -1566,7 +1566,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         cD = 0.25f / fmaxf(MINVALF, (1 - imp) / imp * F[3]);
       } else {
         float R0 = fmaxf(MINVALF, (1 - imp) / imp * F[3] * (1 + cmu * cmu));
-        cD = 1.0f / fmaxf(MINVALF, 2 * cmu * cmu * R0);
+        cD = __builtin_amdgcn_rcpf(fmaxf(MINVALF, 2 * cmu * cmu * R0));
       }
       float pos = -K * imp * (dist - incl);
       caref[0] = -B * (vn + cmu * vt1) + pos; caref[1] = -B * (vn - cmu * vt1) + pos;
@@ -1630,7 +1630,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         float imp = impedance(F + 6, dist, incl), K, B;
         kbi(F[4], F[5], F[7], M.timestep, &K, &B);
         const float R0 = fmaxf(MINVALF, (1 - imp) / imp * F[3] * (1 + cmu * cmu));
-        cD = 1.0f / fmaxf(MINVALF, 2 * cmu * cmu * R0);
+        cD = __builtin_amdgcn_rcpf(fmaxf(MINVALF, 2 * cmu * cmu * R0));
         const float pos = -K * imp * (dist - incl);
         caref[0] = -B * (vn_c + cmu * vt1_c) + pos; caref[1] = -B * (vn_c - cmu * vt1_c) + pos;
         caref[2] = -B * (vn_c + cmu * vt2_c) + pos; caref[3] = -B * (vn_c - cmu * vt2_c) + pos;
@@ -1714,7 +1714,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           cD = 0.25f / fmaxf(MINVALF, (1 - imp) / imp * F[3]);
         } else {
           float R0 = fmaxf(MINVALF, (1 - imp) / imp * F[3] * (1 + cmu * cmu));
-          cD = 1.0f / fmaxf(MINVALF, 2 * cmu * cmu * R0);
+          cD = __builtin_amdgcn_rcpf(fmaxf(MINVALF, 2 * cmu * cmu * R0));
         }
         const float pos = -K * imp * (dist - incl);
         caref[0] = -B * (vn_c + cmu * vt1_c) + pos; caref[1] = -B * (vn_c - cmu * vt1_c) + pos;
@@ -1841,7 +1841,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       float imp = impedance(F + 9, pos, 0.f), K, B;
       kbi(F[7], F[8], F[10], M.timestep, &K, &B);
       earef = -B * vel - K * imp * pos;
-      eD = 1.0f / fmaxf(MINVALF, (1 - imp) / imp * F[14]);
+      eD = __builtin_amdgcn_rcpf(fmaxf(MINVALF, (1 - imp) / imp * F[14]));
     }
     nefc += neq;
     SYNC();

@@ -338,8 +338,11 @@ __device__ __forceinline__ void cobj_shape(CObj& o, int type, const float* size)
 // support point of the un-inflated shape in its own frame, for a direction given in that frame
 __device__ __forceinline__ void support_local(const float* S, float h, const float* dl, float* pl) {
   float s[3] = {S[0] * dl[0], S[1] * dl[1], S[2] * dl[2]};
-  float n = norm3(s);
-  float inv = n > MINVALF ? 1.0f / n : 0.f;
+  // v_rsq_f32 on the squared norm.  (Written as 1.0f / norm3(s), the optimiser turned the three products with the reciprocal into three divisions of
+  // its own making, which no longer carried the fast-division marking of the source: three full IEEE expansions, ~30 instructions, per support call --
+  // sixty per MPR step.  The intrinsic cannot be folded.)
+  const float n2 = dot3(s, s);
+  const float inv = n2 > MINVALF * MINVALF ? __builtin_amdgcn_rsqf(n2) : 0.f;
   pl[0] = S[0] * s[0] * inv; pl[1] = S[1] * s[1] * inv; pl[2] = S[2] * s[2] * inv + (dl[2] >= 0 ? h : -h);
 }
 // polytope shapes (TrackEnv kernels, MPR mode 2): h = -2: box with half sizes S; h = -3: convex hull, S[0] vertices at `verts` (support = best vertex)
