@@ -675,7 +675,8 @@ __device__ __forceinline__ bool mpr_penetration_wl(const CObj& o1, const CObj& o
       normalize3(dir);
     }
   }
-#define PORTAL_DIR() { float a_[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, b_[3] = {p3[0] - p1[0], p3[1] - p1[1], p3[2] - p1[2]}; cross3(dir, a_, b_); normalize3(dir); }
+#define PORTAL_DIR() { float a_[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, b_[3] = {p3[0] - p1[0], p3[1] - p1[1], p3[2] - p1[2]}; cross3(dir, a_, b_); \
+    const float n2_ = dot3(dir, dir); if (n2_ < MINVALF * MINVALF) { dir[0] = 1.f; dir[1] = 0.f; dir[2] = 0.f; } else { const float i_ = __builtin_amdgcn_rsqf(n2_); dir[0] *= i_; dir[1] *= i_; dir[2] *= i_; } }
 #define EXPAND_PORTAL() { \
     P0LOAD(); float va_[3]; cross3(va_, s.v, p0); \
     const int idx_ = dot3(p1, va_) > 0 ? (dot3(p2, va_) > 0 ? 1 : 3) : (dot3(p3, va_) > 0 ? 2 : 1); \
@@ -687,7 +688,7 @@ __device__ __forceinline__ bool mpr_penetration_wl(const CObj& o1, const CObj& o
     if (dot3(dir, p1) >= 0) break;
     mink_support<HF>(o1, o2, dir, s, T);
     float dv4 = dot3(s.v, dir);
-    float dmin = fminf(fminf(dv4 - dot3(p1, dir), dv4 - dot3(p2, dir)), dv4 - dot3(p3, dir));
+    float dmin = dv4 - dot3(p1, dir);   // dir is the portal's normal: p1, p2, p3 have the same component along it (the oracle takes the min of the three: equal up to round-off)
     if (dv4 < 0 || dmin <= tol) return false;
     EXPAND_PORTAL();
   }
@@ -695,7 +696,7 @@ __device__ __forceinline__ bool mpr_penetration_wl(const CObj& o1, const CObj& o
     PORTAL_DIR();
     mink_support<HF>(o1, o2, dir, s, T);
     float dv4 = dot3(s.v, dir);
-    float dmin = fminf(fminf(dv4 - dot3(p1, dir), dv4 - dot3(p2, dir)), dv4 - dot3(p3, dir));
+    float dmin = dv4 - dot3(p1, dir);   // dir is the portal's normal: p1, p2, p3 have the same component along it (the oracle takes the min of the three: equal up to round-off)
     if (dmin <= tol || it > maxit) { if (nsup) *nsup = it; break; }
     EXPAND_PORTAL();
   }
