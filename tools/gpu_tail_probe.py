@@ -7,7 +7,7 @@ os.environ["MYO_HIP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path
 from myosuite_mjx_amd import capi
 from myosuite_mjx_amd.envs import BatchedMyoEnv
 
-B = 4096
+B = int(os.environ.get("B", 4096))
 NAMES = ["load/check", "kinematics", "tendon+muscle", "dynamics", "narrow phase", "rows", "frames+broad", "newton", "euler", "store"]
 env = BatchedMyoEnv("myoHandPoseRandom-v0", num_envs=B, as_torch=False)
 mode = capi.BENCH_OBS | capi.BENCH_FRESH_ACTIONS | capi.BENCH_AUTORESET
