@@ -1847,12 +1847,31 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     SYNC();
     // the mass matrix moves from the square buffer (about to be reused for the Hessian) to a packed copy that
     // aliases the now dead broad-phase scratch
+    // ... and this lane's full (symmetric) row stays in registers for the solver: M * x is then NVT broadcast-multiply-adds with no LDS read or
+    // address arithmetic (twice and a half per substep), and the Newton rows H = M + J^T D J start from it
+    // (36-dof instantiations only: they run two waves per SIMD on a 256-register budget.  In the 24-dof kernels, at four waves per SIMD, the 24 extra
+    // live registers spill -- 23 in the headline kernel -- so those keep reading the packed copy.)
+    constexpr bool MROW = NVT > 24;
+    float mrow[MROW ? NVT : 1];
+    if constexpr (MROW) {
+      const int ml = lane < nv ? lane : 0;
+#pragma unroll
+      for (int k = 0; k < NVT; k++) mrow[k] = lane < nv ? E[Y.sq + ml * (NVT + 1) + k] : 0.f;
+    }
     if (lane < nv) {
       const int based = (lane * (lane + 1)) / 2;
 #pragma unroll
       for (int k = 0; k < NVT; k++) if (k <= lane) E[Y.Mp + based + k] = E[Y.sq + lane * (NVT + 1) + k];
     }
     const float* Mp = E + Y.Mp;
+    auto symv_reg = [&](float x, int lane) -> float {      // (lane by value: inside the Newton loop it is that loop's opaque copy, see there)
+      if constexpr (MROW) {
+        float s0 = 0.f, s1 = 0.f;      // two partial sums: half the dependent chain
+#pragma unroll
+        for (int k = 0; k < NVT; k += 2) { s0 = fmaf(mrow[k], rdlane(x, k), s0); if (k + 1 < NVT) s1 = fmaf(mrow[k + 1], rdlane(x, k + 1), s1); }
+        return s0 + s1;
+      } else return symv_lds<NVT>(Mp, x, lane, nv);
+    };
     SYNC();
     STAMP(5);
     SUB0();
@@ -1865,7 +1884,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     int phase = nefc > 0 ? 0 : 1, iters = 0;
     if (phase == 0) {  // start from the warm start (MuJoCo also tries qacc_smooth; the minimiser is the same)
       qacc = warm_r;
-      Ma = symv_lds<NVT>(Mp, qacc, lane, nv);
+      Ma = symv_reg(qacc, lane);
       ljar = lsign * qacc - laref;
       if constexpr (TRK) fljar = qacc - flaref;
       if (lane < nv) E[Y.xv + lane] = qacc;
@@ -2112,7 +2131,9 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         const float diag_add = (phase == 2 && !RK4) ? h * M.dof_damping[dd] : 0.f;
 #pragma unroll
         for (int k = 0; k < NVT; k++) {
-          float mv = (lane < nv && k <= lane) ? Mp[based + (k <= dd ? k : 0)] : 0.f;                 // lower row of M
+          float mv;
+          if constexpr (MROW) mv = (k <= lane) ? mrow[k] : 0.f;                                      // lower row of M (zero for lanes >= nv)
+          else mv = (lane < nv && k <= lane) ? Mp[based + (k <= dd ? k : 0)] : 0.f;
           float hv = (phase == 0 && lane < nv) ? E[Y.sq + lane * (NVT + 1) + k] : 0.f;              // J^T D J (active rows)
           r[k] = (lane < nv) ? mv + hv + (k == lane ? diag_add : 0.f) : (k == lane ? 1.f : 0.f);
         }
@@ -2139,7 +2160,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       if (phase == 2) { qaccE = x; break; }
       // ---- Newton: exact line search along x
       float search = lane < nv ? x : 0.f;
-      float Mv = symv_lds<NVT>(Mp, search, lane, nv);
+      float Mv = symv_reg(search, lane);
       ljv = lsign * search;
       if constexpr (TRK) fljv = search;
       if (lane < nv) E[Y.xv + lane] = search;
