@@ -663,7 +663,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         const float ang = E[Y.qpos + qa] - M.qpos0[qa];
         const bool hinge = M.dof_type[d] == 3;
         float sn, cs;
-        sincosf(ang, &sn, &cs);
+        sincos_jf(ang, &sn, &cs);
         const float oc = 1 - cs, x = al[0], y = al[1], z = al[2];
         const float Rj[9] = {cs + oc * x * x, oc * x * y - sn * z, oc * x * z + sn * y, oc * x * y + sn * z, cs + oc * y * y, oc * y * z - sn * x,
                              oc * x * z - sn * y, oc * y * z + sn * x, cs + oc * z * z};

@@ -82,6 +82,21 @@ __device__ __forceinline__ void sincos_q1f(float th, float* sn, float* cs) {   /
   const float c = 1.f + z * (-0.5f + z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f)));
   *sn = hi ? c : s; *cs = hi ? s : c;
 }
+// sin / cos of a joint angle (kinematics): Cody-Waite reduction by pi/2 in two fused steps (|x| of a few turns: joint coordinates), the same
+// [-pi/4, pi/4] polynomials as above, quadrant by swap and sign -- about 25 instructions against the library's ~60 with its large-argument path
+__device__ __forceinline__ void sincos_jf(float x, float* sn, float* cs) {
+  if (MYO_EXACT_TRIG) { sincosf(x, sn, cs); return; }
+  const float k = rintf(x * 0.636619772367581343f);
+  float r = fmaf(-k, 1.57079637050628662109375f, x);
+  r = fmaf(-k, -4.37113882867379116e-8f, r);
+  const float z = r * r;
+  const float s = r + r * z * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+  const float c = 1.f + z * (-0.5f + z * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f)));
+  const int q = (int)k;
+  const float a = (q & 1) ? c : s, b = (q & 1) ? s : c;
+  *sn = (q & 2) ? -a : a;
+  *cs = ((q + 1) & 2) ? -b : b;
+}
 __device__ float wrap_inside(float* pnt, const float* d, float rad) {
   const float zinit = 1.f - 1e-7f, tolerance = 1e-6f;
   float len0 = sqrtf(d[0] * d[0] + d[1] * d[1]), len1 = sqrtf(d[2] * d[2] + d[3] * d[3]);
