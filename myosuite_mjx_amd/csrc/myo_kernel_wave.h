@@ -1851,7 +1851,11 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
     // address arithmetic (twice and a half per substep), and the Newton rows H = M + J^T D J start from it
     // (36-dof instantiations only: they run two waves per SIMD on a 256-register budget.  In the 24-dof kernels, at four waves per SIMD, the 24 extra
     // live registers spill -- 23 in the headline kernel -- so those keep reading the packed copy.)
+#ifdef MYO_NO_MROW
+    constexpr bool MROW = false;
+#else
     constexpr bool MROW = NVT > 24;
+#endif
     float mrow[MROW ? NVT : 1];
     if constexpr (MROW) {
       const int ml = lane < nv ? lane : 0;
@@ -2100,7 +2104,10 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       }
       rhs = phase == 0 ? -grad : (phase == 1 ? smooth : smooth + qfc);
       float x;
-      if (SPEC != 0 && !RK4 && phase != 0) {
+#ifndef MYO_NO_TREE
+#define MYO_NO_TREE 0
+#endif
+      if (SPEC != 0 && !RK4 && phase != 0 && !MYO_NO_TREE) {
         // unconstrained and Euler solves of the size-specialised instantiations: M (+ h D) factorised leaves first, tree-sparse
         constexpr int NVS = SpecTree<SPEC>::nv > 0 ? SpecTree<SPEC>::nv : 1;
         const bool act = lane < NVS;

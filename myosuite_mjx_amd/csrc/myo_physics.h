@@ -33,10 +33,22 @@ __device__ float wrap_circle(float* pnt, const float* d, const float* sd, bool h
     sol[i][2] = (d[2] * sqr - sgn * rad * d[3] * s1) / sq1;
     sol[i][3] = (d[3] * sqr + sgn * rad * d[2] * s1) / sq1;
     if (has_side) {
+      // MuJoCo scores a candidate by the direction of the sum of its two tangent points against the side site.  When the tangent points are
+      // nearly antipodal (a half-turn wrap) that sum is the difference of two almost opposite vectors: in float32 its direction is round-off,
+      // the score any number in [-1, 1], and the half-turn candidate can beat the right one -- a 1 cm jump of the tendon length (found in round 3
+      // on tendon UI_UB4: |sum| = 1.6e-6 r).  The sum is always perpendicular to the chord between the tangent points (both have length r), so
+      // whichever of the two is longer gives the direction; the sum then only contributes its sign, which is what is undetermined at a half turn.
       float t0 = sol[i][0] + sol[i][2], t1 = sol[i][1] + sol[i][3];
-      float n = sqrtf(t0 * t0 + t1 * t1);
-      if (n > MINVALF) { t0 /= n; t1 /= n; }
-      good[i] = t0 * sd[0] + t1 * sd[1];
+      const float c0 = sol[i][0] - sol[i][2], c1 = sol[i][1] - sol[i][3];
+      const float n2 = t0 * t0 + t1 * t1, c2 = c0 * c0 + c1 * c1;
+      if (n2 >= c2) {
+        const float n = sqrtf(n2);
+        if (n > MINVALF) { t0 /= n; t1 /= n; }
+        good[i] = t0 * sd[0] + t1 * sd[1];
+      } else {
+        const float inv = __builtin_amdgcn_rsqf(c2), sg = (t1 * c0 - t0 * c1) < 0.f ? -1.f : 1.f;   // unit perpendicular of the chord (-c1, c0) / |c|
+        good[i] = sg * (c0 * sd[1] - c1 * sd[0]) * inv;
+      }
     } else {
       float t0 = sol[i][0] - sol[i][2], t1 = sol[i][1] - sol[i][3];
       good[i] = -(t0 * t0 + t1 * t1);
@@ -85,6 +97,9 @@ __device__ __forceinline__ void sincos_q1f(float th, float* sn, float* cs) {   /
 // sin / cos of a joint angle (kinematics): Cody-Waite reduction by pi/2 in two fused steps (|x| of a few turns: joint coordinates), the same
 // [-pi/4, pi/4] polynomials as above, quadrant by swap and sign -- about 25 instructions against the library's ~60 with its large-argument path
 __device__ __forceinline__ void sincos_jf(float x, float* sn, float* cs) {
+#ifdef MYO_KIN_LIBM
+  sincosf(x, sn, cs); return;
+#endif
   if (MYO_EXACT_TRIG) { sincosf(x, sn, cs); return; }
   const float k = rintf(x * 0.636619772367581343f);
   float r = fmaf(-k, 1.57079637050628662109375f, x);

@@ -555,9 +555,21 @@ static real wrap_circle(real* pnt, const real* d, const real* sd, real rad) {
     sol[i][3] = (d[3] * sqr + sgn * rad * d[2] * s1) / sq1;
     if (sd) {
       real t[2] = {sol[i][0] + sol[i][2], sol[i][1] + sol[i][3]};
+#ifdef MYOO_FLOAT
+      /* float build (mirrors the HIP kernel, csrc/myo_physics.h wrap_circle): nearly antipodal tangent points make the sum round-off in float32;
+       * its direction is then taken from the chord between the tangent points (always perpendicular to the sum), the sum keeps only its sign */
+      real c[2] = {sol[i][0] - sol[i][2], sol[i][1] - sol[i][3]};
+      real n2 = t[0] * t[0] + t[1] * t[1], c2 = c[0] * c[0] + c[1] * c[1];
+      if (n2 < c2) {
+        real inv = 1 / sqrt(c2), sg = (t[1] * c[0] - t[0] * c[1]) < 0 ? -1 : 1;
+        good[i] = sg * (c[0] * sd[1] - c[1] * sd[0]) * inv;
+      } else
+#endif
+      {
       real n = sqrt(t[0] * t[0] + t[1] * t[1]);
       if (n > MINVAL) { t[0] /= n; t[1] /= n; }
       good[i] = t[0] * sd[0] + t[1] * sd[1];
+      }
     } else {
       real t[2] = {sol[i][0] - sol[i][2], sol[i][1] - sol[i][3]};
       good[i] = -(t[0] * t[0] + t[1] * t[1]);

@@ -390,6 +390,26 @@ def test_motor_envs_action_map_and_observation_layout(motorfinger, exo):
         myo.make("myoElbowPose1D6MExoRandom-v0", num_envs=1)
 
 
+def test_wrap_at_a_half_turn_candidate(hand, hipmodel, oracle64):
+    """GPU side of tests/test_oracle.py::test_float32_wrap_survives_a_half_turn_candidate: 2048 copies of the state within 3e-7 rad, one substep; before the
+    fix about one copy in 500 came back with tendon UI_UB4 10.4 mm too long and a velocity error of 0.9 rad/s."""
+    from myosuite_mjx_amd import capi
+    st = np.load(os.path.join(ROOT, "tests", "golden", "wrap_halfturn_state.npz"))
+    K = 2048
+    rng = np.random.default_rng(0)
+    q = np.tile(st["qpos"], (K, 1)).astype(np.float32)
+    q[1:] += rng.normal(0, 3e-7, (K - 1, hand.nq)).astype(np.float32)
+    b = capi.HipBatch(hipmodel, K)
+    b.write(capi.F_QPOS, q); b.write(capi.F_QVEL, np.tile(st["qvel"], (K, 1))); b.write(capi.F_ACT, np.tile(st["act"], (K, 1)))
+    b.write(capi.F_CTRL, np.tile(st["act"], (K, 1))); b.write(capi.F_WARMSTART, np.tile(st["warmstart"], (K, 1)))
+    b.step(None, capi.ACTMAP_NONE, 1)
+    oracle64.set_state(qpos=st["qpos"].astype(float)); oracle64.fwd_position()
+    ref = np.asarray(oracle64.field("ten_length"))[:hand.nu]
+    assert (b.status() == 0).all()
+    assert np.abs(b.read(capi.F_TENLEN) - ref[None]).max() < 5e-6      # (3e-7 rad x moment arms of centimetres: the copies agree with the centre state)
+    assert np.abs(b.read(capi.F_QACC)).max() < 200.0                    # 91 at this state; the wrong branch gave 725 rad/s^2
+
+
 def test_size_specialised_and_generic_instantiations_agree(hand, legs):
     """The wave kernel has size-specialised instantiations for the config models (loop bounds as compile-time constants) and
     run-time-sized ones for anything else; MYO_NO_SPEC=1 at model load forces the latter.  Same algorithm; results agree to float32 round-off."""

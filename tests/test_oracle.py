@@ -1,7 +1,11 @@
 """Oracle pinning and invariants (CPU).  Golden: the MuJoCo-computed muscle `lengthrange` values that the
 reference's own model file stores (simhive/myo_sim/hand/assets/myohand_assets.xml:501-539)."""
+import os
+
 import numpy as np
 import pytest
+
+from conftest import ROOT
 
 # tendons whose stored lengthrange is consistent with the shipped geometry on BOTH ends (the rest were computed on
 # an earlier edit of the model): sphere, cylinder and inside-wrap ("torus") paths are all covered
@@ -153,6 +157,23 @@ def test_f32_oracle_gap_is_small(hand, oracle64, oracle32):
         oracle32.set_state(qpos=q); oracle32.fwd_position()
         worst = max(worst, np.abs(oracle64.field("ten_length") - oracle32.field("ten_length")).max())
     assert worst < 2e-5
+
+
+def test_float32_wrap_survives_a_half_turn_candidate(hand, oracle64, oracle32):
+    """tests/golden/wrap_halfturn_state.npz: a MyoHand state (found in round 3 by the instantiation-agreement test) where, for the second cylinder of
+    tendon UI_UB4, one of wrap_circle's two candidates has its tangent points antipodal to 1.6e-6 r.  MuJoCo scores a candidate by the direction of
+    the SUM of its tangent points; in float32 that sum was pure round-off there, the score a random number, and for 0.2 % of the states within
+    3e-7 rad the half-turn candidate won: the tendon 10.4 mm longer.  The float code (oracle float build = HIP kernel) now takes the direction from
+    the chord between the tangent points when that is the longer vector; float64 keeps MuJoCo's form."""
+    st = np.load(os.path.join(ROOT, "tests", "golden", "wrap_halfturn_state.npz"))
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for i in range(1500):
+        q = st["qpos"].astype(float) + (rng.normal(0, 3e-7, hand.nq) if i else 0.0)
+        oracle64.set_state(qpos=q); oracle64.fwd_position()
+        oracle32.set_state(qpos=q); oracle32.fwd_position()
+        worst = max(worst, np.abs(oracle64.field("ten_length") - oracle32.field("ten_length")).max())
+    assert worst < 2e-6, worst
 
 
 def test_oracle_deterministic_and_batch_driver(hand, oracle64):
