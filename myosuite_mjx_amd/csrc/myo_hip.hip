@@ -402,7 +402,7 @@ int myo_model_load(const void* blobv, size_t nbytes, int device, myo_model** out
         w.kin_pk = (decltype(w.kin_pk))t0; w.link_desc = (decltype(w.link_desc))t1; w.link_adof = (decltype(w.link_adof))t2; w.dof_anc = (decltype(w.dof_anc))t3;
       }
     }
-    const bool common = d.nl <= 64 && d.ncg <= 64 && w.nq <= 64 && w.neq <= 64 && d.maxnnz <= 20;
+    const bool common = d.nl <= 64 && d.ncg <= (m->trk ? 128 : 64) && w.nq <= 64 && w.neq <= 64 && d.maxnnz <= 20;   // (geom ids are bytes in the pair record; the TRK kernel loops over geoms)
     const bool needs_full = w.has_free || w.neq > 0 || plane_pairs || condim1 || m->trk;
     if (m->trk) {
       if (!(common && d.nv <= 36 && d.nu <= 128 && d.ngt <= 128 && d.maxkc <= 20 && !w.hf.on && !w.has_tl)) { myo_model_free(m); return fail(MYO_E_UNSUPPORTED, "condim-4 / friction-loss / box / mesh model exceeds the limits of the TRK step kernel"); }

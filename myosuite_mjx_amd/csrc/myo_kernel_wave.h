@@ -1056,12 +1056,12 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
       int ncand = 0;
       int* cand = (int*)(E + Y.cand);
       PairRaw pnext = pair_raw(min(lane, npair_ > 0 ? npair_ - 1 : 0));   // broad phase, round 0: requested here, behind the geom frames
-      if (lane < ncg_) {   // world centre and long axis (3rd column) of every collision geom
+      for (int g = lane; g < ncg_; g += 64) {   // world centre and long axis (3rd column) of every collision geom (more than 64: MyoDM teapot, wineglass)
         float x[3], R[9];
-        geom_world_pos(W, Y, E, lane, x);
-        geom_world_mat(W, Y, E, lane, R);
-        E[Y.gpos + 3 * lane] = x[0]; E[Y.gpos + 3 * lane + 1] = x[1]; E[Y.gpos + 3 * lane + 2] = x[2];
-        E[Y.gax + 3 * lane] = R[2]; E[Y.gax + 3 * lane + 1] = R[5]; E[Y.gax + 3 * lane + 2] = R[8];
+        geom_world_pos(W, Y, E, g, x);
+        geom_world_mat(W, Y, E, g, R);
+        E[Y.gpos + 3 * g] = x[0]; E[Y.gpos + 3 * g + 1] = x[1]; E[Y.gpos + 3 * g + 2] = x[2];
+        E[Y.gax + 3 * g] = R[2]; E[Y.gax + 3 * g + 1] = R[5]; E[Y.gax + 3 * g + 2] = R[8];
       }
       SYNC();
       for (int base = 0; base < npair_; base += 64) {

@@ -410,7 +410,7 @@ template <int MODE> __device__ __forceinline__ void support_shape(const CObj& o,
         bd = r.x * dl[0] + r.y * dl[1] + r.z * dl[2]; bx = r.x; by = r.y; bz = r.z; bw = r.w;
       }
       for (int it = 0; it < 128; it++) {
-        const int word = (int)bw, e0 = word >> 6, deg = word & 63;
+        const int word = (int)bw, e0 = word >> 8, deg = word & 255;
         bool moved = false;
         for (int e = 0; e < deg; e += 4) {       // lists are padded to a multiple of eight records: four independent 16-byte loads in flight at a time
           float4 r[4];

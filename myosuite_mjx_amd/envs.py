@@ -140,7 +140,19 @@ for _id in [k for k in list(REGISTRY) if k.startswith("myo")]:
 # launch per env step) for the objects that have a compiled asset: MyoHand<Object>Fixed-v0 (a one-row reference), MyoHand<Object>Random-v0 (the
 # two-row randomisation range, also mjx/myodm_v0.py's module-level default) and the motion-tracking ids, whose motion file is the reference's
 # data/<motion>.npz: pass `reference=<path or dict>` or point MYODM_DATA at a directory holding it (the files are not redistributed here).
-MYODM_OBJECTS = ("airplane", "cup", "apple", "cubesmall", "duck", "mug", "hammer", "bowl")      # compiled assets myohand_object_<name>
+# The id tables are data: assets/myodm_tasks.json = the reference's OBJECTS tuple and MyoHand_task_spec entries (tools/make_myodm_registry.py);
+# an object is registered when its compiled asset assets/myohand_object_<name>.myob[.gz] is present (tools/compile_models.py: all 50).
+def _myodm_tables():
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+    with open(os.path.join(here, "myodm_tasks.json")) as f:
+        t = json.load(f)
+    have = [o for o in t["objects"] if os.path.exists(os.path.join(here, f"myohand_object_{o}.myob")) or os.path.exists(os.path.join(here, f"myohand_object_{o}.myob.gz"))]
+    return tuple(have), [tuple(x) for x in t["tasks"] if x[1] in have]
+
+
+MYODM_OBJECTS, _MYODM_TASKS = _myodm_tables()
 _DOF_ROBOT = 29
 for _obj in MYODM_OBJECTS:
     REGISTRY[f"MyoHand{_obj.title()}Fixed-v0"] = dict(task="track", object=_obj, max_episode_steps=50, reference=dict(
@@ -150,17 +162,7 @@ for _obj in MYODM_OBJECTS:
         time=np.array([0.0, 4.0]), robot=np.zeros((2, _DOF_ROBOT)), robot_vel=np.zeros((2, _DOF_ROBOT)),
         object_init=np.array([0.0, 0.0, 0.1, 1.0, 0.0, 0.0, 0.0]),
         object=np.array([[-0.2, -0.2, 0.1, 1.0, 0.0, 0.0, -1.0], [0.2, 0.2, 0.1, 1.0, 0.0, 0.0, 1.0]])))
-for _id, _obj, _motion in (      # MyoHand_task_spec entries of these objects (envs/myo/myodm/__init__.py:25-560)
-        ("MyoHandAirplaneFly-v0", "airplane", "MyoHand_airplane_fly1.npz"), ("MyoHandAirplaneLift-v0", "airplane", "MyoHand_airplane_lift.npz"),
-        ("MyoHandAirplanePass-v0", "airplane", "MyoHand_airplane_pass1.npz"), ("MyoHandAppleLift-v0", "apple", "MyoHand_apple_lift.npz"),
-        ("MyoHandApplePass-v0", "apple", "MyoHand_apple_pass1.npz"), ("MyoHandCupDrink-v0", "cup", "MyoHand_cup_drink1.npz"),
-        ("MyoHandCupPass-v0", "cup", "MyoHand_cup_pass1.npz"), ("MyoHandCupPour-v0", "cup", "MyoHand_cup_pour1.npz"),
-        ("MyoHandDuckInspect-v0", "duck", "MyoHand_duck_inspect1.npz"), ("MyoHandDuckLift-v0", "duck", "MyoHand_duck_lift.npz"),
-        ("MyoHandDuckPass-v0", "duck", "MyoHand_duck_pass1.npz"), ("MyoHandHammerUse-v0", "hammer", "MyoHand_hammer_use1.npz"),
-        ("MyoHandHammerPass-v0", "hammer", "MyoHand_hammer_pass1.npz"), ("MyoHandMugDrink3-v0", "mug", "MyoHand_mug_drink3.npz"),
-        ("MyoHandMugLift-v0", "mug", "MyoHand_mug_lift.npz"), ("MyoHandMugPass-v0", "mug", "MyoHand_mug_pass1.npz"),
-        ("MyoHandBowlDrink2-v0", "bowl", "MyoHand_bowl_drink2.npz"), ("MyoHandBowlPass-v0", "bowl", "MyoHand_bowl_pass1.npz"),
-        ("MyoHandCubesmallPass-v0", "cubesmall", "MyoHand_cubesmall_pass1.npz")):
+for _id, _obj, _motion in _MYODM_TASKS:      # MyoHand_task_spec (envs/myo/myodm/__init__.py:25-560): 89 motion-tracking ids
     REGISTRY[_id] = dict(task="track", object=_obj, max_episode_steps=75, motion=_motion)
 
 # registered by the reference but not runnable on the HIP path (DESIGN.md "out of scope")

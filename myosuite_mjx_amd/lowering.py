@@ -646,7 +646,7 @@ def lower(cm):
     A["hip_mesh_nbr"] = np.array(nbr if nbr else [0], np.int32)
     A["hip_mesh_start"] = np.array(starts if starts else [0] * 6, np.int32)
     # the same graph as self-contained records, one 16-byte load per neighbour and no index chasing: entry e of the adjacency list holds the
-    # neighbour's position AND where the neighbour's own (padded) adjacency list sits: [x, y, z, float(64 * first_entry + padded_degree)] (exact in float32).
+    # neighbour's position AND where the neighbour's own (padded) adjacency list sits: [x, y, z, float(256 * first_entry + padded_degree)] (exact in float32).
     # A climb step is then one level of independent loads; hip_mesh_startrec carries, per mesh, a 96-cell direction table of start vertices
     # (_cube_dirs) in the same form.
     rec, srec = [], []
@@ -658,10 +658,10 @@ def lower(cm):
         # time without a bounds test; first_rec[v] = where global vertex v's padded list starts
         pad4 = lambda n: (n + 7) // 8 * 8
         first_rec = np.concatenate([[0], np.cumsum([pad4(nbr_adr[v + 1] - nbr_adr[v]) for v in range(len(nbr_adr) - 1)])]).astype(int)
-        assert first_rec[-1] < (1 << 18), "adjacency entry numbers are stored exactly in a float32"
+        assert first_rec[-1] < (1 << 16), "adjacency entry numbers are stored exactly in a float32"
         for a, num in zip(adrs, nums):
-            word = lambda v: float(64 * first_rec[a + v] + pad4(nbr_adr[a + v + 1] - nbr_adr[a + v]))
-            assert max(pad4(nbr_adr[a + v + 1] - nbr_adr[a + v]) for v in range(num)) < 64
+            word = lambda v: float(256 * first_rec[a + v] + pad4(nbr_adr[a + v + 1] - nbr_adr[a + v]))
+            assert max(pad4(nbr_adr[a + v + 1] - nbr_adr[a + v]) for v in range(num)) < 256      # (the poles of the sphere meshes have ~100 neighbours)
             for v in range(num):
                 lst = nbr[nbr_adr[a + v]:nbr_adr[a + v + 1]]
                 lst = lst + [lst[-1]] * (pad4(len(lst)) - len(lst))

@@ -26,6 +26,12 @@ MODELS = {
 # more MyoDM objects (round 3): one per shape family of simhive/object_sim -- no new code, only assets (stored gzip-compressed: .myob.gz)
 for _obj in ("apple", "cubesmall", "duck", "mug", "hammer", "bowl"):
     MODELS[f"myohand_object_{_obj}"] = ("myosuite/envs/myo/assets/hand/myohand_object.xml", {"OBJECT_NAME": _obj}, "gz")
+# ... and the rest of the reference's OBJECTS tuple (envs/myo/myodm/__init__.py:586-637): every object MyoDM registers Fixed / Random / motion ids for
+for _obj in ("alarmclock", "banana", "binoculars", "camera", "coffeemug", "cubelarge", "cubemedium", "cylinderlarge", "cylindermedium", "cylindersmall",
+             "elephant", "eyeglasses", "flashlight", "flute", "gamecontroller", "hand", "headphones", "knife", "lightbulb", "mouse", "phone", "piggybank",
+             "pyramidlarge", "pyramidmedium", "pyramidsmall", "scissors", "spherelarge", "spheremedium", "spheresmall", "stamp", "stanfordbunny", "stapler",
+             "teapot", "toothbrush", "toothpaste", "toruslarge", "torusmedium", "torussmall", "train", "watch", "waterbottle", "wineglass"):
+    MODELS[f"myohand_object_{_obj}"] = ("myosuite/envs/myo/assets/hand/myohand_object.xml", {"OBJECT_NAME": _obj}, "gz")
 
 if __name__ == "__main__":
     only = sys.argv[1:]
