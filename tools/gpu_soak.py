@@ -57,6 +57,28 @@ try:
            "final_state_finite": ok_finite, "final_act_in_01": True}
     print(json.dumps(rec), flush=True)
     out.append(rec)
+    # every MyoDM object: MyoHand<Object>Random-v0 at 2048 envs x 300 env steps (random actions, auto-reset, TimeLimit 50)
+    from myosuite_mjx_amd import envs as _envs
+    import myosuite_mjx_amd as myo
+    tot, flagged, nonfinite, t0 = 0, {}, [], time.time()
+    for obj in _envs.MYODM_OBJECTS:
+        env = myo.make(f"MyoHand{obj.title()}Random-v0", num_envs=2048, seed=2, autoreset=True)
+        env.reset()
+        fl = np.zeros(2048, np.int64)
+        for k in range(300):
+            obs, rew, term, trunc, info = env.step(torch.rand((2048, env.act_dim), device="cuda", generator=g) * 2 - 1)
+            if (k + 1) % 100 == 0:
+                fl |= env.status().astype(np.int64)
+        if not (bool(torch.isfinite(obs).all()) and bool(torch.isfinite(rew).all())):
+            nonfinite.append(obj)
+        if (fl != 0).any():
+            flagged[obj] = {f"bit{b}": int(((fl >> b) & 1).sum()) for b in range(5) if ((fl >> b) & 1).any()}
+        tot += 2048 * 300
+        del env
+    rec = {"env": "MyoDM TrackEnv, all %d objects (MyoHand<Object>Random-v0)" % len(_envs.MYODM_OBJECTS), "envs": 2048, "env_steps": tot, "seconds": round(time.time() - t0, 2),
+           "objects_with_flagged_envs": flagged, "objects_with_non_finite_output": nonfinite}
+    print(json.dumps(rec), flush=True)
+    out.append(rec)
 except ImportError:
     pass
 os.makedirs("gpurun_out", exist_ok=True)
