@@ -2077,7 +2077,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
                       int db[4];
 #pragma unroll
                       for (int u = 0; u < 4; u++) {
-                        const int hb = min(hb0 + u, KC - 1);
+                        const int hb = min(hb0 + u, KC - 1);      // (measured: without the clamp the reads merge into wide LDS loads and the TRK assembly gets 20 % slower)
                         db[u] = (hb0 + u < kc) ? CDOFP(cdw, hb) : 0x7fffffff;
                         hv[u] = pn * cJ[hb] + pt * cJ[KC + hb] + pu * cJ[2 * KC + hb];
                         if constexpr (TRK) hv[u] += ps * cJ[3 * KC + hb];

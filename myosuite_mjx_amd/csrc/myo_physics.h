@@ -392,7 +392,11 @@ template <int MODE> __device__ __forceinline__ void support_shape(const CObj& o,
   if (MODE == 2 && o.h == -3.f) {
     const int n = (int)o.S[0];
     float bd = -1e30f, bx = 0.f, by = 0.f, bz = 0.f;
-    if (n <= 24) {          // small hull: scan
+#ifndef MYO_HULL_SCAN_MAX
+#define MYO_HULL_SCAN_MAX 0      // (a scan of a 10 .. 24-vertex hull is a serial chain of dependent-latency loads: 364 k -> 263 k cycles per substep in the
+                                  //  narrow phase of contact-rich TrackEnv states when every hull climbs its vertex graph instead)
+#endif
+    if (n <= MYO_HULL_SCAN_MAX) {          // small hull: scan
       for (int i = 0; i < n; i++) {
         const float x = T.vert[3 * (o.vadr + i)], y = T.vert[3 * (o.vadr + i) + 1], z = T.vert[3 * (o.vadr + i) + 2], t = x * dl[0] + y * dl[1] + z * dl[2];
         if (t > bd) { bd = t; bx = x; by = y; bz = z; }
@@ -412,12 +416,15 @@ template <int MODE> __device__ __forceinline__ void support_shape(const CObj& o,
       for (int it = 0; it < 128; it++) {
         const int word = (int)bw, e0 = word >> 8, deg = word & 255;
         bool moved = false;
-        for (int e = 0; e < deg; e += 4) {       // lists are padded to a multiple of eight records: four independent 16-byte loads in flight at a time
-          float4 r[4];
+#ifndef MYO_HULL_BURST
+#define MYO_HULL_BURST 8
+#endif
+        for (int e = 0; e < deg; e += MYO_HULL_BURST) {       // lists are padded to a multiple of eight records: eight independent 16-byte loads in flight at a time
+          float4 r[MYO_HULL_BURST];
 #pragma unroll
-          for (int k = 0; k < 4; k++) r[k] = T.rec[e0 + e + k];
+          for (int k = 0; k < MYO_HULL_BURST; k++) r[k] = T.rec[e0 + e + k];
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
+          for (int k = 0; k < MYO_HULL_BURST; k++) {
             const float t = r[k].x * dl[0] + r[k].y * dl[1] + r[k].z * dl[2];
             if (t > bd) { bd = t; bx = r[k].x; by = r[k].y; bz = r[k].z; bw = r[k].w; moved = true; }
           }
