@@ -1854,7 +1854,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
 #ifdef MYO_NO_MROW
     constexpr bool MROW = false;
 #else
-    constexpr bool MROW = NVT > 24;
+    constexpr bool MROW = NVT > 24 && !RK4;      // (the Runge-Kutta twins keep four stage derivatives per lane: no room for the row)
 #endif
     float mrow[MROW ? NVT : 1];
     if constexpr (MROW) {
@@ -2039,9 +2039,20 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
           sig_prev = sig;
           if (refactor) {
             f_fact++;
-            WFOR(i, NVT * (NVT + 1)) E[Y.sq + i] = 0;
-            SYNC();
-            if (lane < nv && (lact || flquad)) E[Y.sq + lane * (NVT + 1) + lane] = (lact ? lD : 0.f) + (flquad ? flD : 0.f);
+            // the Hessian buffer starts as M (lower rows; identity rows for the padding lanes) plus the limit / friction-loss diagonal, and the contact
+            // blocks are added on top: the factorisation then reads finished rows instead of combining two LDS reads and three selects per entry
+            if (lane < NVT) {
+              const int dd_ = lane < nv ? lane : 0;
+              const int based_ = (dd_ * (dd_ + 1)) / 2;
+              const float dg_ = (lane < nv) ? ((lact ? lD : 0.f) + (flquad ? flD : 0.f)) : 1.f;
+#pragma unroll
+              for (int k = 0; k < NVT; k++) {
+                float mv_;
+                if constexpr (MROW) mv_ = (k <= lane) ? mrow[k] : 0.f;
+                else mv_ = (lane < nv && k <= lane) ? Mp[based_ + (k <= dd_ ? k : 0)] : 0.f;
+                E[Y.sq + lane * (NVT + 1) + k] = mv_ + (k == lane ? dg_ : 0.f);
+              }
+            }
             float Wn = w0 + w1 + w2 + w3 + w4 + w5, A1 = cmu * (w0 - w1), A2 = cmu * (w2 - w3), B1 = cmu * cmu * (w0 + w1), B2 = cmu * cmu * (w2 + w3);
             const float A3 = cmut * (w4 - w5), B3 = cmut * cmut * (w4 + w5);
             SYNC();
@@ -2133,16 +2144,21 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
         x = __shfl(xp, act ? NVS - 1 - lane : lane);
       } else {
       if (refactor) {
-        const int dd = lane < nv ? lane : 0;
-        const int based = (dd * (dd + 1)) / 2;
-        const float diag_add = (phase == 2 && !RK4) ? h * M.dof_damping[dd] : 0.f;
+        if (phase == 0) {          // Newton: the buffer already holds M + the diagonal terms + J^T D J (see the assembly above)
+          const int ll_ = lane < NVT ? lane : 0;
 #pragma unroll
-        for (int k = 0; k < NVT; k++) {
-          float mv;
-          if constexpr (MROW) mv = (k <= lane) ? mrow[k] : 0.f;                                      // lower row of M (zero for lanes >= nv)
-          else mv = (lane < nv && k <= lane) ? Mp[based + (k <= dd ? k : 0)] : 0.f;
-          float hv = (phase == 0 && lane < nv) ? E[Y.sq + lane * (NVT + 1) + k] : 0.f;              // J^T D J (active rows)
-          r[k] = (lane < nv) ? mv + hv + (k == lane ? diag_add : 0.f) : (k == lane ? 1.f : 0.f);
+          for (int k = 0; k < NVT; k++) r[k] = lane < NVT ? E[Y.sq + ll_ * (NVT + 1) + k] : 0.f;
+        } else {                   // unconstrained / Euler solves of the instantiations without a tree-sparse path: M (+ h D)
+          const int dd = lane < nv ? lane : 0;
+          const int based = (dd * (dd + 1)) / 2;
+          const float diag_add = (phase == 2 && !RK4) ? h * M.dof_damping[dd] : 0.f;
+#pragma unroll
+          for (int k = 0; k < NVT; k++) {
+            float mv;
+            if constexpr (MROW) mv = (k <= lane) ? mrow[k] : 0.f;                                      // lower row of M (zero for lanes >= nv)
+            else mv = (lane < nv && k <= lane) ? Mp[based + (k <= dd ? k : 0)] : 0.f;
+            r[k] = (lane < nv) ? mv + (k == lane ? diag_add : 0.f) : (k == lane ? 1.f : 0.f);
+          }
         }
         SYNC();
         invd = chol_rows<NVT>(r, lane);
