@@ -91,6 +91,9 @@ struct DevModelW {
   unsigned int free_rot[2], free_j3[2];   // dofs that are rotations of a free joint / the first rotation of one
 };
 #define SEGR 9
+#ifndef MPR_TOL
+#define MPR_TOL 1e-8f      // portal refinement stops when the support plane gains less than this (metres)
+#endif
 
 __device__ __forceinline__ float rdlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ int rdlanei(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
@@ -1353,8 +1356,8 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
               if (((const int*)(E + Y.mprw))[4 * i] == p) { nw[0] = E[Y.mprw + 4 * i + 1]; nw[1] = E[Y.mprw + 4 * i + 2]; nw[2] = E[Y.mprw + 4 * i + 3]; have_nw = true; }
             }
             bool pen;
-            if constexpr (HF) pen = mpr_penetration_wl<true>(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr, E + Y.cJ + 12 * lane);
-            else pen = mpr_penetration(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr);
+            if constexpr (HF) pen = mpr_penetration_wl<true>(o1, o2, MPR_TOL, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr, E + Y.cJ + 12 * lane);
+            else pen = mpr_penetration(o1, o2, MPR_TOL, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr);
             if (pen) {
               dist = margin - depth;
               normalize3(dir);
@@ -1400,7 +1403,7 @@ __global__ void __launch_bounds__(64, WPE) step_kernel_w(const DevModel* __restr
             }
             // portal witnesses in per-lane LDS scratch: the contact-jacobian area of region X, not written before the rows stage
             // (TRK: a 1e-6 tolerance -- MuJoCo's ccd default -- was measured: narrow phase -15 %, but the one-substep qpos error p50 grows 2.7e-6 -> 1.5e-5)
-            if (mpr_penetration_wl<TRK ? 2 : 0>(o1, o2, 1e-8f, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr, E + Y.cJ + 12 * lane, MT)) {
+            if (mpr_penetration_wl<TRK ? 2 : 0>(o1, o2, MPR_TOL, 60, &depth, dir, pos, &nsup, have_nw ? nw : nullptr, E + Y.cJ + 12 * lane, MT)) {
               dist = margin - depth;
               normalize3(dir);
               mpr_hit = true; mpr_n[0] = dir[0]; mpr_n[1] = dir[1]; mpr_n[2] = dir[2];
