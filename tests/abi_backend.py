@@ -19,6 +19,8 @@ class Dims(C.Structure):
 
 class Backend:
     def __init__(self, lib_path, device):
+        if os.path.abspath(lib_path) == os.path.abspath(HIP_LIB):
+            capi.lib()          # (lets torch load its bundled HIP runtime first: two HIP runtimes in one process do not share the device, see capi.lib)
         self.L = C.CDLL(lib_path)
         self.device = device
         L = self.L

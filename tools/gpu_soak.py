@@ -10,6 +10,8 @@ from myosuite_mjx_amd.envs import BatchedMyoEnv
 PLAN = [("myoHandPoseRandom-v0", 4096, 20000), ("myoHandReachRandom-v0", 4096, 5000), ("myoLegWalk-v0", 4096, 10000),
         ("myoLegRoughTerrainWalk-v0", 4096, 5000), ("myoLegStairTerrainWalk-v0", 4096, 3000), ("myoHandObjHoldRandom-v0", 4096, 5000),
         ("myoFingerPoseRandom-v0", 4096, 10000), ("myoElbowPose1D6MExoFixed-v0", 4096, 10000)]
+SCALE = int(os.environ.get("SOAK_SCALE", 1))      # multiplies every step count (the committed run: SOAK_SCALE=4)
+PLAN = [(e, B, n * SCALE) for e, B, n in PLAN]
 out = []
 mode = capi.BENCH_OBS | capi.BENCH_FRESH_ACTIONS | capi.BENCH_AUTORESET
 for env_id, B, steps in PLAN:
@@ -35,7 +37,7 @@ for env_id, B, steps in PLAN:
 try:
     import torch
     from myosuite_mjx_amd.track import TrackEnv
-    B, steps = 4096, 2000
+    B, steps = 4096, 2000 * SCALE
     tenv = TrackEnv(num_envs=B, seed=1, autoreset=True)
     tenv.reset()
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -57,7 +59,7 @@ try:
            "final_state_finite": ok_finite, "final_act_in_01": True}
     print(json.dumps(rec), flush=True)
     out.append(rec)
-    # every MyoDM object: MyoHand<Object>Random-v0 at 2048 envs x 300 env steps (random actions, auto-reset, TimeLimit 50)
+    # every MyoDM object: MyoHand<Object>Random-v0 at 2048 envs x 300 (x SOAK_SCALE) env steps (random actions, auto-reset, TimeLimit 50)
     from myosuite_mjx_amd import envs as _envs
     import myosuite_mjx_amd as myo
     tot, flagged, nonfinite, t0 = 0, {}, [], time.time()
@@ -65,7 +67,7 @@ try:
         env = myo.make(f"MyoHand{obj.title()}Random-v0", num_envs=2048, seed=2, autoreset=True)
         env.reset()
         fl = np.zeros(2048, np.int64)
-        for k in range(300):
+        for k in range(300 * SCALE):
             obs, rew, term, trunc, info = env.step(torch.rand((2048, env.act_dim), device="cuda", generator=g) * 2 - 1)
             if (k + 1) % 100 == 0:
                 fl |= env.status().astype(np.int64)
@@ -73,7 +75,7 @@ try:
             nonfinite.append(obj)
         if (fl != 0).any():
             flagged[obj] = {f"bit{b}": int(((fl >> b) & 1).sum()) for b in range(5) if ((fl >> b) & 1).any()}
-        tot += 2048 * 300
+        tot += 2048 * 300 * SCALE
         del env
     rec = {"env": "MyoDM TrackEnv, all %d objects (MyoHand<Object>Random-v0)" % len(_envs.MYODM_OBJECTS), "envs": 2048, "env_steps": tot, "seconds": round(time.time() - t0, 2),
            "objects_with_flagged_envs": flagged, "objects_with_non_finite_output": nonfinite}
